@@ -1,0 +1,165 @@
+/*
+ * ts2d.h -- C ABI of the MI355X-native 2D differentiable triangle rasterizer (libts2d.so).
+ *
+ * This is the drop-in boundary for the hot path of GaodeRender/triangle-splatting's
+ * `diff_triangle_rasterization_2D` extension ("R2D" = submodules/diff-triangle-rasterization-2D in
+ * the reference tree).  Every entry point takes plain device pointers and sizes (no torch types);
+ * the caller owns all memory, including the three opaque state buffers that the reference keeps in
+ * torch uint8 tensors (geometryBuffer / binningBuffer / imageBuffer,
+ * R2D/src/extension_interface.cu:126-128).  All kernels are enqueued on the HIP stream passed in
+ * (`stream` is a hipStream_t; NULL = the null stream).
+ *
+ * What each entry point replaces in the reference:
+ *
+ *   ts2d_forward_bin      -> first half of Rasterizer::forward: preprocessCUDA + InclusiveSum + the
+ *                            D2H read of num_rendered         (R2D/src/rasterizer.cu:116-193)
+ *   ts2d_forward_render   -> second half: duplicateWithKeys + SortPairs + identifyTileRanges +
+ *                            FORWARD::renderCUDA              (R2D/src/rasterizer.cu:195-266)
+ *   ts2d_backward         -> Rasterizer::backward: BACKWARD::renderCUDA + BACKWARD::preprocessCUDA
+ *                                                             (R2D/src/rasterizer.cu:269-358)
+ *   ts2d_*_state_bytes    -> BaseDataBuffer::requiredSize     (R2D/src/param_struct.h:36-40)
+ *
+ * Together, forward_bin + forward_render are what `rasterizeTrianglesForward`
+ * (R2D/src/extension_interface.cu:19-152, pybind name `rasterize_triangles`, R2D/ext.cpp:6) calls, and
+ * ts2d_backward is what `rasterizeTrianglesBackward` (:154-260, `rasterize_triangles_backward`,
+ * R2D/ext.cpp:8) calls.  The split of forward into two calls exists because the caller must size the
+ * binning buffer from num_rendered, exactly like the reference's resize at rasterizer.cu:195.
+ *
+ * Return value: TS2D_OK (0) or a TS2D_ERR_* code; ts2d_last_error() returns a thread-local,
+ * human-readable message for the last failing call.  Error behaviour mirrors the reference's
+ * AT_ERROR checks (extension_interface.cu:53-81): bad shapes / C > 3 / gamma < 0 -> TS2D_ERR_INVALID.
+ *
+ * Matrix convention (unchanged from the reference): viewmatrix / projmatrix are 16 floats, element
+ * [col*4+row] of the usual column-vector matrix, i.e. the row-major storage of the transposed
+ * matrices built by src/diff_recon/utils/camera.py:112-114; see R2D/src/auxiliary.h:40-58.
+ */
+#ifndef TS2D_H
+#define TS2D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TS2D_OK 0
+#define TS2D_ERR_INVALID 1 /* argument validation failed (reference: AT_ERROR) */
+#define TS2D_ERR_HIP 2     /* a HIP runtime call or kernel failed */
+#define TS2D_ERR_CAPACITY 3 /* a caller-provided buffer is too small */
+
+#define TS2D_FLAG_BACK_CULLING 0x1u /* R2D settings.back_culling */
+#define TS2D_FLAG_RICH_INFO 0x2u    /* R2D settings.rich_info: depth, normal, contrib_sum/max + their grads */
+#define TS2D_FLAG_DEBUG 0x4u        /* R2D settings.debug: synchronise + check after every kernel (auxiliary.h:358-367) */
+#define TS2D_FLAG_USE_SHS 0x8u      /* colour from SH coefficients (extension_interface.cu:44) instead of `feature` */
+
+#define TS2D_MAX_CHANNELS 3 /* R2D/src/config.h:3 */
+#define TS2D_TILE 16        /* R2D/src/config.h:4-5 (BLOCK_X = BLOCK_Y = 16) */
+
+/* CameraInfo, R2D/src/param_struct.h:127-136.  All pointers are device pointers. */
+typedef struct ts2d_camera
+{
+    int32_t width, height;
+    float tan_fovx, tan_fovy;
+    const float *viewmatrix; /* 16 floats */
+    const float *projmatrix; /* 16 floats */
+    const float *campos;     /* 3 floats */
+} ts2d_camera;
+
+/* GeometryInfo, R2D/src/param_struct.h:138-153.  All pointers are device pointers. */
+typedef struct ts2d_geometry
+{
+    int32_t P;         /* number of triangles */
+    int32_t sh_degree; /* active SH degree D, 0..3 */
+    int32_t M;         /* SH coefficients stored per triangle ((max_degree+1)^2); 0 in feature mode */
+    int32_t C;         /* colour channels: 3 in SH mode, feature.size(1) <= 3 otherwise */
+    float gamma;
+    float scale_modifier; /* accepted and ignored, like the reference (param_struct.h:147) */
+    float background_depth;
+    const float *background; /* C floats */
+    const float *vertex;     /* P*3*3 floats, world space */
+    const float *shs;        /* P*M*3 floats (SH mode) or NULL */
+    const float *feature;    /* P*C floats (feature mode) or NULL */
+    const float *opacity;    /* P floats */
+} ts2d_geometry;
+
+/* ForwardOutput, R2D/src/param_struct.h:155-166.  depth/normal/contrib_* may be NULL without RICH_INFO.
+ * Every element of every non-NULL output is written by the library (no pre-zeroing needed). */
+typedef struct ts2d_forward_out
+{
+    float *out_feature;  /* C*H*W */
+    float *depth;        /* H*W */
+    float *normal;       /* 3*H*W */
+    float *contrib_sum;  /* P */
+    float *contrib_max;  /* P */
+} ts2d_forward_out;
+
+/* LossInput, R2D/src/param_struct.h:176-181. */
+typedef struct ts2d_loss_grads
+{
+    const float *dL_dout_feature; /* C*H*W */
+    const float *dL_dout_depth;   /* H*W   (RICH_INFO only) */
+    const float *dL_dout_normal;  /* 3*H*W (RICH_INFO only) */
+} ts2d_loss_grads;
+
+/* BackwardOutput, R2D/src/param_struct.h:183-190.  Every element is written by the library. */
+typedef struct ts2d_backward_out
+{
+    float *dL_dvertex;   /* P*3*3 */
+    float *dL_dcenter2D; /* P*2 */
+    float *dL_dshs;      /* P*M*3 (SH mode; may be NULL otherwise) */
+    float *dL_dfeature;  /* P*C: dL/dfeature, or dL/d(rgb) in SH mode like the reference (rasterizer.cu:333) */
+    float *dL_dopacity;  /* P */
+} ts2d_backward_out;
+
+/* The three opaque state buffers (private layout) + the backward scratch. */
+typedef struct ts2d_state
+{
+    void *geometry; size_t geometry_bytes; /* >= ts2d_geometry_state_bytes(P) */
+    void *binning;  size_t binning_bytes;  /* >= ts2d_binning_state_bytes(N, W, H) */
+    void *image;    size_t image_bytes;    /* >= ts2d_image_state_bytes(W, H) */
+} ts2d_state;
+
+const char *ts2d_version(void);
+const char *ts2d_last_error(void);
+
+size_t ts2d_geometry_state_bytes(int32_t P);
+size_t ts2d_binning_state_bytes(int64_t num_rendered, int32_t width, int32_t height);
+size_t ts2d_image_state_bytes(int32_t width, int32_t height);
+size_t ts2d_backward_scratch_bytes(int32_t P);
+
+/* Per-triangle preprocess + prefix sum.  Writes radii[P] and the geometry state, then blocks on
+ * `stream` once to return num_rendered (the reference's cudaMemcpy at rasterizer.cu:191). */
+int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii,
+                     const ts2d_state *state, int64_t *num_rendered, void *stream);
+
+/* Key emission, (tile, depth) sort, tile ranges and the per-pixel blend.  Fully asynchronous. */
+int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t num_rendered,
+                        const ts2d_state *state, const ts2d_forward_out *out, void *stream);
+
+/* Backward.  `scratch` is >= ts2d_backward_scratch_bytes(P) bytes of device memory (zeroed by the
+ * library).  Fully asynchronous. */
+int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t num_rendered,
+                  const int32_t *radii, const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch,
+                  size_t scratch_bytes, const ts2d_backward_out *out, void *stream);
+
+/* Test/diagnostic access to the private state: copies field `field` into host memory `dst`
+ * (dst_bytes must be large enough), synchronising `stream`.  Fields:
+ *   0 screen verts (P*6 f32: v1.xy v2.xy v3.xy)   1 area2 (P f32)       2 normal_view (P*3 f32)
+ *   3 v_depth (P*3 f32)   4 depth key (P f32)      5 rgb (P*3 f32)       6 clamped (P u8, bits 0..2)
+ *   7 point_offsets (P u32)  8 tiles_touched (P u32)  9 rect (P*4 u32: minx miny maxx maxy)
+ *   10 sorted keys (N u64)   11 sorted triangle ids (N u32)   12 ranges (T*2 u32)
+ *   13 n_contrib (H*W u32)   14 final_T (H*W f32)   15 unsorted keys (N u64)  16 unsorted ids (N u32) */
+int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t num_rendered, int32_t width, int32_t height,
+                          int32_t field, void *dst, size_t dst_bytes, void *stream);
+
+/* Timing hook used by bench.py: when enabled, ts2d_forward_render / ts2d_backward bracket each kernel
+ * with HIP events on `stream`; ts2d_profile_read copies out (name, total_ms, launches) rows. */
+void ts2d_profile_enable(int on);
+void ts2d_profile_reset(void);
+int ts2d_profile_read(int32_t index, char *name, size_t name_bytes, double *total_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TS2D_H */

@@ -1,0 +1,94 @@
+"""Shared helpers for the parity tests: run one scene through the CPU oracle and through the HIP path
+(via the drop-in Python package, i.e. through the C ABI), and compare."""
+from __future__ import annotations
+
+import numpy as np
+
+import synthetic
+from oracle import ts2d_oracle as O
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    d = np.linalg.norm((a - b).ravel())
+    n = np.linalg.norm(b.ravel())
+    return d / n if n > 0 else d
+
+
+def oracle_forward(s, rich_info=True, back_culling=False, use_feature=False):
+    shs = None if use_feature else s["shs"]
+    feature = s["feature"] if use_feature else None
+    n, img, radii, depth, normal, csum, cmax, st = O.rasterize_triangles(
+        s["image_width"], s["image_height"], s["tanfovx"], s["tanfovy"], s["viewmatrix"], s["projmatrix"], s["campos"],
+        s["sh_degree"], s["gamma"], s["scale_modifier"], s["background_depth"], s["background"], s["vertex"], shs,
+        feature, s["opacity"], back_culling, rich_info)
+    return dict(num_rendered=n, out_feature=img, radii=radii, depth=depth, normal=normal, contrib_sum=csum,
+                contrib_max=cmax, state=st)
+
+
+def oracle_backward(s, fwd, rich_info=True, use_feature=False):
+    shs = None if use_feature else s["shs"]
+    feature = s["feature"] if use_feature else None
+    dv, dc, dsh, df, dop = O.rasterize_triangles_backward(
+        s["tanfovx"], s["tanfovy"], s["viewmatrix"], s["projmatrix"], s["campos"], s["sh_degree"], s["gamma"],
+        s["scale_modifier"], s["background_depth"], s["background"], s["vertex"], shs, feature, s["opacity"],
+        fwd["radii"], fwd["state"], s["dL_dout_feature"], s.get("dL_dout_depth"), s.get("dL_dout_normal"), rich_info)
+    return dict(dL_dvertex=dv, dL_dcenter2D=dc, dL_dshs=dsh, dL_dfeature=df, dL_dopacity=dop)
+
+
+def hip_settings(s, rich_info=True, back_culling=False, debug=False, device="cuda"):
+    import torch
+    from diff_triangle_rasterization_2D import TriangleRasterizationSettings
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return TriangleRasterizationSettings(
+        image_width=s["image_width"], image_height=s["image_height"], tanfovx=s["tanfovx"], tanfovy=s["tanfovy"],
+        viewmatrix=t(s["viewmatrix"]), projmatrix=t(s["projmatrix"]), campos=t(s["campos"]), sh_degree=s["sh_degree"],
+        gamma=s["gamma"], scale_modifier=s["scale_modifier"], background_depth=s["background_depth"],
+        background=t(s["background"]), back_culling=back_culling, rich_info=rich_info, debug=debug)
+
+
+def hip_forward_backward(s, rich_info=True, back_culling=False, use_feature=False, backward=True, device="cuda", debug=False):
+    """Runs the HIP path through the drop-in autograd module.  Returns numpy outputs + grads + raw state."""
+    import torch
+    from diff_triangle_rasterization_2D import TriangleRasterizer, _C
+
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    rs = hip_settings(s, rich_info, back_culling, debug, device)
+    vertex = t(s["vertex"]).requires_grad_(True)
+    opacity = t(s["opacity"]).requires_grad_(True)
+    center2D = torch.zeros((vertex.shape[0], 2), device=device, requires_grad=True)
+    shs = feature = None
+    if use_feature:
+        feature = t(s["feature"]).requires_grad_(True)
+    else:
+        shs = t(s["shs"]).requires_grad_(True)
+    out = TriangleRasterizer(rs)(vertex, center2D, opacity, shs=shs, feature=feature)
+    res = dict(out_feature=out[0].detach().cpu().numpy(), radii=out[1].cpu().numpy())
+    if rich_info:
+        res.update(depth=out[2].detach().cpu().numpy(), normal=out[3].detach().cpu().numpy(),
+                   contrib_sum=out[4].cpu().numpy(), contrib_max=out[5].cpu().numpy())
+    node = out[0].grad_fn
+    res["num_rendered"] = node.num_rendered
+    saved = node.saved_tensors
+    res["buffers"] = saved[5:8]
+    if backward:
+        loss = (out[0] * t(s["dL_dout_feature"])).sum()
+        if rich_info:
+            loss = loss + (out[2] * t(s["dL_dout_depth"])).sum() + (out[3] * t(s["dL_dout_normal"])).sum()
+        loss.backward()
+        res.update(dL_dvertex=vertex.grad.cpu().numpy(), dL_dcenter2D=center2D.grad.cpu().numpy(),
+                   dL_dopacity=opacity.grad.cpu().numpy())
+        if use_feature:
+            res["dL_dfeature"] = feature.grad.cpu().numpy()
+        else:
+            res["dL_dshs"] = shs.grad.cpu().numpy()
+    return res
+
+
+def hip_state(res, s, name):
+    from diff_triangle_rasterization_2D import _C
+    g, b, im = res["buffers"]
+    P = s["vertex"].shape[0]
+    return _C.debug_read_state(name, P, res["num_rendered"], s["image_width"], s["image_height"], g, b, im).numpy()

@@ -1,0 +1,81 @@
+"""Builds libts2d.so (the C-ABI HIP library of include/ts2d.h) for gfx950 with hipcc, in-tree.
+
+    python triangle-splatting_amd/build.py [--force] [--verbose]
+
+Output: triangle-splatting_amd/diff_triangle_rasterization_2D/libts2d.so (git-ignored, travels with gpurun).
+hipcc cross-compiles without a GPU.  Per-file flags matter:
+  * preprocess.hip is built with -ffp-contract=off (bit-comparable integer state, see the file header);
+  * render.hip uses the default fast contraction and hardware float atomics (-munsafe-fp-atomics).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "diff_triangle_rasterization_2D")
+OBJ_DIR = os.path.join(HERE, "build")
+LIB = os.path.join(OUT_DIR, "libts2d.so")
+ARCH = "gfx950"
+
+COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
+          "-Wno-unused-result", "-DNDEBUG"]
+SOURCES = {
+    "preprocess.hip": ["-ffp-contract=off"],
+    "binning.hip": [],
+    "render.hip": [],
+    "api.hip": [],
+}
+HEADERS = ["ts2d_common.h", "ts2d_math.h", os.path.join("..", "..", "include", "ts2d.h")]
+
+
+def hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: libts2d.so cannot be built (no CPU fallback exists by design)")
+
+
+def _newest_header() -> float:
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc = hipcc()
+    hdr_t = max(_newest_header(), os.path.getmtime(os.path.abspath(__file__)))
+    jobs, objs = [], []
+    for src, extra in SOURCES.items():
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+            jobs.append([cc, *COMMON, *extra, "-c", s, "-o", o])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    if jobs or force or not os.path.exists(LIB):
+        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(a.force, a.verbose))

@@ -1,0 +1,414 @@
+// api.hip -- the C ABI of libts2d.so (include/ts2d.h): validation, state carving, host sequencing.
+//
+// Host sequencing mirrors Rasterizer::forward / Rasterizer::backward (R2D/src/rasterizer.cu:101-267, 269-358)
+// and the argument checks of rasterizeTrianglesForward / Backward (R2D/src/extension_interface.cu:53-81,193-199).
+// Differences by design: everything is enqueued on the caller's stream (the reference uses the legacy default
+// stream), the only host synchronisation is the num_rendered read-back, outputs need no pre-zeroing, and the
+// zero-filled scratch of the backward is one 64-byte-per-triangle gradient record array.
+#include "../../include/ts2d.h"
+#include "ts2d_common.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace
+{
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define TS_HIP(expr)                                                                                                   \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) return fail(TS2D_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));              \
+    } while (0)
+
+// R2D's CHECK_CUDA(debug) (auxiliary.h:358-367): with the debug flag, synchronise and surface errors per kernel.
+#define TS_CHECK(flags, stream, what)                                                                                  \
+    do                                                                                                                 \
+    {                                                                                                                  \
+        hipError_t e_ = hipGetLastError();                                                                             \
+        if (e_ == hipSuccess && ((flags)&TS2D_FLAG_DEBUG)) e_ = hipStreamSynchronize(stream);                          \
+        if (e_ != hipSuccess) return fail(TS2D_ERR_HIP, "%s: %s", what, hipGetErrorString(e_));                        \
+    } while (0)
+
+// ---- optional per-kernel timing with HIP events on the caller's stream ---------------------------------------
+struct ProfRow { std::string name; double ms = 0; int64_t launches = 0; };
+struct ProfPending { int row; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRow> g_prof_rows;
+std::vector<ProfPending> g_prof_pending;
+std::vector<hipEvent_t> g_prof_free;
+
+struct ProfScope
+{
+    hipStream_t s;
+    int row = -1;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(const char *name, hipStream_t stream) : s(stream)
+    {
+        if (!g_prof_on) return;
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        for (size_t i = 0; i < g_prof_rows.size(); i++)
+            if (g_prof_rows[i].name == name) row = (int)i;
+        if (row < 0) { g_prof_rows.push_back({name, 0, 0}); row = (int)g_prof_rows.size() - 1; }
+        auto get = [&]() { hipEvent_t e; if (!g_prof_free.empty()) { e = g_prof_free.back(); g_prof_free.pop_back(); } else (void)hipEventCreate(&e); return e; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope()
+    {
+        if (row < 0) return;
+        (void)hipEventRecord(b, s);
+        std::lock_guard<std::mutex> lk(g_prof_mu);
+        g_prof_pending.push_back({row, a, b});
+    }
+};
+
+void prof_drain()
+{
+    for (auto &p : g_prof_pending)
+    {
+        float ms = 0;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess)
+        {
+            g_prof_rows[p.row].ms += ms;
+            g_prof_rows[p.row].launches += 1;
+        }
+        g_prof_free.push_back(p.a);
+        g_prof_free.push_back(p.b);
+    }
+    g_prof_pending.clear();
+}
+
+int validate(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags)
+{
+    if (!cam || !geom) return fail(TS2D_ERR_INVALID, "null camera/geometry");
+    if (cam->width <= 0 || cam->height <= 0) return fail(TS2D_ERR_INVALID, "image size must be positive");
+    if (cam->width > 65535 * TS_TILE || cam->height > 65535 * TS_TILE) return fail(TS2D_ERR_INVALID, "image too large");
+    if (geom->P < 0) return fail(TS2D_ERR_INVALID, "P must be >= 0");
+    if (geom->C > TS2D_MAX_CHANNELS) // extension_interface.cu:65-68
+        return fail(TS2D_ERR_INVALID, "feature's num_channels can't be larger than MAX_CHANNELS");
+    if (geom->C < 1) return fail(TS2D_ERR_INVALID, "need at least one colour channel");
+    if (geom->gamma < 0.0f) return fail(TS2D_ERR_INVALID, "gamma must be larger than 0"); // extension_interface.cu:73-76
+    if (flags & TS2D_FLAG_USE_SHS)
+    {
+        if (geom->C != 3) return fail(TS2D_ERR_INVALID, "SH mode renders 3 channels");
+        if (geom->sh_degree < 0 || geom->sh_degree > 3) return fail(TS2D_ERR_INVALID, "sh_degree must be in 0..3");
+        if ((geom->sh_degree + 1) * (geom->sh_degree + 1) > geom->M)
+            return fail(TS2D_ERR_INVALID, "shs holds fewer coefficients than sh_degree needs");
+        if (geom->P > 0 && !geom->shs) return fail(TS2D_ERR_INVALID, "shs is null");
+    }
+    else if (geom->P > 0 && !geom->feature) return fail(TS2D_ERR_INVALID, "feature is null");
+    if (geom->P > 0 && (!geom->vertex || !geom->opacity)) return fail(TS2D_ERR_INVALID, "vertex/opacity is null");
+    if (!cam->viewmatrix || !cam->projmatrix || !cam->campos || !geom->background)
+        return fail(TS2D_ERR_INVALID, "camera matrices / background are null");
+    return TS2D_OK;
+}
+
+PreprocessArgs make_pre(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags)
+{
+    PreprocessArgs a;
+    a.W = cam->width; a.H = cam->height; a.P = geom->P; a.D = geom->sh_degree; a.M = geom->M; a.C = geom->C;
+    a.grid_x = (cam->width + TS_TILE - 1) / TS_TILE; a.grid_y = (cam->height + TS_TILE - 1) / TS_TILE;
+    a.rich_info = flags & TS2D_FLAG_RICH_INFO; a.use_shs = flags & TS2D_FLAG_USE_SHS;
+    a.back_culling = flags & TS2D_FLAG_BACK_CULLING;
+    a.tan_fovx = cam->tan_fovx; a.tan_fovy = cam->tan_fovy;
+    a.viewmatrix = cam->viewmatrix; a.projmatrix = cam->projmatrix; a.campos = cam->campos;
+    a.vertex = geom->vertex; a.shs = geom->shs; a.feature = geom->feature; a.opacity = geom->opacity;
+    return a;
+}
+
+RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags)
+{
+    RenderArgs r;
+    r.W = cam->width; r.H = cam->height; r.C = geom->C;
+    r.grid_x = (cam->width + TS_TILE - 1) / TS_TILE; r.grid_y = (cam->height + TS_TILE - 1) / TS_TILE;
+    r.gamma = geom->gamma; r.background_depth = geom->background_depth;
+    r.background = geom->background;
+    r.rich_info = flags & TS2D_FLAG_RICH_INFO;
+    return r;
+}
+} // namespace
+
+extern "C" {
+
+const char *ts2d_version(void) { return "ts2d 0.1 (gfx950)"; }
+const char *ts2d_last_error(void) { return g_err.c_str(); }
+
+size_t ts2d_geometry_state_bytes(int32_t P)
+{
+    GeometryStateView v;
+    return ts_carve_geometry(nullptr, P, v);
+}
+size_t ts2d_binning_state_bytes(int64_t N, int32_t W, int32_t H)
+{
+    BinningStateView v;
+    return ts_carve_binning(nullptr, N, W, H, v);
+}
+size_t ts2d_image_state_bytes(int32_t W, int32_t H)
+{
+    ImageStateView v;
+    return ts_carve_image(nullptr, W, H, v);
+}
+size_t ts2d_backward_scratch_bytes(int32_t P) { return (size_t)(P > 0 ? P : 0) * TS_GRAD_FLOATS * sizeof(float) + TS_ALIGN; }
+
+int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii,
+                     const ts2d_state *state, int64_t *num_rendered, void *stream)
+{
+    if (int rc = validate(cam, geom, flags)) return rc;
+    if (!state || !num_rendered) return fail(TS2D_ERR_INVALID, "null state/num_rendered");
+    hipStream_t s = (hipStream_t)stream;
+    *num_rendered = 0;
+    const int P = geom->P;
+    if (P == 0) return TS2D_OK; // extension_interface.cu:130
+    if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
+    if (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P))
+        return fail(TS2D_ERR_CAPACITY, "geometry state buffer too small: %zu < %zu", state->geometry_bytes,
+                    ts2d_geometry_state_bytes(P));
+    GeometryStateView g;
+    ts_carve_geometry((char *)state->geometry, P, g);
+    const PreprocessArgs a = make_pre(cam, geom, flags);
+    {
+        ProfScope ps("preprocess_fwd", s);
+        ts_launch_preprocess_fwd(a, radii, g, s);
+    }
+    TS_CHECK(flags, s, "preprocess_fwd");
+    {
+        ProfScope ps("scan", s);
+        TS_HIP(ts_scan_offsets(g, P, s));
+    }
+    TS_CHECK(flags, s, "scan");
+    uint32_t n = 0;
+    TS_HIP(hipMemcpyAsync(&n, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    TS_HIP(hipStreamSynchronize(s)); // the reference's blocking cudaMemcpy, rasterizer.cu:191
+    *num_rendered = (int64_t)(int32_t)n;
+    return TS2D_OK;
+}
+
+int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t N,
+                        const ts2d_state *state, const ts2d_forward_out *out, void *stream)
+{
+    if (int rc = validate(cam, geom, flags)) return rc;
+    if (!state || !out || !out->out_feature) return fail(TS2D_ERR_INVALID, "null state/output");
+    const bool rich = flags & TS2D_FLAG_RICH_INFO;
+    if (rich && (!out->depth || !out->normal || (geom->P > 0 && (!out->contrib_sum || !out->contrib_max))))
+        return fail(TS2D_ERR_INVALID, "rich_info outputs are null");
+    hipStream_t s = (hipStream_t)stream;
+    const int P = geom->P, W = cam->width, H = cam->height;
+    if (N < 0) return fail(TS2D_ERR_INVALID, "num_rendered < 0");
+    if (!state->image || state->image_bytes < ts2d_image_state_bytes(W, H))
+        return fail(TS2D_ERR_CAPACITY, "image state buffer too small");
+    if (N > 0 && (!state->binning || state->binning_bytes < ts2d_binning_state_bytes(N, W, H)))
+        return fail(TS2D_ERR_CAPACITY, "binning state buffer too small");
+    if (P > 0 && (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P)))
+        return fail(TS2D_ERR_CAPACITY, "geometry state buffer too small");
+    GeometryStateView g{};
+    BinningStateView b{};
+    ImageStateView im{};
+    if (P > 0) ts_carve_geometry((char *)state->geometry, P, g);
+    if (N > 0) ts_carve_binning((char *)state->binning, N, W, H, b);
+    ts_carve_image((char *)state->image, W, H, im);
+    const RenderArgs r = make_render(cam, geom, flags);
+    const int ntiles = r.grid_x * r.grid_y;
+
+    TS_HIP(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)ntiles, s)); // rasterizer.cu:223
+    if (rich && P > 0)
+    {
+        TS_HIP(hipMemsetAsync(out->contrib_sum, 0, sizeof(float) * (size_t)P, s));
+        TS_HIP(hipMemsetAsync(out->contrib_max, 0, sizeof(float) * (size_t)P, s));
+    }
+    if (N > 0)
+    {
+        {
+            ProfScope ps("emit_keys", s);
+            ts_launch_emit_keys(P, r.grid_x, g, b, s);
+        }
+        TS_CHECK(flags, s, "emit_keys");
+        {
+            ProfScope ps("sort_pairs", s);
+            TS_HIP(ts_sort_pairs(b, N, 32 + ts_higher_msb((uint32_t)ntiles), s)); // rasterizer.cu:210-218
+        }
+        TS_CHECK(flags, s, "sort_pairs");
+        {
+            ProfScope ps("tile_ranges", s);
+            ts_launch_tile_ranges(N, b, im, s);
+        }
+        TS_CHECK(flags, s, "tile_ranges");
+    }
+    {
+        ProfScope ps("render_fwd", s);
+        ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+    }
+    TS_CHECK(flags, s, "render_fwd");
+    return TS2D_OK;
+}
+
+int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t N, const int32_t *radii,
+                  const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch, size_t scratch_bytes,
+                  const ts2d_backward_out *out, void *stream)
+{
+    if (int rc = validate(cam, geom, flags)) return rc;
+    if (!state || !loss || !out) return fail(TS2D_ERR_INVALID, "null state/loss/output");
+    const bool rich = flags & TS2D_FLAG_RICH_INFO, use_shs = flags & TS2D_FLAG_USE_SHS;
+    hipStream_t s = (hipStream_t)stream;
+    const int P = geom->P, W = cam->width, H = cam->height;
+    if (P == 0) return TS2D_OK; // extension_interface.cu:242
+    if (!loss->dL_dout_feature || (rich && (!loss->dL_dout_depth || !loss->dL_dout_normal)))
+        return fail(TS2D_ERR_INVALID, "upstream gradients are null");
+    if (!out->dL_dvertex || !out->dL_dcenter2D || !out->dL_dfeature || !out->dL_dopacity || (use_shs && !out->dL_dshs))
+        return fail(TS2D_ERR_INVALID, "gradient outputs are null");
+    if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
+    if (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P)) return fail(TS2D_ERR_CAPACITY, "backward scratch too small");
+    if (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P) || !state->image ||
+        state->image_bytes < ts2d_image_state_bytes(W, H) ||
+        (N > 0 && (!state->binning || state->binning_bytes < ts2d_binning_state_bytes(N, W, H))))
+        return fail(TS2D_ERR_CAPACITY, "state buffers too small");
+    GeometryStateView g{};
+    BinningStateView b{};
+    ImageStateView im{};
+    ts_carve_geometry((char *)state->geometry, P, g);
+    if (N > 0) ts_carve_binning((char *)state->binning, N, W, H, b);
+    ts_carve_image((char *)state->image, W, H, im);
+    const RenderArgs r = make_render(cam, geom, flags);
+    float *grad_rec = (float *)ts_align_up((size_t)scratch);
+
+    {
+        ProfScope ps("zero_grad_records", s);
+        TS_HIP(hipMemsetAsync(grad_rec, 0, sizeof(float) * TS_GRAD_FLOATS * (size_t)P, s)); // rasterizer.cu:290-300
+    }
+    if (N > 0)
+    {
+        ProfScope ps("render_bwd", s);
+        ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
+    }
+    TS_CHECK(flags, s, "render_bwd");
+    {
+        ProfScope ps("preprocess_bwd", s);
+        const PreprocessArgs a = make_pre(cam, geom, flags);
+        ts_launch_preprocess_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, out->dL_dshs, out->dL_dfeature,
+                                 out->dL_dopacity, s);
+    }
+    TS_CHECK(flags, s, "preprocess_bwd");
+    return TS2D_OK;
+}
+
+int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t W, int32_t H, int32_t field, void *dst,
+                          size_t dst_bytes, void *stream)
+{
+    if (!state || !dst) return fail(TS2D_ERR_INVALID, "null state/dst");
+    hipStream_t s = (hipStream_t)stream;
+    GeometryStateView g{};
+    BinningStateView b{};
+    ImageStateView im{};
+    if (P > 0 && state->geometry) ts_carve_geometry((char *)state->geometry, P, g);
+    if (N > 0 && state->binning) ts_carve_binning((char *)state->binning, N, W, H, b);
+    if (state->image) ts_carve_image((char *)state->image, W, H, im);
+    const int gx = (W + TS_TILE - 1) / TS_TILE, gy = (H + TS_TILE - 1) / TS_TILE;
+    const void *src = nullptr;
+    size_t bytes = 0;
+    std::vector<float> recs;
+    auto need_recs = [&]() -> int {
+        recs.resize((size_t)P * TS_REC_FLOATS);
+        if (P == 0) return TS2D_OK;
+        TS_HIP(hipMemcpyAsync(recs.data(), g.rec, recs.size() * sizeof(float), hipMemcpyDeviceToHost, s));
+        TS_HIP(hipStreamSynchronize(s));
+        return TS2D_OK;
+    };
+    auto from_recs = [&](std::initializer_list<int> cols, bool area) -> int {
+        if (int rc = need_recs()) return rc;
+        const size_t n = area ? 1 : cols.size();
+        if (dst_bytes < (size_t)P * n * sizeof(float)) return fail(TS2D_ERR_CAPACITY, "dst too small");
+        float *o = (float *)dst;
+        for (int i = 0; i < P; i++)
+        {
+            const float *r = &recs[(size_t)i * TS_REC_FLOATS];
+            if (area) o[i] = (r[2] - r[0]) * (r[5] - r[1]) - (r[3] - r[1]) * (r[4] - r[0]);
+            else { size_t c = 0; for (int col : cols) o[(size_t)i * n + c++] = r[col]; }
+        }
+        return TS2D_OK;
+    };
+    switch (field)
+    {
+    case 0: return from_recs({0, 1, 2, 3, 4, 5}, false);
+    case 1: return from_recs({}, true);
+    case 2: return from_recs({10, 11, 12}, false);
+    case 3: return from_recs({13, 14, 15}, false);
+    case 5: return from_recs({7, 8, 9}, false);
+    case 4: src = g.depth; bytes = (size_t)P * 4; break;
+    case 6: src = g.clamped; bytes = (size_t)P; break;
+    case 7: src = g.offsets; bytes = (size_t)P * 4; break;
+    case 8: src = g.tiles_touched; bytes = (size_t)P * 4; break;
+    case 9:
+    {
+        std::vector<uint2> rc((size_t)P);
+        if (dst_bytes < (size_t)P * 16) return fail(TS2D_ERR_CAPACITY, "dst too small");
+        if (P > 0)
+        {
+            TS_HIP(hipMemcpyAsync(rc.data(), g.rect, (size_t)P * sizeof(uint2), hipMemcpyDeviceToHost, s));
+            TS_HIP(hipStreamSynchronize(s));
+        }
+        uint32_t *o = (uint32_t *)dst;
+        for (int i = 0; i < P; i++)
+        {
+            o[4 * i] = rc[i].x & 0xffffu; o[4 * i + 1] = rc[i].x >> 16;
+            o[4 * i + 2] = rc[i].y & 0xffffu; o[4 * i + 3] = rc[i].y >> 16;
+        }
+        return TS2D_OK;
+    }
+    case 10: src = b.keys; bytes = (size_t)N * 8; break;
+    case 11: src = b.vals; bytes = (size_t)N * 4; break;
+    case 12: src = im.ranges; bytes = (size_t)gx * gy * 8; break;
+    case 13: src = im.n_contrib; bytes = (size_t)W * H * 4; break;
+    case 14: src = im.final_T; bytes = (size_t)W * H * 4; break;
+    case 15: src = b.keys_unsorted; bytes = (size_t)N * 8; break;
+    case 16: src = b.vals_unsorted; bytes = (size_t)N * 4; break;
+    default: return fail(TS2D_ERR_INVALID, "unknown field %d", field);
+    }
+    if (dst_bytes < bytes) return fail(TS2D_ERR_CAPACITY, "dst too small");
+    if (bytes)
+    {
+        TS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+        TS_HIP(hipStreamSynchronize(s));
+    }
+    return TS2D_OK;
+}
+
+void ts2d_profile_enable(int on)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+void ts2d_profile_reset(void)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain();
+    g_prof_rows.clear();
+}
+int ts2d_profile_read(int32_t index, char *name, size_t name_bytes, double *total_ms, int64_t *launches)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    prof_drain();
+    if (index < 0 || (size_t)index >= g_prof_rows.size()) return TS2D_ERR_INVALID;
+    const ProfRow &r = g_prof_rows[index];
+    if (name && name_bytes) { strncpy(name, r.name.c_str(), name_bytes - 1); name[name_bytes - 1] = 0; }
+    if (total_ms) *total_ms = r.ms;
+    if (launches) *launches = r.launches;
+    return TS2D_OK;
+}
+} // extern "C"

@@ -1,0 +1,161 @@
+// ts2d_common.h -- private layout of the three opaque state buffers and kernel launch prototypes.
+//
+// The reference bump-allocates SoA arrays inside torch uint8 tensors (R2D/src/param_struct.h:11-125).
+// The layout here is free to differ (the buffers are opaque to callers) and is designed for MI355X:
+//   * one 64-byte "render record" per triangle (a full 64 B sector of a 128 B HBM/L2 line) so that the
+//     per-instance gather in the blend kernels is exactly four dwordx4 loads from one line;
+//   * one 64-byte gradient record per triangle so that a wave's reduced gradients land with a single
+//     16-lane global_atomic_add_f32 on one line;
+//   * tile rectangles packed to 8 bytes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#define TS_TILE 16
+#define TS_ALIGN 256
+
+// Render record (16 floats = 64 B), written by preprocess_fwd, read by render_fwd / render_bwd.
+//   [0..5]  v1.x v1.y v2.x v2.y v3.x v3.y   screen-space vertices        (reference: GeometryState.v{1,2,3}_2D)
+//   [6]     opacity                          copied from the input         (reference: gathered separately)
+//   [7..9]  r g b                            SH colour or feature          (reference: GeometryState.rgb / feature)
+//   [10..12] normal_view.xyz                 rich_info only                (reference: GeometryState.normal_view)
+//   [13..15] v_depth.xyz                     rich_info only                (reference: GeometryState.v_depth)
+// area2 is not stored: it is recomputed as cross(v2-v1, v3-v1), the expression the reference stores.
+#define TS_REC_FLOATS 16
+
+// Gradient record (16 floats = 64 B), accumulated by render_bwd, consumed by preprocess_bwd.
+//   [0..5] dL/dv{1,2,3}_2D   [6] dL/dopacity   [7..9] dL/drgb   [10..12] dL/dnormal_view   [13..15] dL/dv_depth
+#define TS_GRAD_FLOATS 16
+
+struct GeometryStateView
+{
+    float4 *rec;             // P * 4 float4
+    float *depth;            // P   sort key (centroid view-space z)
+    uint32_t *tiles_touched; // P
+    uint32_t *offsets;       // P   inclusive prefix sum of tiles_touched
+    uint2 *rect;             // P   x = minx | miny << 16, y = maxx | maxy << 16
+    uint8_t *clamped;        // P   bit c set when colour channel c was clamped at 0
+    void *scan_temp;
+    size_t scan_temp_bytes;
+};
+
+struct BinningStateView
+{
+    uint64_t *keys_unsorted; // N
+    uint64_t *keys;          // N
+    uint32_t *vals_unsorted; // N
+    uint32_t *vals;          // N   triangle id per sorted instance
+    void *sort_temp;
+    size_t sort_temp_bytes;
+};
+
+struct ImageStateView
+{
+    uint2 *ranges;       // T   [start, end) of each tile in the sorted list
+    uint32_t *n_contrib; // W*H
+    float *final_T;      // W*H
+};
+
+static inline size_t ts_align_up(size_t v) { return (v + TS_ALIGN - 1) & ~(size_t)(TS_ALIGN - 1); }
+
+template <typename T>
+static inline void ts_carve(char *&p, T *&out, size_t count)
+{
+    p = (char *)ts_align_up((size_t)p);
+    out = (T *)p;
+    p += count * sizeof(T);
+}
+
+size_t ts_scan_temp_bytes(int32_t P);
+size_t ts_sort_temp_bytes(int64_t N, int end_bit);
+
+static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView &v)
+{
+    char *p = base;
+    size_t n = (size_t)(P > 0 ? P : 0);
+    ts_carve(p, v.rec, n * 4);
+    ts_carve(p, v.depth, n);
+    ts_carve(p, v.tiles_touched, n);
+    ts_carve(p, v.offsets, n);
+    ts_carve(p, v.rect, n);
+    ts_carve(p, v.clamped, n);
+    v.scan_temp_bytes = ts_scan_temp_bytes(P);
+    char *t;
+    ts_carve(p, t, v.scan_temp_bytes);
+    v.scan_temp = t;
+    return (size_t)(p - base) + TS_ALIGN;
+}
+
+static inline int ts_higher_msb(uint32_t n) // R2D/src/rasterizer.cu:20-35 (same result: bits needed above n's msb search)
+{
+    uint32_t msb = sizeof(n) * 4, step = msb;
+    while (step > 1)
+    {
+        step /= 2;
+        if (n >> msb) msb += step;
+        else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return (int)msb;
+}
+
+static inline size_t ts_carve_binning(char *base, int64_t N, int32_t W, int32_t H, BinningStateView &v)
+{
+    char *p = base;
+    size_t n = (size_t)(N > 0 ? N : 0);
+    int gx = (W + TS_TILE - 1) / TS_TILE, gy = (H + TS_TILE - 1) / TS_TILE;
+    ts_carve(p, v.keys_unsorted, n);
+    ts_carve(p, v.keys, n);
+    ts_carve(p, v.vals_unsorted, n);
+    ts_carve(p, v.vals, n);
+    v.sort_temp_bytes = ts_sort_temp_bytes(N, 32 + ts_higher_msb((uint32_t)(gx * gy)));
+    char *t;
+    ts_carve(p, t, v.sort_temp_bytes);
+    v.sort_temp = t;
+    return (size_t)(p - base) + TS_ALIGN;
+}
+
+static inline size_t ts_carve_image(char *base, int32_t W, int32_t H, ImageStateView &v)
+{
+    char *p = base;
+    int gx = (W + TS_TILE - 1) / TS_TILE, gy = (H + TS_TILE - 1) / TS_TILE;
+    ts_carve(p, v.ranges, (size_t)gx * gy);
+    ts_carve(p, v.n_contrib, (size_t)W * H);
+    ts_carve(p, v.final_T, (size_t)W * H);
+    return (size_t)(p - base) + TS_ALIGN;
+}
+
+// ---- kernel launchers (defined in the .hip files) -------------------------------------------------
+struct PreprocessArgs
+{
+    int W, H, P, D, M, C;
+    int grid_x, grid_y;
+    bool rich_info, use_shs, back_culling;
+    float tan_fovx, tan_fovy;
+    const float *viewmatrix, *projmatrix, *campos;
+    const float *vertex, *shs, *feature, *opacity;
+};
+
+void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s);
+hipError_t ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);
+void ts_launch_emit_keys(int P, int grid_x, const GeometryStateView &g, const BinningStateView &b, hipStream_t s);
+hipError_t ts_sort_pairs(const BinningStateView &b, int64_t N, int end_bit, hipStream_t s);
+void ts_launch_tile_ranges(int64_t N, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
+
+struct RenderArgs
+{
+    int W, H, C, grid_x, grid_y;
+    float gamma, background_depth;
+    const float *background; // C floats, device
+    bool rich_info;
+};
+void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
+                          const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
+                          float *contrib_sum, float *contrib_max, hipStream_t s);
+void ts_launch_render_bwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
+                          const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
+                          const float *dL_dout_normal, float *grad_rec, hipStream_t s);
+void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
+                              const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
+                              float *dL_dfeature, float *dL_dopacity, hipStream_t s);

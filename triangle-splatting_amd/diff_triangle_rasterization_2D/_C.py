@@ -1,0 +1,310 @@
+"""`_C` of the drop-in `diff_triangle_rasterization_2D` package: the two entry points the reference exports
+through pybind (R2D/ext.cpp:6-8), here bound with ctypes onto the C ABI of libts2d.so (include/ts2d.h).
+
+    rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos,
+                        sh_degree, gamma, scale_modifier, background_depth, background, vertex, shs, feature,
+                        opacity, back_culling, rich_info, debug)
+        -> (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max,
+            geometryBuffer, binningBuffer, imageBuffer)          # R2D/src/extension_interface.cu:19-152
+    rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma,
+                        scale_modifier, background_depth, background, vertex, shs, feature, opacity,
+                        num_rendered, radii, geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature,
+                        dL_dout_depth, dL_dout_normal, rich_info, debug)
+        -> (dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity)   # extension_interface.cu:154-260
+
+Same positional signatures, same argument checks and RuntimeErrors, same ownership (the callee allocates every
+output on vertex.device; the three uint8 buffers are opaque).  torch is used only for device memory (caching
+allocator) and the current stream.  There is NO CPU or eager fallback: if libts2d.so is missing or the tensors
+are not on a HIP device, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libts2d.so")
+
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"{_LIB_PATH} not found: build it with `python triangle-splatting_amd/build.py` (hipcc, gfx950). "
+        "The MI355X rasterizer has no CPU fallback."
+    )
+_lib = C.CDLL(_LIB_PATH)
+
+FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS = 1, 2, 4, 8
+MAX_CHANNELS = 3
+
+_fp = C.c_void_p
+
+
+class _Camera(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("tan_fovx", C.c_float), ("tan_fovy", C.c_float),
+                ("viewmatrix", _fp), ("projmatrix", _fp), ("campos", _fp)]
+
+
+class _Geometry(C.Structure):
+    _fields_ = [("P", C.c_int32), ("sh_degree", C.c_int32), ("M", C.c_int32), ("C", C.c_int32),
+                ("gamma", C.c_float), ("scale_modifier", C.c_float), ("background_depth", C.c_float),
+                ("background", _fp), ("vertex", _fp), ("shs", _fp), ("feature", _fp), ("opacity", _fp)]
+
+
+class _ForwardOut(C.Structure):
+    _fields_ = [("out_feature", _fp), ("depth", _fp), ("normal", _fp), ("contrib_sum", _fp), ("contrib_max", _fp)]
+
+
+class _LossGrads(C.Structure):
+    _fields_ = [("dL_dout_feature", _fp), ("dL_dout_depth", _fp), ("dL_dout_normal", _fp)]
+
+
+class _BackwardOut(C.Structure):
+    _fields_ = [("dL_dvertex", _fp), ("dL_dcenter2D", _fp), ("dL_dshs", _fp), ("dL_dfeature", _fp),
+                ("dL_dopacity", _fp)]
+
+
+class _State(C.Structure):
+    _fields_ = [("geometry", _fp), ("geometry_bytes", C.c_size_t), ("binning", _fp), ("binning_bytes", C.c_size_t),
+                ("image", _fp), ("image_bytes", C.c_size_t)]
+
+
+_lib.ts2d_version.restype = C.c_char_p
+_lib.ts2d_last_error.restype = C.c_char_p
+_lib.ts2d_geometry_state_bytes.restype = C.c_size_t
+_lib.ts2d_geometry_state_bytes.argtypes = [C.c_int32]
+_lib.ts2d_binning_state_bytes.restype = C.c_size_t
+_lib.ts2d_binning_state_bytes.argtypes = [C.c_int64, C.c_int32, C.c_int32]
+_lib.ts2d_image_state_bytes.restype = C.c_size_t
+_lib.ts2d_image_state_bytes.argtypes = [C.c_int32, C.c_int32]
+_lib.ts2d_backward_scratch_bytes.restype = C.c_size_t
+_lib.ts2d_backward_scratch_bytes.argtypes = [C.c_int32]
+_lib.ts2d_forward_bin.restype = C.c_int
+_lib.ts2d_forward_bin.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, _fp, C.POINTER(_State),
+                                  C.POINTER(C.c_int64), _fp]
+_lib.ts2d_forward_render.restype = C.c_int
+_lib.ts2d_forward_render.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, C.c_int64,
+                                     C.POINTER(_State), C.POINTER(_ForwardOut), _fp]
+_lib.ts2d_backward.restype = C.c_int
+_lib.ts2d_backward.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, C.c_int64, _fp,
+                               C.POINTER(_State), C.POINTER(_LossGrads), _fp, C.c_size_t, C.POINTER(_BackwardOut), _fp]
+_lib.ts2d_debug_read_state.restype = C.c_int
+_lib.ts2d_debug_read_state.argtypes = [C.POINTER(_State), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp,
+                                       C.c_size_t, _fp]
+_lib.ts2d_profile_enable.argtypes = [C.c_int]
+_lib.ts2d_profile_read.restype = C.c_int
+_lib.ts2d_profile_read.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+
+
+def version() -> str:
+    return _lib.ts2d_version().decode()
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        raise RuntimeError(f"{what}: {_lib.ts2d_last_error().decode()} (ts2d error {rc})")
+
+
+def _ptr(t):
+    if t is None or t.numel() == 0:
+        return None
+    return t.data_ptr()
+
+
+def _use_shs(shs: torch.Tensor, feature: torch.Tensor) -> bool:
+    # R2D/src/extension_interface.cu:44
+    return feature.dim() <= 1 or (feature.size(0) == 0 and shs.size(0) > 0)
+
+
+def _require_device(vertex: torch.Tensor):
+    if not vertex.is_cuda:
+        raise RuntimeError(
+            "diff_triangle_rasterization_2D (MI355X build) needs tensors on a HIP device; there is no CPU fallback"
+        )
+
+
+def _contiguous_or_raise(*tensors):
+    # extension_interface.cu:77-81, 193-199
+    for t in tensors:
+        if t is not None and not t.is_contiguous():
+            raise RuntimeError("input tensors must be contiguous")
+
+
+def _f32_or_raise(*tensors):
+    for t in tensors:
+        if t is not None and t.numel() > 0 and t.dtype != torch.float32:
+            raise RuntimeError("expected scalar type Float")  # what data_ptr<float>() raises in the reference
+
+
+def _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
+             background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M):
+    cam = _Camera(int(W), int(H), float(tan_fovx), float(tan_fovy), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos))
+    geom = _Geometry(int(vertex.size(0)), int(sh_degree), int(M), int(Cn), float(gamma), float(scale_modifier),
+                     float(background_depth), _ptr(background), _ptr(vertex), _ptr(shs) if use_shs else None,
+                     None if use_shs else _ptr(feature), _ptr(opacity))
+    return cam, geom
+
+
+def _state(geometryBuffer, binningBuffer, imageBuffer) -> _State:
+    return _State(_ptr(geometryBuffer), geometryBuffer.numel(), _ptr(binningBuffer), binningBuffer.numel(),
+                  _ptr(imageBuffer), imageBuffer.numel())
+
+
+def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma,
+                        scale_modifier, background_depth, background, vertex, shs, feature, opacity, back_culling,
+                        rich_info, debug):
+    P = vertex.size(0)
+    H, W = int(image_height), int(image_width)
+    use_shs = _use_shs(shs, feature)
+    Cn = 3 if use_shs else feature.size(1)
+    M = shs.size(1) if (shs.size(0) != 0 and shs.dim() >= 2) else 0
+
+    # R2D/src/extension_interface.cu:53-81
+    if vertex.dim() != 3 or vertex.size(1) != 3 or vertex.size(2) != 3:
+        raise RuntimeError("vertex must have dimensions (num_points, 3, 3)")
+    if not use_shs and feature.dim() != 2:
+        raise RuntimeError("feature must have dimensions (num_points, num_channels)")
+    if use_shs and shs.dim() != 3:
+        raise RuntimeError("shs must have dimensions (num_points, (1 + sh_degree) ** 2, 3)")
+    if Cn > MAX_CHANNELS:
+        raise RuntimeError("feature's num_channels can't be larger than MAX_CHANNELS")
+    if Cn != background.size(0):
+        raise RuntimeError("background must have the same number of channels as feature")
+    if gamma < 0.0:
+        raise RuntimeError("gamma must be larger than 0")
+    _contiguous_or_raise(viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity)
+    _require_device(vertex)
+    _f32_or_raise(viewmatrix, projmatrix, campos, background, vertex, shs if use_shs else None,
+                  None if use_shs else feature, opacity)
+
+    dev = vertex.device
+    f32 = dict(device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):  # OptionalCUDAGuard, extension_interface.cu:83
+        stream = torch.cuda.current_stream().cuda_stream
+        # every element of these is written by the library (ts2d.h), so no zero-fill pass is needed when P > 0
+        alloc = torch.zeros if P == 0 else torch.empty
+        out_feature = alloc((Cn, H, W), **f32)
+        radii = alloc((P,), device=dev, dtype=torch.int32)
+        if rich_info:
+            depth = alloc((H, W), **f32)
+            normal = alloc((3, H, W), **f32)
+            contrib_sum = alloc((P,), **f32)
+            contrib_max = alloc((P,), **f32)
+        else:
+            depth = torch.empty((0,), **f32)
+            normal = torch.empty((0,), **f32)
+            contrib_sum = torch.empty((0,), **f32)
+            contrib_max = torch.empty((0,), **f32)
+        u8 = dict(device=dev, dtype=torch.uint8)
+        if P == 0:  # extension_interface.cu:130: zero images, empty state
+            return (0, out_feature, radii, depth, normal, contrib_sum, contrib_max, torch.empty((0,), **u8),
+                    torch.empty((0,), **u8), torch.empty((0,), **u8))
+
+        flags = ((FLAG_BACK_CULLING if back_culling else 0) | (FLAG_RICH_INFO if rich_info else 0) |
+                 (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0))
+        cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
+                             background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
+        geometryBuffer = torch.empty((_lib.ts2d_geometry_state_bytes(P),), **u8)
+        imageBuffer = torch.empty((_lib.ts2d_image_state_bytes(W, H),), **u8)
+        binningBuffer = torch.empty((0,), **u8)
+        st = _state(geometryBuffer, binningBuffer, imageBuffer)
+        n = C.c_int64(0)
+        _check(_lib.ts2d_forward_bin(C.byref(cam), C.byref(geom), flags, _ptr(radii), C.byref(st), C.byref(n), stream),
+               "rasterize_triangles")
+        num_rendered = int(n.value)
+        binningBuffer = torch.empty((_lib.ts2d_binning_state_bytes(num_rendered, W, H),), **u8)
+        st = _state(geometryBuffer, binningBuffer, imageBuffer)
+        out = _ForwardOut(_ptr(out_feature), _ptr(depth), _ptr(normal), _ptr(contrib_sum), _ptr(contrib_max))
+        _check(_lib.ts2d_forward_render(C.byref(cam), C.byref(geom), flags, num_rendered, C.byref(st), C.byref(out), stream),
+               "rasterize_triangles")
+    return (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max, geometryBuffer, binningBuffer,
+            imageBuffer)
+
+
+def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
+                                 background_depth, background, vertex, shs, feature, opacity, num_rendered, radii,
+                                 geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
+                                 dL_dout_normal, rich_info, debug):
+    P = vertex.size(0)
+    H, W = dL_dout_feature.size(1), dL_dout_feature.size(2)  # extension_interface.cu:182-183
+    use_shs = _use_shs(shs, feature)
+    Cn = 3 if use_shs else feature.size(1)
+    M = shs.size(1) if (shs.size(0) != 0 and shs.dim() >= 2) else 0
+    _contiguous_or_raise(viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity, radii, geometryBuffer,
+                         binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth, dL_dout_normal)
+    _require_device(vertex)
+    _f32_or_raise(dL_dout_feature, dL_dout_depth, dL_dout_normal)
+
+    dev = vertex.device
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        alloc = torch.zeros if P == 0 else torch.empty  # every element is written by the library when P > 0
+        opts = dict(device=dev, dtype=vertex.dtype)
+        dL_dvertex = alloc((P, 3, 3), **opts)
+        dL_dcenter2D = alloc((P, 2), **opts)
+        dL_dshs = alloc((P, M, 3), **opts) if use_shs else torch.zeros((P, M, 3), **opts)
+        dL_dfeature = alloc((P, Cn), **opts)
+        dL_dopacity = alloc((P, 1), **opts)
+        if P == 0:
+            return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
+        flags = ((FLAG_RICH_INFO if rich_info else 0) | (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0))
+        cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
+                             background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
+        st = _state(geometryBuffer, binningBuffer, imageBuffer)
+        loss = _LossGrads(_ptr(dL_dout_feature), _ptr(dL_dout_depth) if rich_info else None,
+                          _ptr(dL_dout_normal) if rich_info else None)
+        scratch = torch.empty((_lib.ts2d_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+        out = _BackwardOut(_ptr(dL_dvertex), _ptr(dL_dcenter2D), _ptr(dL_dshs), _ptr(dL_dfeature), _ptr(dL_dopacity))
+        _check(_lib.ts2d_backward(C.byref(cam), C.byref(geom), flags, int(num_rendered), _ptr(radii), C.byref(st),
+                                  C.byref(loss), _ptr(scratch), scratch.numel(), C.byref(out), stream),
+               "rasterize_triangles_backward")
+    return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
+
+
+# ---- diagnostics used by tests and bench.py (not part of the reference's surface) ---------------------------
+_FIELD_SPEC = {
+    "v_2D": (0, torch.float32, lambda P, N, T, HW: (P, 6)), "area2": (1, torch.float32, lambda P, N, T, HW: (P,)),
+    "normal_view": (2, torch.float32, lambda P, N, T, HW: (P, 3)), "v_depth": (3, torch.float32, lambda P, N, T, HW: (P, 3)),
+    "depth": (4, torch.float32, lambda P, N, T, HW: (P,)), "rgb": (5, torch.float32, lambda P, N, T, HW: (P, 3)),
+    "clamped": (6, torch.uint8, lambda P, N, T, HW: (P,)), "point_offsets": (7, torch.int32, lambda P, N, T, HW: (P,)),
+    "tiles_touched": (8, torch.int32, lambda P, N, T, HW: (P,)), "rect": (9, torch.int32, lambda P, N, T, HW: (P, 4)),
+    "keys": (10, torch.int64, lambda P, N, T, HW: (N,)), "vals": (11, torch.int32, lambda P, N, T, HW: (N,)),
+    "ranges": (12, torch.int32, lambda P, N, T, HW: (T, 2)), "n_contrib": (13, torch.int32, lambda P, N, T, HW: HW),
+    "final_T": (14, torch.float32, lambda P, N, T, HW: HW), "keys_unsorted": (15, torch.int64, lambda P, N, T, HW: (N,)),
+    "vals_unsorted": (16, torch.int32, lambda P, N, T, HW: (N,)),
+}
+
+
+def debug_read_state(name, P, num_rendered, W, H, geometryBuffer, binningBuffer, imageBuffer) -> torch.Tensor:
+    """Copies one private state array to a CPU tensor (see ts2d_debug_read_state in include/ts2d.h)."""
+    field, dtype, shape = _FIELD_SPEC[name]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    out = torch.empty(shape(P, num_rendered, T, (H, W)), dtype=dtype)
+    st = _state(geometryBuffer, binningBuffer, imageBuffer)
+    with torch.cuda.device(geometryBuffer.device):
+        stream = torch.cuda.current_stream().cuda_stream
+        _check(_lib.ts2d_debug_read_state(C.byref(st), P, num_rendered, W, H, field, out.data_ptr(),
+                                          out.numel() * out.element_size(), stream), "debug_read_state")
+    return out
+
+
+def profile_enable(on: bool):
+    _lib.ts2d_profile_enable(1 if on else 0)
+
+
+def profile_reset():
+    _lib.ts2d_profile_reset()
+
+
+def profile_read():
+    rows, i = [], 0
+    name = C.create_string_buffer(64)
+    ms, n = C.c_double(0), C.c_int64(0)
+    while _lib.ts2d_profile_read(i, name, 64, C.byref(ms), C.byref(n)) == 0:
+        rows.append((name.value.decode(), ms.value, n.value))
+        i += 1
+    return rows

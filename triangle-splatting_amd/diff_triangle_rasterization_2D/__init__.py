@@ -1,0 +1,141 @@
+"""MI355X-native drop-in for the reference's `diff_triangle_rasterization_2D` Python package.
+
+Public surface -- same names, field order, argument meaning and error behaviour as the reference module
+R2D/diff_triangle_rasterization_2D/__init__.py (R2D = submodules/diff-triangle-rasterization-2D):
+
+    TriangleRasterizationSettings   NamedTuple, the reference's 15 fields in the reference's order  (:28-46)
+    TriangleRasterizer              nn.Module with `.raster_settings` and
+                                    `.forward(vertex, center2D, opacity, shs=None, feature=None)`,
+                                    returning 2 or 6 tensors depending on rich_info                 (:167-187)
+    _RasterizeTriangles             the torch.autograd.Function behind it                           (:49-164)
+
+so src/diff_recon/renderer/triangle_renderer.py (the direct caller, :3-6, :38-57, :69-75) works unchanged.
+The native side is libts2d.so (hand-written HIP for gfx950, C ABI in include/ts2d.h) reached through `_C`;
+nothing here falls back to CPU or eager torch.
+
+Deliberate deviations from the reference module:
+  * FIX: the reference's backward raises NameError with rich_info=False because
+    grad_out_depth / grad_out_normal are never bound (:114-117, :141).  Here they are empty tensors.
+  * radii / contrib_sum / contrib_max are marked non-differentiable, and upstream gradients are made
+    contiguous instead of tripping the "input tensors must be contiguous" check.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import NamedTuple
+
+import torch
+import torch.nn as nn
+
+from . import _C
+
+
+class TriangleRasterizationSettings(NamedTuple):
+    image_width: int
+    image_height: int
+    tanfovx: float
+    tanfovy: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    campos: torch.Tensor
+    sh_degree: int
+    gamma: float
+    scale_modifier: float
+    background_depth: float
+    background: torch.Tensor
+    back_culling: bool
+    rich_info: bool
+    debug: bool
+
+
+@contextlib.contextmanager
+def _snapshot_on_error(tag: str, args: tuple, enabled: bool):
+    """settings.debug behaviour of the reference (:14-25): if the native call throws, a CPU copy of its
+    arguments is saved to snapshot_<tag>.dump for offline reproduction, then the error propagates."""
+    if not enabled:
+        yield
+        return
+    frozen = tuple(a.detach().cpu().clone() if isinstance(a, torch.Tensor) else a for a in args)
+    try:
+        yield
+    except Exception:
+        torch.save(frozen, f"snapshot_{tag}.dump")
+        print(f"\nAn error occured in {tag}. Writing snapshot_{tag}.dump for debugging.")
+        raise
+
+
+def _camera_and_geometry_args(rs: TriangleRasterizationSettings, background_depth: float) -> tuple:
+    """The ten settings-derived arguments that both native entry points share, in their positional order
+    (tan_fovx .. background; R2D/src/extension_interface.h:7-62)."""
+    return (
+        rs.tanfovx, rs.tanfovy,
+        rs.viewmatrix.contiguous(), rs.projmatrix.contiguous(), rs.campos.contiguous(),
+        rs.sh_degree, rs.gamma, rs.scale_modifier, background_depth, rs.background.contiguous(),
+    )
+
+
+class _RasterizeTriangles(torch.autograd.Function):
+    """autograd inputs: (vertex, center2D, shs, feature, opacity, raster_settings); center2D is a gradient
+    sink only and is never sent to the native side (reference :52-60, :156-164)."""
+
+    @staticmethod
+    def forward(ctx, vertex, center2D, shs, feature, opacity, raster_settings):
+        rs = raster_settings
+        # background_depth may arrive as a 0-dim device tensor (src/diff_recon/models/VanillaTS_model.py:623);
+        # pybind converts it to float in the reference, which is the same blocking read.
+        bg_depth = float(rs.background_depth)
+        native_args = (rs.image_width, rs.image_height) + _camera_and_geometry_args(rs, bg_depth) + (
+            vertex, shs, feature, opacity, rs.back_culling, rs.rich_info, rs.debug)
+        with _snapshot_on_error("rasterize_triangles", native_args, rs.debug):
+            (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max,
+             geometryBuffer, binningBuffer, imageBuffer) = _C.rasterize_triangles(*native_args)
+
+        ctx.raster_settings = rs
+        ctx.num_rendered = num_rendered
+        ctx.bg_depth = bg_depth
+        ctx.save_for_backward(vertex, shs, feature, opacity, radii, geometryBuffer, binningBuffer, imageBuffer)
+        if rs.rich_info:
+            ctx.mark_non_differentiable(radii, contrib_sum, contrib_max)
+            return out_feature, radii, depth, normal, contrib_sum, contrib_max
+        ctx.mark_non_differentiable(radii)
+        return out_feature, radii
+
+    @staticmethod
+    def backward(ctx, *grads_out):
+        rs = ctx.raster_settings
+        vertex, shs, feature, opacity, radii, geometryBuffer, binningBuffer, imageBuffer = ctx.saved_tensors
+        g_feature = grads_out[0]
+        if rs.rich_info:
+            g_depth, g_normal = grads_out[2], grads_out[3]
+        else:  # FIX of the reference's unbound names
+            g_depth = g_normal = torch.empty((0,), device=vertex.device, dtype=vertex.dtype)
+        native_args = _camera_and_geometry_args(rs, ctx.bg_depth) + (
+            vertex, shs, feature, opacity, ctx.num_rendered, radii, geometryBuffer, binningBuffer, imageBuffer,
+            g_feature.contiguous(), g_depth.contiguous(), g_normal.contiguous(), rs.rich_info, rs.debug)
+        with _snapshot_on_error("rasterize_triangles_backward", native_args, rs.debug):
+            g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(*native_args)
+        # The placeholder standing in for the unused one of shs/feature is a CPU `torch.Tensor([])`
+        # (reference :183-184) that never requires grad; hand autograd None for it.
+        if not ctx.needs_input_grad[2]:
+            g_shs = None
+        if not ctx.needs_input_grad[3]:
+            g_feat = None
+        return g_vertex, g_center2D, g_shs, g_feat, g_opacity, None
+
+
+class TriangleRasterizer(nn.Module):
+    def __init__(self, raster_settings: TriangleRasterizationSettings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, vertex, center2D, opacity, shs=None, feature=None):
+        if (shs is None) == (feature is None):
+            # same exception type and message as the reference (:180-181)
+            raise Exception("Please provide excatly one of either SHs or feature!")
+        placeholder = torch.Tensor([])  # stays on the CPU like the reference's; never dereferenced
+        return _RasterizeTriangles.apply(
+            vertex, center2D, placeholder if shs is None else shs, placeholder if feature is None else feature,
+            opacity, self.raster_settings)
+
+
+__all__ = ["TriangleRasterizationSettings", "TriangleRasterizer"]
