@@ -1,0 +1,218 @@
+#!/usr/bin/env python
+"""bench.py -- fwd+bwd throughput of the MI355X triangle rasterizer on BASELINE.json's headline workload.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one forward + one backward of the rasterizer over one view of the synthetic scene
+S(P=1M, 1920x1080, SH degree 3, rich_info=True) (SURVEY.md 8d / BASELINE.md 4), through the drop-in Python
+package, i.e. through the C ABI of libts2d.so.  Inputs are resident in HBM before the timed region.  With N > 1
+every rank renders its own view of the same triangles (image-parallel, weak scaling) and the per-triangle
+gradients are summed with one RCCL all-reduce inside the step.  Rank 0 prints ONE JSON line.
+
+Extra objects in the JSON line:
+  roofline     -- the dominant kernel's algorithmic bytes / its average duration (HIP events on the launch stream,
+                  recorded inside the timed region by libts2d's profile hook) against the 8 TB/s HBM peak.
+  cpu_baseline -- the CPU oracle (oracle/, OpenMP, all host cores) timed once on the same scene (N=1, rank 0 only).
+The oracle is used here only as the timed CPU baseline and to cross-check the image; it is never on the product path.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "triangle-splatting_amd")]
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def msb_bits(ntiles: int) -> int:
+    n, b = ntiles, 0
+    while n:
+        n >>= 1
+        b += 1
+    return b
+
+
+def algorithmic_bytes(P, N, W, H, D, ntiles):
+    """per-kernel algorithmic HBM bytes of one fwd+bwd step (rich_info, SH colour)."""
+    sh = 12 * (D + 1) ** 2
+    passes = -(-(32 + msb_bits(ntiles)) // 8)
+    k = {
+        "preprocess_fwd": P * (36 + sh + 99),
+        "scan": P * 8,
+        "emit_keys": P * 28 + N * 12,
+        "sort_pairs": N * 24 * passes,
+        "tile_ranges": N * 8,
+        "render_fwd": N * 72 + W * H * 36,
+        "render_bwd": N * 72 + W * H * 36 + P * 2 * 64,
+        "preprocess_bwd": P * (36 + sh + 3 + 4 + 48 + 12) + P * (36 + 8 + sh),
+    }
+    k["total"] = sum(k.values())
+    return k
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--triangles", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the rasterizer has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import synthetic
+    from diff_triangle_rasterization_2D import TriangleRasterizationSettings, TriangleRasterizer, _C
+    from diff_triangle_rasterization_2D.parallel import GradBucket
+
+    P, W, H, D = args.triangles, args.width, args.height, args.sh_degree
+    s = synthetic.scene(P, W, H, D, seed=42)
+    # one view per rank: same triangles, camera shifted sideways by a few world units per rank
+    cam = synthetic.camera(W, H)
+    if rank > 0:
+        view = cam["viewmatrix"].copy()
+        shift = np.array([7.0 * rank, -3.0 * rank, 0.0], np.float32)
+        view[3, :3] -= shift * np.array([-1, 1, -1], np.float32)  # translate the camera centre by `shift`
+        cam["viewmatrix"] = view
+        cam["projmatrix"] = (view @ synthetic.projection_matrix(cam["tanfovx"], cam["tanfovy"]).T).astype(np.float32)
+        cam["campos"] = np.array([0, 0, synthetic.CAM_DIST], np.float32) + shift
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs = TriangleRasterizationSettings(
+        image_width=W, image_height=H, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], viewmatrix=t(cam["viewmatrix"]),
+        projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]), sh_degree=D, gamma=1.0, scale_modifier=1.0,
+        background_depth=5000.0, background=t(s["background"]), back_culling=False, rich_info=True, debug=False)
+    raster = TriangleRasterizer(rs)
+    vertex = t(s["vertex"]).requires_grad_(True)
+    shs = t(s["shs"]).requires_grad_(True)
+    opacity = t(s["opacity"]).requires_grad_(True)
+    g_feat, g_depth, g_norm = t(s["dL_dout_feature"]), t(s["dL_dout_depth"]), t(s["dL_dout_normal"])
+    bucket = None
+    if world > 1:
+        bucket = GradBucket([vertex.shape, shs.shape, opacity.shape, torch.Size((P, 2))], dev)
+
+    state = {}
+
+    def step():
+        center2D = torch.zeros((P, 2), device=dev, requires_grad=True)  # like triangle_renderer.py:67
+        out = raster(vertex, center2D, opacity, shs=shs)
+        torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
+        if bucket is not None:
+            bucket.all_reduce([vertex.grad, shs.grad, opacity.grad, center2D.grad])
+        state["num_rendered"] = out[0].grad_fn.num_rendered
+        state["image"] = out[0]
+        vertex.grad = None
+        shs.grad = None
+        opacity.grad = None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    events = not args.no_kernel_events
+    if events:
+        _C.profile_reset()
+        _C.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if events:
+        _C.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    mpix_s = world * W * H / (elapsed / args.steps) / 1e6
+    N = int(state["num_rendered"])
+    ntiles = ((W + 15) // 16) * ((H + 15) // 16)
+    alg = algorithmic_bytes(P, N, W, H, D, ntiles)
+
+    result = {
+        "metric": "fwd+bwd Mpixels/sec @ 1M triangles, 1920x1080; achieved HBM GB/s",
+        "value": round(mpix_s, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
+                   "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N,
+                   "parallelism": f"image-parallel x{world}" + (", RCCL all-reduce of per-triangle grads" if world > 1 else ""),
+                   "algorithmic_bytes_per_step": alg["total"],
+                   "achieved_hbm_gbs_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9, 2),
+                   "hbm_roofline_frac_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
+    }
+
+    if rank == 0:
+        if events:
+            rows = _C.profile_read()
+            kernels = {name: {"avg_ms": ms / max(n, 1), "launches": n} for name, ms, n in rows}
+            result["kernels_avg_ms"] = {k: round(v["avg_ms"], 4) for k, v in kernels.items()}
+            dom = max((k for k in kernels if k in alg), key=lambda k: kernels[k]["avg_ms"])
+            ach = alg[dom] / (kernels[dom]["avg_ms"] * 1e-3) / 1e9
+            result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": None,
+                                  "algorithmic_bytes_per_launch": alg[dom],
+                                  "avg_launch_ms": round(kernels[dom]["avg_ms"], 4)}
+        else:
+            result["roofline"] = None
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(s, state["image"].detach().cpu().numpy())
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(s, hip_image):
+    """The CPU oracle (a port of the reference algorithm, OpenMP over tiles, all host cores) on the same scene:
+    one fwd+bwd.  The full 1M-triangle / 1080p step is ~15-20 s on 8 cores, which is the bounded sample."""
+    from oracle import ts2d_oracle as O
+    tests_dir = os.path.join(ROOT, "tests")
+    if tests_dir not in sys.path:
+        sys.path.insert(0, tests_dir)
+    import helpers
+
+    cores = O.num_threads()
+    t0 = time.perf_counter()
+    of = helpers.oracle_forward(s, rich_info=True)
+    t1 = time.perf_counter()
+    helpers.oracle_backward(s, of, rich_info=True)
+    t2 = time.perf_counter()
+    W, H = s["image_width"], s["image_height"]
+    return {"value": round(W * H / (t2 - t0) / 1e6, 4), "unit": "Mpix/s", "cores": cores, "kind": "port",
+            "sample": f"1 full fwd+bwd step of the same scene ({s['vertex'].shape[0]} triangles, {W}x{H}); "
+                      f"fwd {t1 - t0:.2f} s + bwd {t2 - t1:.2f} s on {cores} OpenMP threads",
+            "image_rel_l2_hip_vs_oracle": float(helpers.rel_l2(hip_image, of["out_feature"]))}
+
+
+if __name__ == "__main__":
+    main()
