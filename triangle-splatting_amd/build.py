@@ -28,7 +28,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-a
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "render.hip": [],
+    "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "api.hip": [],
 }
 HEADERS = ["ts2d_common.h", "ts2d_math.h", os.path.join("..", "..", "include", "ts2d.h")]

@@ -83,22 +83,26 @@ __device__ __forceinline__ void swap16(float &a, float &b) // odd rows of a <-> 
     b = __uint_as_float(r[1]);
 }
 
-// Transpose-reduce: 16 values per lane x 64 lanes -> each lane returns the complete 64-lane sum of ONE of the
-// 16 values; the four lanes of a quad hold the same value and the 16 quads hold the 16 different values.  Which
-// value a lane ends up with is discovered once per wave by reducing indicator inputs (see slot_of_lane()).
-__device__ __forceinline__ float reduce16(float (&v)[16], int lane)
+// Transpose-reduce: 16 values per lane x 64 lanes -> each lane returns the complete 64-lane reduction of ONE of
+// the 16 values; the four lanes of a quad hold the same value and the 16 quads hold the 16 different values.
+// Which value a lane ends up with is discovered once per wave by reducing indicator inputs (slot_of_lane()).
+struct OpAdd { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
+struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+
+template <typename Op>
+__device__ __forceinline__ float reduce16(float (&v)[16], int lane, Op op)
 {
 #pragma unroll
     for (int i = 0; i < 8; i++) // 64 -> 32 lanes per value, two values per register
     {
         swap32(v[2 * i], v[2 * i + 1]);
-        v[i] = v[2 * i] + v[2 * i + 1];
+        v[i] = op(v[2 * i], v[2 * i + 1]);
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) // 32 -> 16 lanes per value, one value per row
     {
         swap16(v[2 * i], v[2 * i + 1]);
-        v[i] = v[2 * i] + v[2 * i + 1];
+        v[i] = op(v[2 * i], v[2 * i + 1]);
     }
     const bool b3 = lane & 8, b2 = lane & 4;
 #pragma unroll
@@ -106,18 +110,19 @@ __device__ __forceinline__ float reduce16(float (&v)[16], int lane)
     {
         const float own = b3 ? v[2 * i + 1] : v[2 * i];
         const float oth = b3 ? v[2 * i] : v[2 * i + 1];
-        v[i] = own + dpp<DPP_ROR8>(oth);
+        v[i] = op(own, dpp<DPP_ROR8>(oth));
     }
     {
         const float own = b2 ? v[1] : v[0]; // 8 -> 4 lanes per value
         const float oth = b2 ? v[0] : v[1];
-        v[0] = own + dpp<DPP_HALF_MIRROR>(oth);
+        v[0] = op(own, dpp<DPP_HALF_MIRROR>(oth));
     }
     float r = v[0];
-    r += dpp<DPP_XOR1>(r);
-    r += dpp<DPP_XOR2>(r);
+    r = op(r, dpp<DPP_XOR1>(r));
+    r = op(r, dpp<DPP_XOR2>(r));
     return r;
 }
+__device__ __forceinline__ float reduce16(float (&v)[16], int lane) { return reduce16(v, lane, OpAdd()); }
 
 __device__ __forceinline__ int slot_of_lane(int lane)
 {
@@ -182,7 +187,16 @@ __device__ __forceinline__ EntrySetup entry_setup(float v1x, float v1y, float v2
     const float pad = 0.05f;
     const float bminx = cx + fminf(fminf(e1x, e2x), e3x) - pad, bmaxx = cx + fmaxf(fmaxf(e1x, e2x), e3x) + pad;
     const float bminy = cy + fminf(fminf(e1y, e2y), e3y) - pad, bmaxy = cy + fmaxf(fmaxf(e1y, e2y), e3y) + pad;
-    s.overlap = (E > 0.0f) && bminx <= 7.0f && bmaxx >= 0.0f && bminy <= 7.0f && bmaxy >= 0.0f;
+    // Separating-axis test of the E-scaled triangle against the quadrant's 8x8 sample box: box axes (the bbox
+    // above) plus the three edge normals.  ecc <= E  <=>  min_i a_i >= (1 - E) / 3, and each a_i is affine in q,
+    // so its maximum over the box is C_i + max(0, 7 A_i) + max(0, 7 B_i).
+    const float m = (1.0f - E) * (1.0f / 3.0f);
+    const float A3 = -s.A1 - s.A2, B3 = -s.B1 - s.B2, C3 = 1.0f - s.C1 - s.C2;
+    const float max1 = s.C1 + fmaxf(0.0f, 7.0f * s.A1) + fmaxf(0.0f, 7.0f * s.B1);
+    const float max2 = s.C2 + fmaxf(0.0f, 7.0f * s.A2) + fmaxf(0.0f, 7.0f * s.B2);
+    const float max3 = C3 + fmaxf(0.0f, 7.0f * A3) + fmaxf(0.0f, 7.0f * B3);
+    s.overlap = (E > 0.0f) && bminx <= 7.0f && bmaxx >= 0.0f && bminy <= 7.0f && bmaxy >= 0.0f && max1 >= m &&
+                max2 >= m && max3 >= m;
     return s;
 }
 
@@ -210,6 +224,35 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, anx = 0.0f, any_ = 0.0f, anz = 0.0f, ad = 0.0f;
     bool done = !inside;
     uint32_t last = (uint32_t)len; // a pixel that never saturates examines the whole list (forward.cu:296-297)
+
+    // contrib_sum / contrib_max (forward.cu:323-324): the reference issues two global atomics per (pixel, triangle).
+    // Here each contributing entry parks its 64 per-pixel contributions in a wave-private LDS slot; every 16
+    // entries the 16 x 64 block is reduced by two transpose-reduce passes (sum, max) and leaves as ONE 16-lane
+    // atomic add + ONE 16-lane atomic max.  (LDS float atomics are not an option: ds_add_f32 measures ~190
+    // cycles per wave instruction on gfx950, see profiles/r01_lds_atomic_microbench.txt.)
+    __shared__ float stage[4][16][64];
+    int staged = 0;                 // entries parked so far (wave-uniform)
+    uint32_t staged_ids = 0;        // lane k holds the triangle id of parked entry k
+    const int slot = RICH ? slot_of_lane(lane) : 0;
+    auto flush = [&]() {
+        float vs[16], vm[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++)
+        {
+            const float x = (i < staged) ? stage[wave][i][lane] : 0.0f;
+            vs[i] = x;
+            vm[i] = x;
+        }
+        const float rs = reduce16(vs, lane, OpAdd());
+        const float rm = reduce16(vm, lane, OpMax());
+        const uint32_t gid = (uint32_t)__shfl((int)staged_ids, slot);
+        if ((lane & 3) == 0 && slot < staged)
+        {
+            unsafeAtomicAdd(contrib_sum + gid, rs);
+            atomicMax((int *)contrib_max + gid, __float_as_int(rm)); // rm > 0: int order == float order
+        }
+        staged = 0;
+    };
 
     for (int base = 0; base < len; base += 64)
     {
@@ -242,40 +285,30 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
             const float pw = GAMMA1 ? ecc * ecc : pow_nonneg(ecc, g2);
             const float alpha = fminf(0.99f, bcast(r1.z, j) * fast_exp(-0.5f * pw)); // forward.cu:311-312
             hit = hit && alpha >= 1.0f / 255.0f;                                       // forward.cu:313
-            const unsigned long long hits = __ballot(hit);
-            if (hits == 0) continue;
-            float contrib = 0.0f;
-            if (hit)
+            if (__ballot(hit) == 0) continue;
+            // Branch-free blend: lanes that do not hit run with alpha = 0, which leaves every accumulator and T
+            // bit-unchanged (x + c*0 == x, T*1 == T).
+            const float al = hit ? alpha : 0.0f;
+            const float contrib = al * T;
+            ar = fmaf(bcast(r1.w, j), contrib, ar);
+            ag = fmaf(bcast(r2.x, j), contrib, ag);
+            ab = fmaf(bcast(r2.y, j), contrib, ab);
+            if (RICH)
             {
-                contrib = alpha * T;
-                ar += bcast(r1.w, j) * contrib;
-                ag += bcast(r2.x, j) * contrib;
-                ab += bcast(r2.y, j) * contrib;
-                if (RICH)
-                {
-                    anx += bcast(r2.z, j) * contrib;
-                    any_ += bcast(r2.w, j) * contrib;
-                    anz += bcast(r3.x, j) * contrib;
-                    const float d = bcast(r3.y, j) * a1 + bcast(r3.z, j) * a2 + bcast(r3.w, j) * a3; // forward.cu:328
-                    ad += d * contrib;
-                }
-                T *= (1.0f - alpha);
-                if (T <= 0.0001f) // forward.cu:333
-                {
-                    done = true;
-                    last = (uint32_t)(base + j + 1);
-                }
+                anx = fmaf(bcast(r2.z, j), contrib, anx);
+                any_ = fmaf(bcast(r2.w, j), contrib, any_);
+                anz = fmaf(bcast(r3.x, j), contrib, anz);
+                const float d = bcast(r3.y, j) * a1 + bcast(r3.z, j) * a2 + bcast(r3.w, j) * a3; // forward.cu:328
+                ad = fmaf(d, contrib, ad);
+                stage[wave][staged][lane] = contrib;
+                staged_ids = (lane == staged) ? bcast(id, j) : staged_ids;
+                if (++staged == 16) flush();
             }
-            if (RICH) // forward.cu:323-324, one atomic pair per (quadrant, triangle) instead of per pixel
+            T *= (1.0f - al);
+            if (hit && T <= 0.0001f) // forward.cu:333
             {
-                const float cs = wave_sum63(contrib);
-                const float cm = wave_max63_nonneg(contrib);
-                if (lane == 63)
-                {
-                    const uint32_t gid = bcast(id, j);
-                    unsafeAtomicAdd(contrib_sum + gid, cs);
-                    atomicMax((int *)contrib_max + gid, __float_as_int(cm)); // cm > 0: int order == float order
-                }
+                done = true;
+                last = (uint32_t)(base + j + 1);
             }
             if (__ballot(!done) == 0)
             {
@@ -284,6 +317,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
             }
         }
     }
+    if (RICH && staged > 0) flush();
 
     if (inside)
     {
@@ -321,24 +355,28 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
     const bool inside = px < a.W && py < a.H;
     const float fx = (float)lx, fy = (float)ly, OX = (float)X0, OY = (float)Y0;
     const uint2 range = ranges[tile];
-    const int len = (int)(range.y - range.x);
     const float g2 = 2.0f * a.gamma;
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
 
     float T = inside ? final_T[pix] : 0.0f;                  // backward.cu:318
     const int last = inside ? (int)n_contrib[pix] : 0;       // backward.cu:320
-    float acr = 0.0f, acg = 0.0f, acb = 0.0f;                // back-to-front composites, start at the background
-    float acnx = 0.0f, acny = 0.0f, acnz = 0.0f, acd = a.background_depth;
-    float dpr = 0.0f, dpg = 0.0f, dpb = 0.0f, dnx = 0.0f, dny = 0.0f, dnz = 0.0f, dd = 0.0f;
+    // The reference keeps seven back-to-front composites per pixel (accum_feature[3], accum_normal, accum_depth,
+    // backward.cu:323-325) but only ever uses them through dL_dcontrib = sum_c dL_dpix_c * (value_c - accum_c)
+    // (:415,425,435).  With X = sum_c dL_dpix_c * value_c and B = sum_c dL_dpix_c * accum_c this is X - B, and the
+    // per-channel update accum_c <- alpha*value_c + (1-alpha)*accum_c collapses to B <- alpha*X + (1-alpha)*B:
+    // one scalar of sequential state instead of seven (same mathematics, different rounding order).
+    float dpr = 0.0f, dpg = 0.0f, dpb = 0.0f, dnx = 0.0f, dny = 0.0f, dnz = 0.0f, dd = 0.0f, B = 0.0f;
     if (inside) // backward.cu:331-343
     {
-        acr = a.background[0]; dpr = dL_dout_feature[pix];
-        if (a.C > 1) { acg = a.background[1]; dpg = dL_dout_feature[HW + pix]; }
-        if (a.C > 2) { acb = a.background[2]; dpb = dL_dout_feature[2 * HW + pix]; }
+        dpr = dL_dout_feature[pix];
+        B = dpr * a.background[0];
+        if (a.C > 1) { dpg = dL_dout_feature[HW + pix]; B = fmaf(dpg, a.background[1], B); }
+        if (a.C > 2) { dpb = dL_dout_feature[2 * HW + pix]; B = fmaf(dpb, a.background[2], B); }
         if (RICH)
         {
             dnx = dL_dout_normal[pix]; dny = dL_dout_normal[HW + pix]; dnz = dL_dout_normal[2 * HW + pix];
             dd = dL_dout_depth[pix];
+            B = fmaf(dd, a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
         }
     }
     const int slot = slot_of_lane(lane);
@@ -385,59 +423,58 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
             hit = hit && alpha >= 1.0f / 255.0f; // backward.cu:400
             if (__ballot(hit) == 0) continue;
 
+            // Branch-free from here on: lanes that do not hit run with alpha = 0 so that T, B stay bit-unchanged
+            // and every gradient term they produce is an exact 0 (all terms carry a factor alpha or contrib).
             float v[16];
-#pragma unroll
-            for (int i = 0; i < 16; i++) v[i] = 0.0f;
-            if (hit)
+            const float al = hit ? alpha : 0.0f;
+            const float oma = 1.0f - al;
+            T = T * __builtin_amdgcn_rcpf(oma); // backward.cu:403
+            const float contrib = al * T;
+            const float fr = bcast(r1.w, j), fg = bcast(r2.x, j), fb = bcast(r2.y, j);
+            v[7] = dpr * contrib; v[8] = dpg * contrib; v[9] = dpb * contrib; // backward.cu:412
+            float X = fmaf(dpb, fb, fmaf(dpg, fg, dpr * fr));
+            float da1 = 0.0f, da2 = 0.0f, da3 = 0.0f;
+            if (RICH) // backward.cu:419-437
             {
-                T = T * __builtin_amdgcn_rcpf(1.0f - alpha); // backward.cu:403
-                const float contrib = alpha * T;
-                const float oma = 1.0f - alpha;
-                float dL_dcontrib = 0.0f, da1 = 0.0f, da2 = 0.0f, da3 = 0.0f;
-                { // backward.cu:410-417
-                    const float fr = bcast(r1.w, j), fg = bcast(r2.x, j), fb = bcast(r2.y, j);
-                    v[7] = dpr * contrib; v[8] = dpg * contrib; v[9] = dpb * contrib;
-                    dL_dcontrib += dpr * (fr - acr); acr = alpha * fr + oma * acr;
-                    dL_dcontrib += dpg * (fg - acg); acg = alpha * fg + oma * acg;
-                    dL_dcontrib += dpb * (fb - acb); acb = alpha * fb + oma * acb;
-                }
-                if (RICH) // backward.cu:419-437
-                {
-                    const float nx = bcast(r2.z, j), ny = bcast(r2.w, j), nz = bcast(r3.x, j);
-                    v[10] = dnx * contrib; v[11] = dny * contrib; v[12] = dnz * contrib;
-                    dL_dcontrib += dnx * (nx - acnx) + dny * (ny - acny) + dnz * (nz - acnz);
-                    acnx = alpha * nx + oma * acnx; acny = alpha * ny + oma * acny; acnz = alpha * nz + oma * acnz;
-                    const float dL_ddepth = dd * contrib;
-                    v[13] = dL_ddepth * a1; v[14] = dL_ddepth * a2; v[15] = dL_ddepth * a3;
-                    const float vd1 = bcast(r3.y, j), vd2 = bcast(r3.z, j), vd3 = bcast(r3.w, j);
-                    da1 = dL_ddepth * vd1; da2 = dL_ddepth * vd2; da3 = dL_ddepth * vd3;
-                    const float depth = vd1 * a1 + vd2 * a2 + vd3 * a3;
-                    dL_dcontrib += dd * (depth - acd);
-                    acd = alpha * depth + oma * acd;
-                }
-                const float dL_dalpha = dL_dcontrib * T;
-                const float dL_dpower = (op * G < 0.99f) ? dL_dalpha * alpha : 0.0f;                  // backward.cu:443-446
-                const float dL_decc = dL_dpower * g2 * power * __builtin_amdgcn_rcpf(ecc + 1e-8f);    // backward.cu:447
-                if (a1 <= a2 && a1 <= a3) da1 += -3.0f * dL_decc;                                     // backward.cu:449-461
-                else if (a2 <= a1 && a2 <= a3) da2 += -3.0f * dL_decc;
-                else da3 += -3.0f * dL_decc;
-                // backward.cu:464-479 regrouped: with E_k = perp(opposite edge of vertex k) / area2 =
-                // -(A_k, B_k) and S = sum_i dL/da_i * a_i,
-                //   dL/dv1 = S*E1 + perp(da3*p_v2 - da2*p_v3)/area2, and cyclically for v2, v3.
-                const float S = da1 * a1 + da2 * a2 + da3 * a3;
-                const float ia = bcast(inv_area, j);
-                const float p1x = bcast(u1x, j) - fx, p1y = bcast(u1y, j) - fy;
-                const float p2x = bcast(u2x, j) - fx, p2y = bcast(u2y, j) - fy;
-                const float p3x = bcast(u3x, j) - fx, p3y = bcast(u3y, j) - fy;
-                const float sA3 = -sA1 - sA2, sB3 = -sB1 - sB2;
-                const float t1x = da3 * p2x - da2 * p3x, t1y = da3 * p2y - da2 * p3y;
-                const float t2x = da1 * p3x - da3 * p1x, t2y = da1 * p3y - da3 * p1y;
-                const float t3x = da2 * p1x - da1 * p2x, t3y = da2 * p1y - da1 * p2y;
-                v[0] = ia * t1y - S * sA1; v[1] = -ia * t1x - S * sB1;
-                v[2] = ia * t2y - S * sA2; v[3] = -ia * t2x - S * sB2;
-                v[4] = ia * t3y - S * sA3; v[5] = -ia * t3x - S * sB3;
-                v[6] = dL_dalpha * G; // backward.cu:490 (not gated by the clamp)
+                const float nx = bcast(r2.z, j), ny = bcast(r2.w, j), nz = bcast(r3.x, j);
+                v[10] = dnx * contrib; v[11] = dny * contrib; v[12] = dnz * contrib;
+                X = fmaf(dnz, nz, fmaf(dny, ny, fmaf(dnx, nx, X)));
+                const float dL_ddepth = dd * contrib;
+                v[13] = dL_ddepth * a1; v[14] = dL_ddepth * a2; v[15] = dL_ddepth * a3;
+                const float vd1 = bcast(r3.y, j), vd2 = bcast(r3.z, j), vd3 = bcast(r3.w, j);
+                da1 = dL_ddepth * vd1; da2 = dL_ddepth * vd2; da3 = dL_ddepth * vd3;
+                const float depth = fmaf(vd3, a3, fmaf(vd2, a2, vd1 * a1));
+                X = fmaf(dd, depth, X);
             }
+            else
+            {
+                v[10] = v[11] = v[12] = v[13] = v[14] = v[15] = 0.0f;
+            }
+            const float dL_dcontrib = X - B;
+            B = fmaf(al, X, oma * B);
+            const float dL_dalpha = dL_dcontrib * T;
+            // backward.cu:443-447: dL_decc = dL_dpower * 2 gamma * power / (ecc + 1e-8), dL_dpower = dL_dalpha * alpha
+            // unless the 0.99 clamp was active.  The select sits last so that a non-hit lane never multiplies 0 * inf.
+            const float decc_raw = dL_dalpha * alpha * g2 * power * __builtin_amdgcn_rcpf(ecc + 1e-8f);
+            const float z = (hit && op * G < 0.99f) ? -3.0f * decc_raw : 0.0f;
+            if (a1 <= a2 && a1 <= a3) da1 += z; // backward.cu:449-461 (ties: a1, then a2)
+            else if (a2 <= a1 && a2 <= a3) da2 += z;
+            else da3 += z;
+            // backward.cu:464-479 regrouped: with E_k = perp(opposite edge of vertex k) / area2 = -(A_k, B_k) and
+            // S = sum_i dL/da_i * a_i:  dL/dv1 = S*E1 + perp(da3*p_v2 - da2*p_v3)/area2, cyclically for v2, v3.
+            const float S = da1 * a1 + da2 * a2 + da3 * a3;
+            const float ia = bcast(inv_area, j);
+            const float p1x = bcast(u1x, j) - fx, p1y = bcast(u1y, j) - fy;
+            const float p2x = bcast(u2x, j) - fx, p2y = bcast(u2y, j) - fy;
+            const float p3x = bcast(u3x, j) - fx, p3y = bcast(u3y, j) - fy;
+            const float sA3 = -sA1 - sA2, sB3 = -sB1 - sB2;
+            const float t1x = da3 * p2x - da2 * p3x, t1y = da3 * p2y - da2 * p3y;
+            const float t2x = da1 * p3x - da3 * p1x, t2y = da1 * p3y - da3 * p1y;
+            const float t3x = da2 * p1x - da1 * p2x, t3y = da2 * p1y - da1 * p2y;
+            v[0] = ia * t1y - S * sA1; v[1] = -ia * t1x - S * sB1;
+            v[2] = ia * t2y - S * sA2; v[3] = -ia * t2x - S * sB2;
+            v[4] = ia * t3y - S * sA3; v[5] = -ia * t3x - S * sB3;
+            v[6] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
             const float r = reduce16(v, lane);
             if (writer) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)bcast(id, j) + slot, r);
         }
