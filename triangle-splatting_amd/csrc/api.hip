@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -142,6 +143,8 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.gamma = geom->gamma; r.background_depth = geom->background_depth;
     r.background = geom->background;
     r.rich_info = flags & TS2D_FLAG_RICH_INFO;
+    const char *ab = getenv("TS2D_ABLATE");
+    r.ablate = ab ? atoi(ab) : 0;
     return r;
 }
 } // namespace

@@ -148,28 +148,56 @@ __device__ __forceinline__ int tile_of_block(int b, int ntiles)
     return x * q + min(x, r) + i;
 }
 
-// Per-entry setup shared by forward and backward.  All values live in the lane that owns the entry.
+// ---- reduce4: 4 values per lane x 64 lanes -> every lane of row r returns the complete sum of value map[r] ----
+__device__ __forceinline__ float reduce4(float x0, float x1, float x2, float x3)
+{
+    swap32(x0, x1);
+    x0 += x1;
+    swap32(x2, x3);
+    x2 += x3;
+    swap16(x0, x2);
+    float r = x0 + x2;
+    r += dpp<DPP_XOR1>(r);
+    r += dpp<DPP_XOR2>(r);
+    r += dpp<DPP_HALF_MIRROR>(r);
+    r += dpp<DPP_MIRROR>(r);
+    return r;
+}
+__device__ __forceinline__ int slot4_of_lane(int lane)
+{
+    const float i = (lane == 0) ? 1.0f : 0.0f;
+    return (int)reduce4(0.0f, i, 2.0f * i, 3.0f * i);
+}
+
+// Per-entry constants travel from the lane that owns the entry to all 64 pixel lanes through a wave-private LDS
+// table read with uniform addresses (ds_read_b128 broadcast): that costs no VALU issue slots, whereas one
+// v_readlane per constant costs ~4.3 cycles each (profiles/r01_valu_microbench.txt) in kernels that are VALU-bound.
+// Row layout (CST floats per entry; 20-dword stride keeps the 8-lane ds_write_b128 groups conflict-free):
+//   [0..3] A1 B1 C1 A2   [4..7] B2 C2 opacity id   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3
+constexpr int CST = 20;
+
 struct EntrySetup
 {
     float A1, B1, C1, A2, B2, C2; // a1(q) = A1*qx + B1*qy + C1 (q = pixel offset inside the quadrant), same for a2
-    bool overlap;                 // support box meets the quadrant
+    float inv_area;               // 1 / area2
+    float u1x, u1y, u2x, u2y, u3x, u3y; // screen vertices relative to the quadrant origin
+    bool overlap;                 // the entry's support region meets the quadrant's 8x8 sample box
 };
 
 template <bool GAMMA1>
 __device__ __forceinline__ EntrySetup entry_setup(float v1x, float v1y, float v2x, float v2y, float v3x, float v3y,
-                                                  float op, float g2, float OX, float OY, float &inv_area,
-                                                  float &u1x, float &u1y, float &u2x, float &u2y, float &u3x, float &u3y)
+                                                  float op, float g2, float OX, float OY)
 {
     EntrySetup s;
     const float area2 = (v2x - v1x) * (v3y - v1y) - (v2y - v1y) * (v3x - v1x); // the value the reference stores, forward.cu:137
-    inv_area = 1.0f / area2;
-    u1x = v1x - OX; u1y = v1y - OY; u2x = v2x - OX; u2y = v2y - OY; u3x = v3x - OX; u3y = v3y - OY;
-    s.C1 = (u2x * u3y - u2y * u3x) * inv_area;
-    s.A1 = (v2y - v3y) * inv_area;
-    s.B1 = (v3x - v2x) * inv_area;
-    s.C2 = (u3x * u1y - u3y * u1x) * inv_area;
-    s.A2 = (v3y - v1y) * inv_area;
-    s.B2 = (v1x - v3x) * inv_area;
+    s.inv_area = 1.0f / area2;
+    s.u1x = v1x - OX; s.u1y = v1y - OY; s.u2x = v2x - OX; s.u2y = v2y - OY; s.u3x = v3x - OX; s.u3y = v3y - OY;
+    s.C1 = (s.u2x * s.u3y - s.u2y * s.u3x) * s.inv_area;
+    s.A1 = (v2y - v3y) * s.inv_area;
+    s.B1 = (v3x - v2x) * s.inv_area;
+    s.C2 = (s.u3x * s.u1y - s.u3y * s.u1x) * s.inv_area;
+    s.A2 = (v3y - v1y) * s.inv_area;
+    s.B2 = (v1x - v3x) * s.inv_area;
     // Conservative support: alpha >= 1/255 needs ecc^(2 gamma) <= 2 ln(255 op), and ecc <= E is the triangle
     // scaled by E about its centroid.
     const float t = 255.0f * op;
@@ -181,15 +209,17 @@ __device__ __forceinline__ EntrySetup entry_setup(float v1x, float v1y, float v2
         else E = (g2 < 1e-6f) ? 10.0f : pow_nonneg(L, 1.0f / g2);
         E = fminf(E * 1.0005f + 0.002f, 10.01f);
     }
-    const float cx = (u1x + u2x + u3x) * (1.0f / 3.0f), cy = (u1y + u2y + u3y) * (1.0f / 3.0f);
-    const float e1x = E * (u1x - cx), e2x = E * (u2x - cx), e3x = E * (u3x - cx);
-    const float e1y = E * (u1y - cy), e2y = E * (u2y - cy), e3y = E * (u3y - cy);
+    const float cx = (s.u1x + s.u2x + s.u3x) * (1.0f / 3.0f), cy = (s.u1y + s.u2y + s.u3y) * (1.0f / 3.0f);
+    const float e1x = E * (s.u1x - cx), e2x = E * (s.u2x - cx), e3x = E * (s.u3x - cx);
+    const float e1y = E * (s.u1y - cy), e2y = E * (s.u2y - cy), e3y = E * (s.u3y - cy);
     const float pad = 0.05f;
     const float bminx = cx + fminf(fminf(e1x, e2x), e3x) - pad, bmaxx = cx + fmaxf(fmaxf(e1x, e2x), e3x) + pad;
     const float bminy = cy + fminf(fminf(e1y, e2y), e3y) - pad, bmaxy = cy + fmaxf(fmaxf(e1y, e2y), e3y) + pad;
     // Separating-axis test of the E-scaled triangle against the quadrant's 8x8 sample box: box axes (the bbox
     // above) plus the three edge normals.  ecc <= E  <=>  min_i a_i >= (1 - E) / 3, and each a_i is affine in q,
     // so its maximum over the box is C_i + max(0, 7 A_i) + max(0, 7 B_i).
+    // (A per-row interval coverage mask was tried instead: exact, but its ~200 VALU per batch cost more than the
+    // few no-hit entries it removes -- see profiles/r01_notes.md.)
     const float m = (1.0f - E) * (1.0f / 3.0f);
     const float A3 = -s.A1 - s.A2, B3 = -s.B1 - s.B2, C3 = 1.0f - s.C1 - s.C2;
     const float max1 = s.C1 + fmaxf(0.0f, 7.0f * s.A1) + fmaxf(0.0f, 7.0f * s.B1);
@@ -200,6 +230,22 @@ __device__ __forceinline__ EntrySetup entry_setup(float v1x, float v1y, float v2
     return s;
 }
 
+// Publishes the owning lane's constants for its entry.  Read back by every lane with a uniform row index.
+template <bool RICH>
+__device__ __forceinline__ void publish_entry(float *row, const EntrySetup &s, uint32_t id, const float4 &r1, const float4 &r2,
+                                              const float4 &r3)
+{
+    float4 *q = (float4 *)row;
+    q[0] = make_float4(s.A1, s.B1, s.C1, s.A2);
+    q[1] = make_float4(s.B2, s.C2, r1.z, __uint_as_float(id));
+    q[2] = make_float4(r1.w, r2.x, r2.y, r2.z);
+    if (RICH)
+    {
+        q[3] = make_float4(r2.w, r3.x, r3.y, r3.z);
+        row[16] = r3.w;
+    }
+}
+
 template <bool RICH, bool GAMMA1>
 __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                           const uint32_t *__restrict__ point_list,
@@ -208,6 +254,9 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
                                                           float *__restrict__ out_depth, float *__restrict__ out_normal,
                                                           float *__restrict__ contrib_sum, float *__restrict__ contrib_max)
 {
+    __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CST];
+    __shared__ float stage_all[RICH ? 4 : 1][16][64];
+
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -220,6 +269,8 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
     const int len = (int)(range.y - range.x);
     const float g2 = 2.0f * a.gamma;
     const float bg0 = a.background[0], bg1 = a.C > 1 ? a.background[1] : 0.0f, bg2 = a.C > 2 ? a.background[2] : 0.0f;
+    float *cst = cst_all[wave];
+    float(*stage)[64] = stage_all[RICH ? wave : 0];
 
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, anx = 0.0f, any_ = 0.0f, anz = 0.0f, ad = 0.0f;
     bool done = !inside;
@@ -230,16 +281,15 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
     // entries the 16 x 64 block is reduced by two transpose-reduce passes (sum, max) and leaves as ONE 16-lane
     // atomic add + ONE 16-lane atomic max.  (LDS float atomics are not an option: ds_add_f32 measures ~190
     // cycles per wave instruction on gfx950, see profiles/r01_lds_atomic_microbench.txt.)
-    __shared__ float stage[4][16][64];
-    int staged = 0;                 // entries parked so far (wave-uniform)
-    uint32_t staged_ids = 0;        // lane k holds the triangle id of parked entry k
+    int staged = 0;          // entries parked so far (wave-uniform)
+    uint32_t staged_ids = 0; // lane k holds the triangle id of parked entry k
     const int slot = RICH ? slot_of_lane(lane) : 0;
     auto flush = [&]() {
         float vs[16], vm[16];
 #pragma unroll
         for (int i = 0; i < 16; i++)
         {
-            const float x = (i < staged) ? stage[wave][i][lane] : 0.0f;
+            const float x = (i < staged) ? stage[i][lane] : 0.0f;
             vs[i] = x;
             vm[i] = x;
         }
@@ -254,9 +304,10 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
         staged = 0;
     };
 
+    unsigned long long alive = __ballot(!done); // pixels that still blend (wave-uniform copy of !done)
     for (int base = 0; base < len; base += 64)
     {
-        if (__ballot(!done) == 0) break;
+        if (alive == 0) break;
         const int k = base + lane;
         const bool valid = k < len;
         uint32_t id = 0;
@@ -268,49 +319,68 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
             if (RICH) r3 = rp[3];
         }
-        float inv_area, u1x, u1y, u2x, u2y, u3x, u3y;
-        const EntrySetup s = entry_setup<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY, inv_area, u1x, u1y,
-                                                 u2x, u2y, u3x, u3y);
+        const EntrySetup s = entry_setup<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
         unsigned long long mask = __ballot(valid && s.overlap);
+        if (mask == 0) continue;
+        publish_entry<RICH>(cst + lane * CST, s, id, r1, r2, r3);
+
+        int j = __builtin_ctzll(mask);
+        float4 n0 = *(const float4 *)(cst + j * CST), n1 = *(const float4 *)(cst + j * CST + 4);
         while (mask)
         {
-            const int j = __builtin_ctzll(mask);
+            const float4 c0 = n0, c1 = n1;
+            const int jc = j;
             mask &= mask - 1;
-            const float a1 = fmaf(bcast(s.A1, j), fx, fmaf(bcast(s.B1, j), fy, bcast(s.C1, j)));
-            const float a2 = fmaf(bcast(s.A2, j), fx, fmaf(bcast(s.B2, j), fy, bcast(s.C2, j)));
+            if (mask) // prefetch the next entry's stage-1 constants behind this entry's arithmetic
+            {
+                j = __builtin_ctzll(mask);
+                n0 = *(const float4 *)(cst + j * CST);
+                n1 = *(const float4 *)(cst + j * CST + 4);
+            }
+            const float a1 = fmaf(c0.x, fx, fmaf(c0.y, fy, c0.z));
+            const float a2 = fmaf(c0.w, fx, fmaf(c1.x, fy, c1.y));
             const float a3 = 1.0f - a1 - a2;
             const float ecc = 1.0f - 3.0f * fminf(fminf(a1, a2), a3);
             bool hit = !done && ecc >= 0.0f && ecc <= 10.0f; // forward.cu:307
             if (__ballot(hit) == 0) continue;
+            const float4 c2 = *(const float4 *)(cst + jc * CST + 8);
+            float4 c3 = make_float4(0, 0, 0, 0);
+            float c4 = 0.0f;
+            if (RICH)
+            {
+                c3 = *(const float4 *)(cst + jc * CST + 12);
+                c4 = cst[jc * CST + 16];
+            }
             const float pw = GAMMA1 ? ecc * ecc : pow_nonneg(ecc, g2);
-            const float alpha = fminf(0.99f, bcast(r1.z, j) * fast_exp(-0.5f * pw)); // forward.cu:311-312
-            hit = hit && alpha >= 1.0f / 255.0f;                                       // forward.cu:313
+            const float alpha = fminf(0.99f, c1.z * fast_exp(-0.5f * pw)); // forward.cu:311-312
+            hit = hit && alpha >= 1.0f / 255.0f;                           // forward.cu:313
             if (__ballot(hit) == 0) continue;
             // Branch-free blend: lanes that do not hit run with alpha = 0, which leaves every accumulator and T
             // bit-unchanged (x + c*0 == x, T*1 == T).
             const float al = hit ? alpha : 0.0f;
             const float contrib = al * T;
-            ar = fmaf(bcast(r1.w, j), contrib, ar);
-            ag = fmaf(bcast(r2.x, j), contrib, ag);
-            ab = fmaf(bcast(r2.y, j), contrib, ab);
+            ar = fmaf(c2.x, contrib, ar);
+            ag = fmaf(c2.y, contrib, ag);
+            ab = fmaf(c2.z, contrib, ab);
             if (RICH)
             {
-                anx = fmaf(bcast(r2.z, j), contrib, anx);
-                any_ = fmaf(bcast(r2.w, j), contrib, any_);
-                anz = fmaf(bcast(r3.x, j), contrib, anz);
-                const float d = bcast(r3.y, j) * a1 + bcast(r3.z, j) * a2 + bcast(r3.w, j) * a3; // forward.cu:328
+                anx = fmaf(c2.w, contrib, anx);
+                any_ = fmaf(c3.x, contrib, any_);
+                anz = fmaf(c3.y, contrib, anz);
+                const float d = c3.z * a1 + c3.w * a2 + c4 * a3; // forward.cu:328
                 ad = fmaf(d, contrib, ad);
-                stage[wave][staged][lane] = contrib;
-                staged_ids = (lane == staged) ? bcast(id, j) : staged_ids;
+                stage[staged][lane] = contrib;
+                staged_ids = (lane == staged) ? __float_as_uint(c1.w) : staged_ids;
                 if (++staged == 16) flush();
             }
             T *= (1.0f - al);
             if (hit && T <= 0.0001f) // forward.cu:333
             {
                 done = true;
-                last = (uint32_t)(base + j + 1);
+                last = (uint32_t)(base + jc + 1);
             }
-            if (__ballot(!done) == 0)
+            alive = __ballot(!done);
+            if (alive == 0)
             {
                 mask = 0;
                 base = len; // leave both loops
@@ -337,6 +407,16 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
     }
 }
 
+// Backward.  Per (pixel, triangle) pair the reference adds 16 values into per-triangle arrays (backward.cu:412-490).
+// All of them are linear in three per-pair scalars with per-PIXEL weights:
+//     contrib             -> dL/drgb (weights dL_dpix_rgb), dL/dnormal (dL_dpix_normal), w = dL_dpix_depth * contrib
+//     z = -3 dL/decc      -> enters dL/da_k of the arg-min barycentric k only
+//     dL/dalpha * G       -> dL/dopacity
+// and the six screen-space vertex gradients and three v_depth gradients are per-TRIANGLE linear maps of the
+// zeroth and first pixel moments of w and z_k (a_k and p_v_k = u_k - q are affine in the pixel offset q).  The hot
+// loop therefore only forms 19 products per lane (moments + colour/normal/opacity terms), reduces them across the
+// wave, parks the 19 sums of entry j in LDS, and once per batch the lane that OWNS entry j turns them into the 16
+// gradient values with its own (register-resident) triangle constants and issues the global atomics.
 template <bool RICH, bool GAMMA1>
 __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                           const uint32_t *__restrict__ point_list,
@@ -346,6 +426,9 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
                                                           const float *__restrict__ dL_dout_depth,
                                                           const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
+    __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CST];
+    __shared__ __attribute__((aligned(16))) float sums_all[4][64 * CST];
+
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -357,9 +440,11 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
     const uint2 range = ranges[tile];
     const float g2 = 2.0f * a.gamma;
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
+    float *cst = cst_all[wave];
+    float *sums = sums_all[wave];
 
-    float T = inside ? final_T[pix] : 0.0f;                  // backward.cu:318
-    const int last = inside ? (int)n_contrib[pix] : 0;       // backward.cu:320
+    float T = inside ? final_T[pix] : 0.0f;            // backward.cu:318
+    const int last = inside ? (int)n_contrib[pix] : 0; // backward.cu:320
     // The reference keeps seven back-to-front composites per pixel (accum_feature[3], accum_normal, accum_depth,
     // backward.cu:323-325) but only ever uses them through dL_dcontrib = sum_c dL_dpix_c * (value_c - accum_c)
     // (:415,425,435).  With X = sum_c dL_dpix_c * value_c and B = sum_c dL_dpix_c * accum_c this is X - B, and the
@@ -380,7 +465,8 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
         }
     }
     const int slot = slot_of_lane(lane);
-    const bool writer = ((lane & 3) == 0) && (RICH || slot < 10);
+    const int slot4 = RICH ? slot4_of_lane(lane) : 0;
+    const bool writer16 = (lane & 3) == 0, writer4 = RICH && (lane & 15) == 0;
 
     // entries at list positions >= max(last) are skipped by every pixel of the quadrant (backward.cu:377-379)
     const int wlast = __builtin_amdgcn_readlane(__float_as_int(wave_max63_nonneg((float)last)), 63);
@@ -400,55 +486,63 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
             if (RICH) r3 = rp[3];
         }
-        float inv_area, u1x, u1y, u2x, u2y, u3x, u3y;
-        const EntrySetup s = entry_setup<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY, inv_area, u1x, u1y,
-                                                 u2x, u2y, u3x, u3y);
+        const EntrySetup s = entry_setup<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
         unsigned long long mask = __ballot(valid && s.overlap);
+        if (mask == 0) continue;
+        publish_entry<RICH>(cst + lane * CST, s, id, r1, r2, r3);
+        unsigned long long touched = 0; // entries of this batch that received gradient sums
+
+        int j = 63 - __builtin_clzll(mask);
+        float4 n0 = *(const float4 *)(cst + j * CST), n1 = *(const float4 *)(cst + j * CST + 4);
         while (mask)
         {
-            const int j = 63 - __builtin_clzll(mask);
-            mask &= ~(1ull << j);
-            const float sA1 = bcast(s.A1, j), sB1 = bcast(s.B1, j), sA2 = bcast(s.A2, j), sB2 = bcast(s.B2, j);
-            const float a1 = fmaf(sA1, fx, fmaf(sB1, fy, bcast(s.C1, j)));
-            const float a2 = fmaf(sA2, fx, fmaf(sB2, fy, bcast(s.C2, j)));
+            const float4 c0 = n0, c1 = n1;
+            const int jc = j;
+            mask &= ~(1ull << jc);
+            if (mask) // prefetch the next entry's stage-1 constants behind this entry's arithmetic
+            {
+                j = 63 - __builtin_clzll(mask);
+                n0 = *(const float4 *)(cst + j * CST);
+                n1 = *(const float4 *)(cst + j * CST + 4);
+            }
+            const float a1 = fmaf(c0.x, fx, fmaf(c0.y, fy, c0.z));
+            const float a2 = fmaf(c0.w, fx, fmaf(c1.x, fy, c1.y));
             const float a3 = 1.0f - a1 - a2;
             const float ecc = 1.0f - 3.0f * fminf(fminf(a1, a2), a3);
-            bool hit = (base + j < last) && ecc >= 0.0f && ecc <= 10.0f; // backward.cu:378,393
+            bool hit = (base + jc < last) && ecc >= 0.0f && ecc <= 10.0f; // backward.cu:378,393
             if (__ballot(hit) == 0) continue;
+            if (a.ablate == 3) { T += ecc * 1e-30f; continue; } // profiling: stage 1 only
+            const float4 c2 = *(const float4 *)(cst + jc * CST + 8);
+            float4 c3 = make_float4(0, 0, 0, 0);
+            float c4 = 0.0f;
+            if (RICH)
+            {
+                c3 = *(const float4 *)(cst + jc * CST + 12);
+                c4 = cst[jc * CST + 16];
+            }
             const float pw = GAMMA1 ? ecc * ecc : pow_nonneg(ecc, g2);
             const float power = -0.5f * pw;
-            const float op = bcast(r1.z, j);
+            const float op = c1.z;
             const float G = fast_exp(power);
             const float alpha = fminf(0.99f, op * G);
             hit = hit && alpha >= 1.0f / 255.0f; // backward.cu:400
             if (__ballot(hit) == 0) continue;
+            if (a.ablate == 2) { T = T * __builtin_amdgcn_rcpf(1.0f - (hit ? alpha : 0.0f)); continue; } // profiling
 
             // Branch-free from here on: lanes that do not hit run with alpha = 0 so that T, B stay bit-unchanged
-            // and every gradient term they produce is an exact 0 (all terms carry a factor alpha or contrib).
-            float v[16];
+            // and every term they produce is an exact 0 (all terms carry a factor alpha, contrib or `hit`).
             const float al = hit ? alpha : 0.0f;
             const float oma = 1.0f - al;
             T = T * __builtin_amdgcn_rcpf(oma); // backward.cu:403
             const float contrib = al * T;
-            const float fr = bcast(r1.w, j), fg = bcast(r2.x, j), fb = bcast(r2.y, j);
-            v[7] = dpr * contrib; v[8] = dpg * contrib; v[9] = dpb * contrib; // backward.cu:412
-            float X = fmaf(dpb, fb, fmaf(dpg, fg, dpr * fr));
-            float da1 = 0.0f, da2 = 0.0f, da3 = 0.0f;
+            float X = fmaf(dpb, c2.z, fmaf(dpg, c2.y, dpr * c2.x)); // backward.cu:415
+            float w = 0.0f;
             if (RICH) // backward.cu:419-437
             {
-                const float nx = bcast(r2.z, j), ny = bcast(r2.w, j), nz = bcast(r3.x, j);
-                v[10] = dnx * contrib; v[11] = dny * contrib; v[12] = dnz * contrib;
-                X = fmaf(dnz, nz, fmaf(dny, ny, fmaf(dnx, nx, X)));
-                const float dL_ddepth = dd * contrib;
-                v[13] = dL_ddepth * a1; v[14] = dL_ddepth * a2; v[15] = dL_ddepth * a3;
-                const float vd1 = bcast(r3.y, j), vd2 = bcast(r3.z, j), vd3 = bcast(r3.w, j);
-                da1 = dL_ddepth * vd1; da2 = dL_ddepth * vd2; da3 = dL_ddepth * vd3;
-                const float depth = fmaf(vd3, a3, fmaf(vd2, a2, vd1 * a1));
+                X = fmaf(dnz, c3.y, fmaf(dny, c3.x, fmaf(dnx, c2.w, X)));
+                const float depth = fmaf(c4, a3, fmaf(c3.w, a2, c3.z * a1));
                 X = fmaf(dd, depth, X);
-            }
-            else
-            {
-                v[10] = v[11] = v[12] = v[13] = v[14] = v[15] = 0.0f;
+                w = dd * contrib; // dL_ddepth
             }
             const float dL_dcontrib = X - B;
             B = fmaf(al, X, oma * B);
@@ -457,26 +551,86 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
             // unless the 0.99 clamp was active.  The select sits last so that a non-hit lane never multiplies 0 * inf.
             const float decc_raw = dL_dalpha * alpha * g2 * power * __builtin_amdgcn_rcpf(ecc + 1e-8f);
             const float z = (hit && op * G < 0.99f) ? -3.0f * decc_raw : 0.0f;
-            if (a1 <= a2 && a1 <= a3) da1 += z; // backward.cu:449-461 (ties: a1, then a2)
-            else if (a2 <= a1 && a2 <= a3) da2 += z;
-            else da3 += z;
-            // backward.cu:464-479 regrouped: with E_k = perp(opposite edge of vertex k) / area2 = -(A_k, B_k) and
-            // S = sum_i dL/da_i * a_i:  dL/dv1 = S*E1 + perp(da3*p_v2 - da2*p_v3)/area2, cyclically for v2, v3.
-            const float S = da1 * a1 + da2 * a2 + da3 * a3;
-            const float ia = bcast(inv_area, j);
-            const float p1x = bcast(u1x, j) - fx, p1y = bcast(u1y, j) - fy;
-            const float p2x = bcast(u2x, j) - fx, p2y = bcast(u2y, j) - fy;
-            const float p3x = bcast(u3x, j) - fx, p3y = bcast(u3y, j) - fy;
-            const float sA3 = -sA1 - sA2, sB3 = -sB1 - sB2;
-            const float t1x = da3 * p2x - da2 * p3x, t1y = da3 * p2y - da2 * p3y;
-            const float t2x = da1 * p3x - da3 * p1x, t2y = da1 * p3y - da3 * p1y;
-            const float t3x = da2 * p1x - da1 * p2x, t3y = da2 * p1y - da1 * p2y;
-            v[0] = ia * t1y - S * sA1; v[1] = -ia * t1x - S * sB1;
-            v[2] = ia * t2y - S * sA2; v[3] = -ia * t2x - S * sB2;
-            v[4] = ia * t3y - S * sA3; v[5] = -ia * t3x - S * sB3;
-            v[6] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
-            const float r = reduce16(v, lane);
-            if (writer) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)bcast(id, j) + slot, r);
+            const bool k1 = a1 <= a2 && a1 <= a3;        // backward.cu:449-461 (ties: a1, then a2)
+            const bool k2 = !k1 && a2 <= a1 && a2 <= a3;
+            const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = (k1 || k2) ? 0.0f : z;
+
+            float v[16];
+            v[0] = z1; v[1] = z1 * fx; v[2] = z1 * fy;
+            v[3] = z2; v[4] = z2 * fx; v[5] = z2 * fy;
+            v[6] = z3; v[7] = z3 * fx; v[8] = z3 * fy;
+            v[9] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
+            v[10] = dpr * contrib; v[11] = dpg * contrib; v[12] = dpb * contrib; // backward.cu:412
+            v[13] = dnx * contrib; v[14] = dny * contrib; v[15] = dnz * contrib; // backward.cu:421-423
+            if (a.ablate == 1) // profiling: everything except the cross-lane reductions
+            {
+#pragma unroll
+                for (int i = 0; i < 16; i++) asm volatile("" ::"v"(v[i]));
+                asm volatile("" ::"v"(w));
+                continue;
+            }
+            const float r16 = reduce16(v, lane);
+            if (writer16) sums[jc * CST + slot] = r16;
+            if (RICH)
+            {
+                const float r4 = reduce4(w, w * fx, w * fy, 0.0f);
+                if (writer4) sums[jc * CST + 16 + slot4] = r4;
+            }
+            touched |= 1ull << jc;
+        }
+
+        // Batch epilogue: the lane that owns a touched entry converts the 19 sums into the 16 gradient values.
+        if (touched == 0) continue;
+        if ((touched >> lane) & 1)
+        {
+            const float4 *sq = (const float4 *)(sums + lane * CST);
+            const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3];
+            float W0 = 0.0f, Wx = 0.0f, Wy = 0.0f;
+            if (RICH)
+            {
+                const float4 s4 = sq[4];
+                W0 = s4.x; Wx = s4.y; Wy = s4.z;
+            }
+            const float vd1 = r3.y, vd2 = r3.z, vd3 = r3.w;
+            // zeroth / first moments of dL/da_k = w * vd_k + z_k   (backward.cu:433,462)
+            const float D10 = fmaf(vd1, W0, s0.x), D1x = fmaf(vd1, Wx, s0.y), D1y = fmaf(vd1, Wy, s0.z);
+            const float D20 = fmaf(vd2, W0, s0.w), D2x = fmaf(vd2, Wx, s1.x), D2y = fmaf(vd2, Wy, s1.y);
+            const float D30 = fmaf(vd3, W0, s1.z), D3x = fmaf(vd3, Wx, s1.w), D3y = fmaf(vd3, Wy, s2.x);
+            const float A3 = -s.A1 - s.A2, B3 = -s.B1 - s.B2, C3 = 1.0f - s.C1 - s.C2;
+            // S = sum_pixels sum_k dL/da_k * a_k with a_k = A_k qx + B_k qy + C_k
+            const float S = s.A1 * D1x + s.B1 * D1y + s.C1 * D10 + s.A2 * D2x + s.B2 * D2y + s.C2 * D20 + A3 * D3x + B3 * D3y +
+                            C3 * D30;
+            // backward.cu:464-479 regrouped: with E_k = perp(opposite edge of vertex k) / area2 = -(A_k, B_k):
+            //   dL/dv1 = S*E1 + perp(sum(da3*p_v2 - da2*p_v3))/area2, cyclically; p_v_k = u_k - q.
+            const float t1x = s.u2x * D30 - D3x - s.u3x * D20 + D2x, t1y = s.u2y * D30 - D3y - s.u3y * D20 + D2y;
+            const float t2x = s.u3x * D10 - D1x - s.u1x * D30 + D3x, t2y = s.u3y * D10 - D1y - s.u1y * D30 + D3y;
+            const float t3x = s.u1x * D20 - D2x - s.u2x * D10 + D1x, t3y = s.u1y * D20 - D2y - s.u2y * D10 + D1y;
+            const float ia = s.inv_area;
+            // park the 16 gradient values in the entry's own LDS row (it has just been read), in grad-record order
+            float4 *gq = (float4 *)(sums + lane * CST);
+            gq[0] = make_float4(ia * t1y - S * s.A1, -ia * t1x - S * s.B1, ia * t2y - S * s.A2, -ia * t2x - S * s.B2);
+            gq[1] = make_float4(ia * t3y - S * A3, -ia * t3x - S * B3, s2.y /* dL/dopacity */, s2.z /* dL/drgb */);
+            gq[2] = make_float4(s2.w, s3.x, s3.y /* dL/dnormal_view */, s3.z);
+            // dL/dv_depth_k = sum w * a_k   (backward.cu:429-431)
+            gq[3] = make_float4(s3.w, s.A1 * Wx + s.B1 * Wy + s.C1 * W0, s.A2 * Wx + s.B2 * Wy + s.C2 * W0,
+                                A3 * Wx + B3 * Wy + C3 * W0);
+        }
+        // Coalesced flush: 16 consecutive lanes add the 16 floats (one 64-byte line) of one triangle's gradient
+        // record, four touched-or-not entries per instruction.  (One atomic per lane-and-value instead would be
+        // 16x the atomic requests: measured 4.6 ms for this scene.)
+        {
+            const int sub = lane >> 4, col = lane & 15;
+#pragma unroll 1
+            for (int e0 = 0; e0 < 64; e0 += 4)
+            {
+                if (((touched >> e0) & 0xFull) == 0) continue;
+                const int e = e0 + sub;
+                if ((touched >> e) & 1)
+                {
+                    const uint32_t eid = __float_as_uint(cst[e * CST + 7]);
+                    if (RICH || col < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + col, sums[e * CST + col]);
+                }
+            }
         }
     }
 }

@@ -149,6 +149,7 @@ struct RenderArgs
     float gamma, background_depth;
     const float *background; // C floats, device
     bool rich_info;
+    int ablate; // profiling only (env TS2D_ABLATE): 0 = full kernel; see render.hip
 };
 void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                           const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
