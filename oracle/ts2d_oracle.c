@@ -972,6 +972,21 @@ int ts2d_oracle_backward(const ts2d_oracle_state *s, float tan_fovx, float tan_f
     return 0;
 }
 
+/* Test hook: the SH colour polynomial alone (rgb_from_sh above, R2D/src/forward.cu:9-59) for n points, so that it
+ * can be pinned against the reference's Python eval_sh (tests/golden/sh_eval.npz).  rgb_out is the clamped
+ * colour (max(., 0) after +0.5), clamped_out the 3 flags per point. */
+void ts2d_oracle_sh_color(int n, int deg, int M, const float *shs, const float *pos, const float *campos,
+                          float *rgb_out, uint8_t *clamped_out)
+{
+    const f3 cp = {campos[0], campos[1], campos[2]};
+    for (int i = 0; i < n; i++)
+    {
+        const f3 p = {pos[3 * i], pos[3 * i + 1], pos[3 * i + 2]};
+        f3 c = rgb_from_sh(i, deg, M, p, cp, shs, clamped_out);
+        rgb_out[3 * i] = c.x; rgb_out[3 * i + 1] = c.y; rgb_out[3 * i + 2] = c.z;
+    }
+}
+
 /* ---- state introspection for tests --------------------------------------------------------- */
 int64_t ts2d_oracle_num_rendered(const ts2d_oracle_state *s) { return s->N; }
 int ts2d_oracle_grid_x(const ts2d_oracle_state *s) { return s->grid_x; }

@@ -65,6 +65,7 @@ def lib():
         L.ts2d_oracle_higher_msb.restype = C.c_uint32
         L.ts2d_oracle_higher_msb.argtypes = [C.c_uint32]
         L.ts2d_oracle_num_threads.restype = C.c_int
+        L.ts2d_oracle_sh_color.argtypes = [C.c_int, C.c_int, C.c_int, fp, fp, fp, fp, C.POINTER(C.c_uint8)]
         L.ts2d_oracle_set_num_threads.argtypes = [C.c_int]
         _lib = L
     return _lib
@@ -214,6 +215,17 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
     if rc != 0:
         raise RuntimeError(f"ts2d_oracle_backward failed with code {rc}")
     return dv, dc, dsh, df, dop
+
+
+def sh_color(deg: int, shs: np.ndarray, pos: np.ndarray, campos: np.ndarray):
+    """SH colour of n points (shs (n,M,3), pos (n,3)) seen from campos; returns (rgb (n,3), clamped (n,3) bool)."""
+    shs, pos, campos = _f32(shs), _f32(pos), _f32(campos, (3,))
+    n, M = shs.shape[0], shs.shape[1]
+    rgb = np.zeros((n, 3), np.float32)
+    cl = np.zeros((n, 3), np.uint8)
+    lib().ts2d_oracle_sh_color(n, int(deg), M, _fp(shs), _fp(pos), _fp(campos), _fp(rgb),
+                               cl.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return rgb, cl.astype(bool)
 
 
 def higher_msb(n: int) -> int:

@@ -1,0 +1,130 @@
+"""CPU tests of the drop-in boundary (no GPU, no compute calls): libts2d.so loads and exports every symbol that
+include/ts2d.h declares; the Python package mirrors the reference's interface (names, field order, errors)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ts2d.h")
+
+
+@pytest.fixture(scope="module")
+def lib(hip_lib_built):
+    return ctypes.CDLL(hip_lib_built)
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ts2d_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_expected_entry_points():
+    names = _declared_functions()
+    for must in ("ts2d_forward_bin", "ts2d_forward_render", "ts2d_backward", "ts2d_geometry_state_bytes",
+                 "ts2d_binning_state_bytes", "ts2d_image_state_bytes", "ts2d_backward_scratch_bytes", "ts2d_last_error",
+                 "ts2d_version", "ts2d_debug_read_state"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"libts2d.so does not export {name}"
+
+
+def test_state_size_queries_are_monotone_and_aligned(lib):
+    lib.ts2d_geometry_state_bytes.restype = ctypes.c_size_t
+    lib.ts2d_geometry_state_bytes.argtypes = [ctypes.c_int32]
+    lib.ts2d_image_state_bytes.restype = ctypes.c_size_t
+    lib.ts2d_image_state_bytes.argtypes = [ctypes.c_int32, ctypes.c_int32]
+    lib.ts2d_backward_scratch_bytes.restype = ctypes.c_size_t
+    lib.ts2d_backward_scratch_bytes.argtypes = [ctypes.c_int32]
+    a, b = lib.ts2d_geometry_state_bytes(1000), lib.ts2d_geometry_state_bytes(2000)
+    assert 1000 * 64 <= a < b  # at least the 64-byte render record per triangle
+    assert lib.ts2d_image_state_bytes(1920, 1080) >= 1920 * 1080 * 8 + 120 * 68 * 8
+    assert lib.ts2d_backward_scratch_bytes(1000) >= 1000 * 64
+    assert lib.ts2d_geometry_state_bytes(0) < 4096
+
+
+def test_null_arguments_are_rejected_not_crashed(lib):
+    lib.ts2d_forward_bin.restype = ctypes.c_int
+    lib.ts2d_last_error.restype = ctypes.c_char_p
+    rc = lib.ts2d_forward_bin(None, None, 0, None, None, None, None)
+    assert rc == 1 and b"null" in lib.ts2d_last_error()
+
+
+# ---- Python surface: same names / order / errors as R2D/diff_triangle_rasterization_2D/__init__.py ----------
+REFERENCE_SETTINGS_FIELDS = ("image_width", "image_height", "tanfovx", "tanfovy", "viewmatrix", "projmatrix", "campos",
+                             "sh_degree", "gamma", "scale_modifier", "background_depth", "background", "back_culling",
+                             "rich_info", "debug")  # reference __init__.py:28-46
+
+
+def _settings(**kw):
+    from diff_triangle_rasterization_2D import TriangleRasterizationSettings
+    base = dict(image_width=32, image_height=32, tanfovx=0.3, tanfovy=0.3, viewmatrix=torch.eye(4), projmatrix=torch.eye(4),
+                campos=torch.zeros(3), sh_degree=0, gamma=1.0, scale_modifier=1.0, background_depth=10.0,
+                background=torch.zeros(3), back_culling=False, rich_info=True, debug=False)
+    base.update(kw)
+    return TriangleRasterizationSettings(**base)
+
+
+def test_settings_namedtuple_matches_reference(hip_lib_built):
+    from diff_triangle_rasterization_2D import TriangleRasterizationSettings
+    assert TriangleRasterizationSettings._fields == REFERENCE_SETTINGS_FIELDS
+
+
+def test_rasterizer_module_surface(hip_lib_built):
+    from diff_triangle_rasterization_2D import TriangleRasterizer
+    rs = _settings()
+    r = TriangleRasterizer(rs)
+    assert isinstance(r, torch.nn.Module) and r.raster_settings is rs  # read by triangle_renderer.py:77
+    v, c2d, op = torch.rand(4, 3, 3), torch.zeros(4, 2), torch.rand(4, 1)
+    with pytest.raises(Exception, match="excatly one"):  # reference __init__.py:180-181 (sic)
+        r(v, c2d, op)
+    with pytest.raises(Exception, match="excatly one"):
+        r(v, c2d, op, shs=torch.rand(4, 1, 3), feature=torch.rand(4, 3))
+
+
+def test_argument_checks_mirror_reference_errors(hip_lib_built):
+    """extension_interface.cu:53-81: the same conditions raise RuntimeError with the same messages; tensors on the CPU
+    are refused loudly (there is no CPU fallback in the product path)."""
+    from diff_triangle_rasterization_2D import _C
+    E = torch.Tensor([])
+
+    def call(vertex=None, shs=None, feature=E, opacity=None, gamma=1.0, background=None, view=None):
+        vertex = torch.rand(4, 3, 3) if vertex is None else vertex
+        shs = torch.rand(4, 1, 3) if shs is None else shs
+        opacity = torch.rand(4, 1) if opacity is None else opacity
+        background = torch.zeros(3) if background is None else background
+        view = torch.eye(4) if view is None else view
+        return _C.rasterize_triangles(32, 32, 0.3, 0.3, view, torch.eye(4), torch.zeros(3), 0, gamma, 1.0, 10.0, background,
+                                      vertex, shs, feature, opacity, False, True, False)
+
+    with pytest.raises(RuntimeError, match=r"vertex must have dimensions \(num_points, 3, 3\)"):
+        call(vertex=torch.rand(4, 3, 2))
+    with pytest.raises(RuntimeError, match="num_channels can't be larger than MAX_CHANNELS"):
+        call(shs=E, feature=torch.rand(4, 5), background=torch.zeros(5))
+    with pytest.raises(RuntimeError, match="background must have the same number of channels"):
+        call(background=torch.zeros(2))
+    with pytest.raises(RuntimeError, match="gamma must be larger than 0"):
+        call(gamma=-1.0)
+    with pytest.raises(RuntimeError, match="input tensors must be contiguous"):
+        call(view=torch.arange(16.0).view(4, 4).t())  # a transposed view, like camera.py:112 before .contiguous()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        call()
+
+
+def test_missing_library_fails_loudly(tmp_path, hip_lib_built):
+    """The product must not degrade silently when the HIP library is absent."""
+    import shutil
+    import subprocess
+    import sys
+    pkg_src = os.path.join(ROOT, "triangle-splatting_amd", "diff_triangle_rasterization_2D")
+    pkg = tmp_path / "diff_triangle_rasterization_2D"
+    shutil.copytree(pkg_src, pkg, ignore=shutil.ignore_patterns("*.so", "__pycache__"))
+    r = subprocess.run([sys.executable, "-c", "import diff_triangle_rasterization_2D"], cwd=tmp_path, capture_output=True,
+                       text=True, env={**os.environ, "PYTHONPATH": str(tmp_path)})
+    assert r.returncode != 0 and "libts2d.so" in r.stderr and "no CPU fallback" in r.stderr
