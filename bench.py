@@ -51,13 +51,16 @@ def algorithmic_bytes(P, N, W, H, D, ntiles):
         "preprocess_fwd": P * (36 + sh + 99),
         "scan": P * 8,
         "emit_keys": P * 28 + N * 12,
-        "sort_pairs": N * 24 * passes,
+        "sort_pairs": N * 24 * passes,  # the reference's single 64-bit sort; counted in `total`
         "tile_ranges": N * 8,
         "render_fwd": N * 72 + W * H * 36,
         "render_bwd": N * 72 + W * H * 36 + P * 2 * 64,
         "preprocess_bwd": P * (36 + sh + 3 + 4 + 48 + 12) + P * (36 + 8 + sh),
     }
     k["total"] = sum(k.values())
+    # our two-stage ordering (binning.hip) moves fewer bytes than the SURVEY row; listed for the per-kernel table only
+    k["depth_sort"] = P * 16 * 4
+    k["tile_sort"] = N * 16 * -(-msb_bits(ntiles) // 8)
     return k
 
 

@@ -12,7 +12,7 @@ def run(P, W, H, D, rich=True, gamma=1.0, **kw):
     hf = helpers.hip_forward_backward(s, rich)
     print(f"--- P={P} {W}x{H} D={D} rich={rich} gamma={gamma} N(oracle)={of['num_rendered']} N(hip)={hf['num_rendered']} oracle {to:.2f}s")
     st = of["state"]
-    for name, oname in [("tiles_touched","tiles_touched"),("point_offsets","point_offsets"),("vals","vals"),("keys","keys"),("ranges","ranges"),("n_contrib","n_contrib")]:
+    for name, oname in [("tiles_touched","tiles_touched"),(("vals","vals"),("keys","keys"),("ranges","ranges"),("n_contrib","n_contrib")]:
         a = helpers.hip_state(hf, s, name); b = st.field(oname)
         a = a.astype(np.int64).reshape(-1); b = b.astype(np.int64).reshape(-1)
         if name == "keys": b = st.field("keys").view(np.int64).reshape(-1)

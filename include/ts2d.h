@@ -147,9 +147,10 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
  * (dst_bytes must be large enough), synchronising `stream`.  Fields:
  *   0 screen verts (P*6 f32: v1.xy v2.xy v3.xy)   1 area2 (P f32)       2 normal_view (P*3 f32)
  *   3 v_depth (P*3 f32)   4 depth key (P f32)      5 rgb (P*3 f32)       6 clamped (P u8, bits 0..2)
- *   7 point_offsets (P u32)  8 tiles_touched (P u32)  9 rect (P*4 u32: minx miny maxx maxy)
+ *   7 instance offsets in depth order (P u32)  8 tiles_touched (P u32)  9 rect (P*4 u32: minx miny maxx maxy)
  *   10 sorted keys (N u64)   11 sorted triangle ids (N u32)   12 ranges (T*2 u32)
- *   13 n_contrib (H*W u32)   14 final_T (H*W f32)   15 unsorted keys (N u64)  16 unsorted ids (N u32) */
+ *   13 n_contrib (H*W u32)   14 final_T (H*W f32)   15 unsorted tile ids (N u32)  16 unsorted ids (N u32)
+ *   17 triangle ids in (depth, id) order (P u32) */
 int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t num_rendered, int32_t width, int32_t height,
                           int32_t field, void *dst, size_t dst_bytes, void *stream);
 

@@ -26,12 +26,17 @@ def _check_state(s, hf, of):
     st = of["state"]
     assert hf["num_rendered"] == of["num_rendered"]
     assert np.array_equal(hf["radii"], of["radii"])
-    for hip_name, ora_name in [("tiles_touched", "tiles_touched"), ("point_offsets", "point_offsets"),
-                               ("vals", "vals"), ("ranges", "ranges")]:
+    for hip_name, ora_name in [("tiles_touched", "tiles_touched"), ("vals", "vals"), ("ranges", "ranges")]:
         a = helpers.hip_state(hf, s, hip_name).astype(np.int64).reshape(-1)
         b = st.field(ora_name).astype(np.int64).reshape(-1)
         assert np.array_equal(a, b), hip_name
     assert np.array_equal(helpers.hip_state(hf, s, "keys").reshape(-1), st.field("keys").view(np.int64).reshape(-1))
+    # private ordering state: triangles in (depth bits, id) order, and the instance slots that follow from it
+    perm = helpers.hip_state(hf, s, "depth_perm").astype(np.int64)
+    dbits = st.field("depth").view(np.uint32).astype(np.int64)
+    assert np.array_equal(perm, np.lexsort((np.arange(len(dbits)), dbits)))
+    assert np.array_equal(helpers.hip_state(hf, s, "point_offsets").astype(np.int64),
+                          np.cumsum(st.field("tiles_touched").astype(np.int64)[perm]))
     rect = helpers.hip_state(hf, s, "rect")
     vis = of["radii"] > 0
     assert np.array_equal(rect[vis, :2], st.field("rect_min")[vis].astype(np.int32))

@@ -193,6 +193,11 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     }
     TS_CHECK(flags, s, "preprocess_fwd");
     {
+        ProfScope ps("depth_sort", s);
+        TS_HIP(ts_sort_by_depth(g, P, s));
+    }
+    TS_CHECK(flags, s, "depth_sort");
+    {
         ProfScope ps("scan", s);
         TS_HIP(ts_scan_offsets(g, P, s));
     }
@@ -244,10 +249,10 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
         }
         TS_CHECK(flags, s, "emit_keys");
         {
-            ProfScope ps("sort_pairs", s);
-            TS_HIP(ts_sort_pairs(b, N, 32 + ts_higher_msb((uint32_t)ntiles), s)); // rasterizer.cu:210-218
+            ProfScope ps("tile_sort", s);
+            TS_HIP(ts_sort_pairs(b, N, ts_higher_msb((uint32_t)ntiles), s)); // tile bits only, see binning.hip
         }
-        TS_CHECK(flags, s, "sort_pairs");
+        TS_CHECK(flags, s, "tile_sort");
         {
             ProfScope ps("tile_ranges", s);
             ts_launch_tile_ranges(N, b, im, s);
@@ -374,13 +379,28 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
         }
         return TS2D_OK;
     }
-    case 10: src = b.keys; bytes = (size_t)N * 8; break;
+    case 10: // the reference's 64-bit key (tile << 32 | depth bits) of every sorted instance, rebuilt on the host
+    {
+        if (dst_bytes < (size_t)N * 8) return fail(TS2D_ERR_CAPACITY, "dst too small");
+        std::vector<uint32_t> tile((size_t)N), vals((size_t)N), depth((size_t)P);
+        if (N > 0)
+        {
+            TS_HIP(hipMemcpyAsync(tile.data(), b.tile, (size_t)N * 4, hipMemcpyDeviceToHost, s));
+            TS_HIP(hipMemcpyAsync(vals.data(), b.vals, (size_t)N * 4, hipMemcpyDeviceToHost, s));
+            TS_HIP(hipMemcpyAsync(depth.data(), g.depth, (size_t)P * 4, hipMemcpyDeviceToHost, s));
+            TS_HIP(hipStreamSynchronize(s));
+        }
+        uint64_t *o = (uint64_t *)dst;
+        for (int64_t i = 0; i < N; i++) o[i] = ((uint64_t)tile[i] << 32) | depth[vals[i]];
+        return TS2D_OK;
+    }
     case 11: src = b.vals; bytes = (size_t)N * 4; break;
     case 12: src = im.ranges; bytes = (size_t)gx * gy * 8; break;
     case 13: src = im.n_contrib; bytes = (size_t)W * H * 4; break;
     case 14: src = im.final_T; bytes = (size_t)W * H * 4; break;
-    case 15: src = b.keys_unsorted; bytes = (size_t)N * 8; break;
+    case 15: src = b.tile_unsorted; bytes = (size_t)N * 4; break;
     case 16: src = b.vals_unsorted; bytes = (size_t)N * 4; break;
+    case 17: src = g.perm; bytes = (size_t)P * 4; break;
     default: return fail(TS2D_ERR_INVALID, "unknown field %d", field);
     }
     if (dst_bytes < bytes) return fail(TS2D_ERR_CAPACITY, "dst too small");

@@ -155,6 +155,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a, i
     g.rect[idx] = out_rect;
     g.clamped[idx] = out_clamped;
     g.depth[idx] = out_depth;
+    g.ids[idx] = (uint32_t)idx; // values of the depth sort (binning.hip step 1)
     float4 *r = g.rec + 4 * (size_t)idx;
     r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
     r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);

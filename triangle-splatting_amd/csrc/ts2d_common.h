@@ -31,19 +31,23 @@
 struct GeometryStateView
 {
     float4 *rec;             // P * 4 float4
-    float *depth;            // P   sort key (centroid view-space z)
+    float *depth;            // P   sort key (centroid view-space z; its bit pattern is the radix key)
     uint32_t *tiles_touched; // P
-    uint32_t *offsets;       // P   inclusive prefix sum of tiles_touched
     uint2 *rect;             // P   x = minx | miny << 16, y = maxx | maxy << 16
     uint8_t *clamped;        // P   bit c set when colour channel c was clamped at 0
-    void *scan_temp;
+    uint32_t *ids;           // P   0..P-1 (values of the depth sort)
+    uint32_t *depth_sorted;  // P   depth keys in ascending order (sort output, unused afterwards)
+    uint32_t *perm;          // P   triangle ids in (depth, id) order
+    uint32_t *tiles_sorted;  // P   tiles_touched[perm[i]]
+    uint32_t *offsets;       // P   inclusive prefix sum of tiles_sorted: instance slots of the i-th nearest triangle
+    void *scan_temp;         //     shared by the depth sort and the scan
     size_t scan_temp_bytes;
 };
 
 struct BinningStateView
 {
-    uint64_t *keys_unsorted; // N
-    uint64_t *keys;          // N
+    uint32_t *tile_unsorted; // N   tile id of each instance, emitted in depth order
+    uint32_t *tile;          // N   sorted by tile (stable => depth order inside a tile)
     uint32_t *vals_unsorted; // N
     uint32_t *vals;          // N   triangle id per sorted instance
     void *sort_temp;
@@ -67,8 +71,8 @@ static inline void ts_carve(char *&p, T *&out, size_t count)
     p += count * sizeof(T);
 }
 
-size_t ts_scan_temp_bytes(int32_t P);
-size_t ts_sort_temp_bytes(int64_t N, int end_bit);
+size_t ts_scan_temp_bytes(int32_t P);                 // max(depth sort of P pairs, scan of P)
+size_t ts_sort_temp_bytes(int64_t N, int end_bit);    // tile sort of N pairs
 
 static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView &v)
 {
@@ -77,9 +81,13 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.rec, n * 4);
     ts_carve(p, v.depth, n);
     ts_carve(p, v.tiles_touched, n);
-    ts_carve(p, v.offsets, n);
     ts_carve(p, v.rect, n);
     ts_carve(p, v.clamped, n);
+    ts_carve(p, v.ids, n);
+    ts_carve(p, v.depth_sorted, n);
+    ts_carve(p, v.perm, n);
+    ts_carve(p, v.tiles_sorted, n);
+    ts_carve(p, v.offsets, n);
     v.scan_temp_bytes = ts_scan_temp_bytes(P);
     char *t;
     ts_carve(p, t, v.scan_temp_bytes);
@@ -105,11 +113,11 @@ static inline size_t ts_carve_binning(char *base, int64_t N, int32_t W, int32_t 
     char *p = base;
     size_t n = (size_t)(N > 0 ? N : 0);
     int gx = (W + TS_TILE - 1) / TS_TILE, gy = (H + TS_TILE - 1) / TS_TILE;
-    ts_carve(p, v.keys_unsorted, n);
-    ts_carve(p, v.keys, n);
+    ts_carve(p, v.tile_unsorted, n);
+    ts_carve(p, v.tile, n);
     ts_carve(p, v.vals_unsorted, n);
     ts_carve(p, v.vals, n);
-    v.sort_temp_bytes = ts_sort_temp_bytes(N, 32 + ts_higher_msb((uint32_t)(gx * gy)));
+    v.sort_temp_bytes = ts_sort_temp_bytes(N, ts_higher_msb((uint32_t)(gx * gy)));
     char *t;
     ts_carve(p, t, v.sort_temp_bytes);
     v.sort_temp = t;
@@ -138,6 +146,7 @@ struct PreprocessArgs
 };
 
 void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s);
+hipError_t ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s);
 hipError_t ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);
 void ts_launch_emit_keys(int P, int grid_x, const GeometryStateView &g, const BinningStateView &b, hipStream_t s);
 hipError_t ts_sort_pairs(const BinningStateView &b, int64_t N, int end_bit, hipStream_t s);

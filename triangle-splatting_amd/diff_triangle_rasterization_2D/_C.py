@@ -274,8 +274,8 @@ _FIELD_SPEC = {
     "tiles_touched": (8, torch.int32, lambda P, N, T, HW: (P,)), "rect": (9, torch.int32, lambda P, N, T, HW: (P, 4)),
     "keys": (10, torch.int64, lambda P, N, T, HW: (N,)), "vals": (11, torch.int32, lambda P, N, T, HW: (N,)),
     "ranges": (12, torch.int32, lambda P, N, T, HW: (T, 2)), "n_contrib": (13, torch.int32, lambda P, N, T, HW: HW),
-    "final_T": (14, torch.float32, lambda P, N, T, HW: HW), "keys_unsorted": (15, torch.int64, lambda P, N, T, HW: (N,)),
-    "vals_unsorted": (16, torch.int32, lambda P, N, T, HW: (N,)),
+    "final_T": (14, torch.float32, lambda P, N, T, HW: HW), "tile_unsorted": (15, torch.int32, lambda P, N, T, HW: (N,)),
+    "vals_unsorted": (16, torch.int32, lambda P, N, T, HW: (N,)), "depth_perm": (17, torch.int32, lambda P, N, T, HW: (P,)),
 }
 
 
