@@ -324,19 +324,11 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
         if (mask == 0) continue;
         publish_entry<RICH>(cst + lane * CST, s, id, r1, r2, r3);
 
-        int j = __builtin_ctzll(mask);
-        float4 n0 = *(const float4 *)(cst + j * CST), n1 = *(const float4 *)(cst + j * CST + 4);
         while (mask)
         {
-            const float4 c0 = n0, c1 = n1;
-            const int jc = j;
+            const int jc = __builtin_ctzll(mask);
             mask &= mask - 1;
-            if (mask) // prefetch the next entry's stage-1 constants behind this entry's arithmetic
-            {
-                j = __builtin_ctzll(mask);
-                n0 = *(const float4 *)(cst + j * CST);
-                n1 = *(const float4 *)(cst + j * CST + 4);
-            }
+            const float4 c0 = *(const float4 *)(cst + jc * CST), c1 = *(const float4 *)(cst + jc * CST + 4);
             const float a1 = fmaf(c0.x, fx, fmaf(c0.y, fy, c0.z));
             const float a2 = fmaf(c0.w, fx, fmaf(c1.x, fy, c1.y));
             const float a3 = 1.0f - a1 - a2;
@@ -492,26 +484,20 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
         publish_entry<RICH>(cst + lane * CST, s, id, r1, r2, r3);
         unsigned long long touched = 0; // entries of this batch that received gradient sums
 
-        int j = 63 - __builtin_clzll(mask);
-        float4 n0 = *(const float4 *)(cst + j * CST), n1 = *(const float4 *)(cst + j * CST + 4);
         while (mask)
         {
-            const float4 c0 = n0, c1 = n1;
-            const int jc = j;
+            const int jc = 63 - __builtin_clzll(mask);
             mask &= ~(1ull << jc);
-            if (mask) // prefetch the next entry's stage-1 constants behind this entry's arithmetic
-            {
-                j = 63 - __builtin_clzll(mask);
-                n0 = *(const float4 *)(cst + j * CST);
-                n1 = *(const float4 *)(cst + j * CST + 4);
-            }
+            const float4 c0 = *(const float4 *)(cst + jc * CST), c1 = *(const float4 *)(cst + jc * CST + 4);
             const float a1 = fmaf(c0.x, fx, fmaf(c0.y, fy, c0.z));
             const float a2 = fmaf(c0.w, fx, fmaf(c1.x, fy, c1.y));
             const float a3 = 1.0f - a1 - a2;
             const float ecc = 1.0f - 3.0f * fminf(fminf(a1, a2), a3);
             bool hit = (base + jc < last) && ecc >= 0.0f && ecc <= 10.0f; // backward.cu:378,393
             if (__ballot(hit) == 0) continue;
+#ifdef TS2D_ABLATION
             if (a.ablate == 3) { T += ecc * 1e-30f; continue; } // profiling: stage 1 only
+#endif
             const float4 c2 = *(const float4 *)(cst + jc * CST + 8);
             float4 c3 = make_float4(0, 0, 0, 0);
             float c4 = 0.0f;
@@ -527,7 +513,9 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
             const float alpha = fminf(0.99f, op * G);
             hit = hit && alpha >= 1.0f / 255.0f; // backward.cu:400
             if (__ballot(hit) == 0) continue;
+#ifdef TS2D_ABLATION
             if (a.ablate == 2) { T = T * __builtin_amdgcn_rcpf(1.0f - (hit ? alpha : 0.0f)); continue; } // profiling
+#endif
 
             // Branch-free from here on: lanes that do not hit run with alpha = 0 so that T, B stay bit-unchanged
             // and every term they produce is an exact 0 (all terms carry a factor alpha, contrib or `hit`).
@@ -562,6 +550,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
             v[9] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
             v[10] = dpr * contrib; v[11] = dpg * contrib; v[12] = dpb * contrib; // backward.cu:412
             v[13] = dnx * contrib; v[14] = dny * contrib; v[15] = dnz * contrib; // backward.cu:421-423
+#ifdef TS2D_ABLATION
             if (a.ablate == 1) // profiling: everything except the cross-lane reductions
             {
 #pragma unroll
@@ -569,6 +558,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
                 asm volatile("" ::"v"(w));
                 continue;
             }
+#endif
             const float r16 = reduce16(v, lane);
             if (writer16) sums[jc * CST + slot] = r16;
             if (RICH)
