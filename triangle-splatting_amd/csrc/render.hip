@@ -124,6 +124,40 @@ __device__ __forceinline__ float reduce16(float (&v)[16], int lane, Op op)
 }
 __device__ __forceinline__ float reduce16(float (&v)[16], int lane) { return reduce16(v, lane, OpAdd()); }
 
+// Same idea for 8 values: each lane returns the complete reduction of ONE of the 8 values, the 8 lanes of a group
+// (lane >> 3) share it.  Used by the forward's contribution statistics (8 parked entries per flush).
+template <typename Op>
+__device__ __forceinline__ float reduce8(float (&v)[8], int lane, Op op)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        swap32(v[2 * i], v[2 * i + 1]);
+        v[i] = op(v[2 * i], v[2 * i + 1]);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+    {
+        swap16(v[2 * i], v[2 * i + 1]);
+        v[i] = op(v[2 * i], v[2 * i + 1]);
+    }
+    const bool b3 = lane & 8;
+    const float own = b3 ? v[1] : v[0];
+    const float oth = b3 ? v[0] : v[1];
+    float r = op(own, dpp<DPP_ROR8>(oth));
+    r = op(r, dpp<DPP_HALF_MIRROR>(r));
+    r = op(r, dpp<DPP_XOR1>(r));
+    r = op(r, dpp<DPP_XOR2>(r));
+    return r;
+}
+__device__ __forceinline__ int slot8_of_lane(int lane)
+{
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = (lane == 0) ? (float)i : 0.0f;
+    return (int)reduce8(v, lane, OpAdd());
+}
+
 __device__ __forceinline__ int slot_of_lane(int lane)
 {
     float v[16];
@@ -173,7 +207,7 @@ __device__ __forceinline__ int slot4_of_lane(int lane)
 // table read with uniform addresses (ds_read_b128 broadcast): that costs no VALU issue slots, whereas one
 // v_readlane per constant costs ~4.3 cycles each (profiles/r01_valu_microbench.txt) in kernels that are VALU-bound.
 // Row layout (CST floats per entry; 20-dword stride keeps the 8-lane ds_write_b128 groups conflict-free):
-//   [0..3] A1 B1 C1 A2   [4..7] B2 C2 opacity id   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3
+//   [0..3] A1 B1 C1 A2   [4..6] B2 C2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [19] id
 constexpr int CST = 20;
 
 struct EntrySetup
@@ -237,13 +271,28 @@ __device__ __forceinline__ void publish_entry(float *row, const EntrySetup &s, u
 {
     float4 *q = (float4 *)row;
     q[0] = make_float4(s.A1, s.B1, s.C1, s.A2);
-    q[1] = make_float4(s.B2, s.C2, r1.z, __uint_as_float(id));
+    q[1] = make_float4(s.B2, s.C2, r1.z, 0.0f);
+    row[19] = __uint_as_float(id);
     q[2] = make_float4(r1.w, r2.x, r2.y, r2.z);
     if (RICH)
     {
         q[3] = make_float4(r2.w, r3.x, r3.y, r3.z);
         row[16] = r3.w;
     }
+}
+
+// Forward variant: exactly 16 floats per entry (the triangle id is not needed per pixel and travels by v_readlane):
+//   [0..3] A1 B1 C1 A2   [4..7] B2 C2 opacity r   [8..11] g b nx ny   [12..15] nz vd1 vd2 vd3
+constexpr int CSTF = 16;
+template <bool RICH>
+__device__ __forceinline__ void publish_entry_fwd(float *row, const EntrySetup &s, const float4 &r1, const float4 &r2,
+                                                  const float4 &r3)
+{
+    float4 *q = (float4 *)row;
+    q[0] = make_float4(s.A1, s.B1, s.C1, s.A2);
+    q[1] = make_float4(s.B2, s.C2, r1.z, r1.w);
+    q[2] = make_float4(r2.x, r2.y, r2.z, r2.w);
+    if (RICH) q[3] = make_float4(r3.x, r3.y, r3.z, r3.w);
 }
 
 template <bool RICH, bool GAMMA1>
@@ -254,8 +303,8 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
                                                           float *__restrict__ out_depth, float *__restrict__ out_normal,
                                                           float *__restrict__ contrib_sum, float *__restrict__ contrib_max)
 {
-    __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CST];
-    __shared__ float stage_all[RICH ? 4 : 1][16][64];
+    __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CSTF];
+    __shared__ float stage_all[RICH ? 4 : 1][8][64];
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -277,26 +326,26 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
     uint32_t last = (uint32_t)len; // a pixel that never saturates examines the whole list (forward.cu:296-297)
 
     // contrib_sum / contrib_max (forward.cu:323-324): the reference issues two global atomics per (pixel, triangle).
-    // Here each contributing entry parks its 64 per-pixel contributions in a wave-private LDS slot; every 16
-    // entries the 16 x 64 block is reduced by two transpose-reduce passes (sum, max) and leaves as ONE 16-lane
-    // atomic add + ONE 16-lane atomic max.  (LDS float atomics are not an option: ds_add_f32 measures ~190
+    // Here each contributing entry parks its 64 per-pixel contributions in a wave-private LDS slot; every 8
+    // entries the 8 x 64 block is reduced by two transpose-reduce passes (sum, max) and leaves as ONE 8-lane
+    // atomic add + ONE 8-lane atomic max.  (LDS float atomics are not an option: ds_add_f32 measures ~190
     // cycles per wave instruction on gfx950, see profiles/r01_lds_atomic_microbench.txt.)
     int staged = 0;          // entries parked so far (wave-uniform)
     uint32_t staged_ids = 0; // lane k holds the triangle id of parked entry k
-    const int slot = RICH ? slot_of_lane(lane) : 0;
+    const int slot = RICH ? slot8_of_lane(lane) : 0;
     auto flush = [&]() {
-        float vs[16], vm[16];
+        float vs[8], vm[8];
 #pragma unroll
-        for (int i = 0; i < 16; i++)
+        for (int i = 0; i < 8; i++)
         {
             const float x = (i < staged) ? stage[i][lane] : 0.0f;
             vs[i] = x;
             vm[i] = x;
         }
-        const float rs = reduce16(vs, lane, OpAdd());
-        const float rm = reduce16(vm, lane, OpMax());
+        const float rs = reduce8(vs, lane, OpAdd());
+        const float rm = reduce8(vm, lane, OpMax());
         const uint32_t gid = (uint32_t)__shfl((int)staged_ids, slot);
-        if ((lane & 3) == 0 && slot < staged)
+        if ((lane & 7) == 0 && slot < staged)
         {
             unsafeAtomicAdd(contrib_sum + gid, rs);
             atomicMax((int *)contrib_max + gid, __float_as_int(rm)); // rm > 0: int order == float order
@@ -322,27 +371,22 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
         const EntrySetup s = entry_setup<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
         unsigned long long mask = __ballot(valid && s.overlap);
         if (mask == 0) continue;
-        publish_entry<RICH>(cst + lane * CST, s, id, r1, r2, r3);
+        publish_entry_fwd<RICH>(cst + lane * CSTF, s, r1, r2, r3);
 
         while (mask)
         {
             const int jc = __builtin_ctzll(mask);
             mask &= mask - 1;
-            const float4 c0 = *(const float4 *)(cst + jc * CST), c1 = *(const float4 *)(cst + jc * CST + 4);
+            const float4 c0 = *(const float4 *)(cst + jc * CSTF), c1 = *(const float4 *)(cst + jc * CSTF + 4);
             const float a1 = fmaf(c0.x, fx, fmaf(c0.y, fy, c0.z));
             const float a2 = fmaf(c0.w, fx, fmaf(c1.x, fy, c1.y));
             const float a3 = 1.0f - a1 - a2;
             const float ecc = 1.0f - 3.0f * fminf(fminf(a1, a2), a3);
             bool hit = !done && ecc >= 0.0f && ecc <= 10.0f; // forward.cu:307
             if (__ballot(hit) == 0) continue;
-            const float4 c2 = *(const float4 *)(cst + jc * CST + 8);
+            const float4 c2 = *(const float4 *)(cst + jc * CSTF + 8);
             float4 c3 = make_float4(0, 0, 0, 0);
-            float c4 = 0.0f;
-            if (RICH)
-            {
-                c3 = *(const float4 *)(cst + jc * CST + 12);
-                c4 = cst[jc * CST + 16];
-            }
+            if (RICH) c3 = *(const float4 *)(cst + jc * CSTF + 12);
             const float pw = GAMMA1 ? ecc * ecc : pow_nonneg(ecc, g2);
             const float alpha = fminf(0.99f, c1.z * fast_exp(-0.5f * pw)); // forward.cu:311-312
             hit = hit && alpha >= 1.0f / 255.0f;                           // forward.cu:313
@@ -351,19 +395,19 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
             // bit-unchanged (x + c*0 == x, T*1 == T).
             const float al = hit ? alpha : 0.0f;
             const float contrib = al * T;
-            ar = fmaf(c2.x, contrib, ar);
-            ag = fmaf(c2.y, contrib, ag);
-            ab = fmaf(c2.z, contrib, ab);
+            ar = fmaf(c1.w, contrib, ar);
+            ag = fmaf(c2.x, contrib, ag);
+            ab = fmaf(c2.y, contrib, ab);
             if (RICH)
             {
-                anx = fmaf(c2.w, contrib, anx);
-                any_ = fmaf(c3.x, contrib, any_);
-                anz = fmaf(c3.y, contrib, anz);
-                const float d = c3.z * a1 + c3.w * a2 + c4 * a3; // forward.cu:328
+                anx = fmaf(c2.z, contrib, anx);
+                any_ = fmaf(c2.w, contrib, any_);
+                anz = fmaf(c3.x, contrib, anz);
+                const float d = c3.y * a1 + c3.z * a2 + c3.w * a3; // forward.cu:328
                 ad = fmaf(d, contrib, ad);
                 stage[staged][lane] = contrib;
-                staged_ids = (lane == staged) ? __float_as_uint(c1.w) : staged_ids;
-                if (++staged == 16) flush();
+                staged_ids = (lane == staged) ? bcast(id, jc) : staged_ids;
+                if (++staged == 8) flush();
             }
             T *= (1.0f - al);
             if (hit && T <= 0.0001f) // forward.cu:333
@@ -419,7 +463,6 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
                                                           const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
     __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CST];
-    __shared__ __attribute__((aligned(16))) float sums_all[4][64 * CST];
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -433,7 +476,10 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
     const float g2 = 2.0f * a.gamma;
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
     float *cst = cst_all[wave];
-    float *sums = sums_all[wave];
+    // The 19 reduced sums of an entry are parked in the entry's own constants row: the row is dead once the entry has
+    // been processed (each entry is visited once per batch; LDS executes a wave's accesses in order) except for the
+    // triangle id in slot 19.
+    float *sums = cst;
 
     float T = inside ? final_T[pix] : 0.0f;            // backward.cu:318
     const int last = inside ? (int)n_contrib[pix] : 0; // backward.cu:320
@@ -564,7 +610,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
             if (RICH)
             {
                 const float r4 = reduce4(w, w * fx, w * fy, 0.0f);
-                if (writer4) sums[jc * CST + 16 + slot4] = r4;
+                if (writer4 && slot4 < 3) sums[jc * CST + 16 + slot4] = r4; // slot 19 keeps the triangle id
             }
             touched |= 1ull << jc;
         }
@@ -617,7 +663,7 @@ __global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uin
                 const int e = e0 + sub;
                 if ((touched >> e) & 1)
                 {
-                    const uint32_t eid = __float_as_uint(cst[e * CST + 7]);
+                    const uint32_t eid = __float_as_uint(cst[e * CST + 19]);
                     if (RICH || col < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + col, sums[e * CST + col]);
                 }
             }
