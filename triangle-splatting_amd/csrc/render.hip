@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
 // wave, parks the 19 sums of entry j in LDS, and once per batch the lane that OWNS entry j turns them into the 16
 // gradient values with its own (register-resident) triangle constants and issues the global atomics.
 template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256) render_bwd_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+__global__ void __launch_bounds__(256, 7) render_bwd_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                           const uint32_t *__restrict__ point_list,
                                                           const float4 *__restrict__ rec, const float *__restrict__ final_T,
                                                           const uint32_t *__restrict__ n_contrib,
