@@ -157,6 +157,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t num_render
 /* Timing hook used by bench.py: when enabled, ts2d_forward_render / ts2d_backward bracket each kernel
  * with HIP events on `stream`; ts2d_profile_read copies out (name, total_ms, launches) rows. */
 void ts2d_profile_enable(int on);
+void ts2d_profile_only(const char *kernel_name); /* NULL or "" = time every kernel; else only the named one */
 void ts2d_profile_reset(void);
 int ts2d_profile_read(int32_t index, char *name, size_t name_bytes, double *total_ms, int64_t *launches);
 

@@ -52,6 +52,7 @@ struct ProfRow { std::string name; double ms = 0; int64_t launches = 0; };
 struct ProfPending { int row; hipEvent_t a, b; };
 std::mutex g_prof_mu;
 bool g_prof_on = false;
+std::string g_prof_only; // when non-empty, only scopes with exactly this name are timed
 std::vector<ProfRow> g_prof_rows;
 std::vector<ProfPending> g_prof_pending;
 std::vector<hipEvent_t> g_prof_free;
@@ -65,6 +66,7 @@ struct ProfScope
     {
         if (!g_prof_on) return;
         std::lock_guard<std::mutex> lk(g_prof_mu);
+        if (!g_prof_only.empty() && g_prof_only != name) return;
         for (size_t i = 0; i < g_prof_rows.size(); i++)
             if (g_prof_rows[i].name == name) row = (int)i;
         if (row < 0) { g_prof_rows.push_back({name, 0, 0}); row = (int)g_prof_rows.size() - 1; }
@@ -416,6 +418,11 @@ void ts2d_profile_enable(int on)
 {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = on != 0;
+}
+void ts2d_profile_only(const char *name)
+{
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_only = name ? name : "";
 }
 void ts2d_profile_reset(void)
 {

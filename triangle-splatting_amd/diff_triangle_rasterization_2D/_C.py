@@ -92,6 +92,7 @@ _lib.ts2d_debug_read_state.restype = C.c_int
 _lib.ts2d_debug_read_state.argtypes = [C.POINTER(_State), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp,
                                        C.c_size_t, _fp]
 _lib.ts2d_profile_enable.argtypes = [C.c_int]
+_lib.ts2d_profile_only.argtypes = [C.c_char_p]
 _lib.ts2d_profile_read.restype = C.c_int
 _lib.ts2d_profile_read.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
 
@@ -294,6 +295,10 @@ def debug_read_state(name, P, num_rendered, W, H, geometryBuffer, binningBuffer,
 
 def profile_enable(on: bool):
     _lib.ts2d_profile_enable(1 if on else 0)
+
+
+def profile_only(name: str = ""):
+    _lib.ts2d_profile_only(name.encode() if name else None)
 
 
 def profile_reset():
