@@ -141,11 +141,13 @@ def main():
     # dominant kernel).  In the timed region only the dominant kernel is bracketed by events (2 events per step on
     # the launch stream) so that the measurement does not perturb `value` (all-kernel events cost ~2.7 %).
     events = not args.no_kernel_events
+    step()  # cold step (library initialisation, allocator growth) -- never timed
+    barrier()
     if events:
         _C.profile_reset()
         _C.profile_only("")
         _C.profile_enable(True)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup - 1, 1)):
         step()
     barrier()
     warm_rows = _C.profile_read() if events else []
