@@ -200,3 +200,15 @@ def test_full_size_properties():
     grads2 = torch.autograd.grad([out[0], out[2], out[3]], [vertex, opacity], [2.5 * g1, gd, gn])
     for a, b2 in zip(grads1, grads2):
         assert float((2.5 * a - b2).norm() / b2.norm()) < 2e-4  # fp32 atomics: summation order differs between runs
+
+
+def test_refstruct_mode_matches(monkeypatch):
+    """The reference-structured measurement kernels (TS2D_MODE=refstruct, csrc/refstruct.hip) produce the same results
+    as the oracle, so timing them is a fair stand-in for 'the reference structure on this hardware'."""
+    monkeypatch.setenv("TS2D_MODE", "refstruct")
+    s = synthetic.scene(3000, 160, 112, 3, seed=77)
+    of = helpers.oracle_forward(s, True)
+    ob = helpers.oracle_backward(s, of, True)
+    hf = helpers.hip_forward_backward(s, True)
+    _check_state(s, hf, of)
+    _check_outputs(hf, of, ob, True)

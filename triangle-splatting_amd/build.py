@@ -29,6 +29,7 @@ SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+    "refstruct.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],  # measurement aid (TS2D_MODE=refstruct)
     "api.hip": [],
 }
 HEADERS = ["ts2d_common.h", "ts2d_math.h", os.path.join("..", "..", "include", "ts2d.h")]

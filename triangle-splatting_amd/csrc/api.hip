@@ -147,6 +147,8 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.rich_info = flags & TS2D_FLAG_RICH_INFO;
     const char *ab = getenv("TS2D_ABLATE");
     r.ablate = ab ? atoi(ab) : 0;
+    const char *mode = getenv("TS2D_MODE");
+    r.refstruct = (mode && strcmp(mode, "refstruct") == 0) ? 1 : 0;
     return r;
 }
 } // namespace
@@ -263,7 +265,10 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     }
     {
         ProfScope ps("render_fwd", s);
-        ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+        if (r.refstruct)
+            ts_launch_refstruct_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+        else
+            ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
     }
     TS_CHECK(flags, s, "render_fwd");
     return TS2D_OK;
@@ -305,7 +310,10 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     if (N > 0)
     {
         ProfScope ps("render_bwd", s);
-        ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
+        if (r.refstruct)
+            ts_launch_refstruct_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
+        else
+            ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
     }
     TS_CHECK(flags, s, "render_bwd");
     {

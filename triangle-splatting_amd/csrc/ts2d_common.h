@@ -158,7 +158,8 @@ struct RenderArgs
     float gamma, background_depth;
     const float *background; // C floats, device
     bool rich_info;
-    int ablate; // profiling only (env TS2D_ABLATE): 0 = full kernel; see render.hip
+    int ablate; // profiling only (env TS2D_ABLATE, builds with -DTS2D_ABLATION): 0 = full kernel; see render.hip
+    int refstruct; // measurement aid (env TS2D_MODE=refstruct): reference-structured blend kernels, see refstruct.hip
 };
 void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                           const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
@@ -166,6 +167,12 @@ void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const
 void ts_launch_render_bwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                           const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
                           const float *dL_dout_normal, float *grad_rec, hipStream_t s);
+void ts_launch_refstruct_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
+                             const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
+                             float *contrib_sum, float *contrib_max, hipStream_t s);
+void ts_launch_refstruct_bwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
+                             const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
+                             const float *dL_dout_normal, float *grad_rec, hipStream_t s);
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                               float *dL_dfeature, float *dL_dopacity, hipStream_t s);
