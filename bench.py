@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", default="product", choices=["product", "refstruct"],
                     help="refstruct = reference-structured blend kernels (measurement aid, BASELINE.md section 3)")
+    ap.add_argument("--rasterizer", default="2D", choices=["2D", "3D"],
+                    help="2D = the headline path (BASELINE.json); 3D = the ray/plane variant (SURVEY.md 8f rank 1), not the headline")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -94,6 +96,8 @@ def main():
 
     import synthetic
     from diff_triangle_rasterization_2D import TriangleRasterizationSettings, TriangleRasterizer, _C
+    if args.rasterizer == "3D":
+        from diff_triangle_rasterization_3D import TriangleRasterizer
     from diff_triangle_rasterization_2D.parallel import GradBucket
 
     P, W, H, D = args.triangles, args.width, args.height, args.sh_degree
@@ -183,7 +187,7 @@ def main():
         "value": round(mpix_s, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"mode": args.mode, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
+        "config": {"mode": args.mode, "rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
                    "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N,
                    "parallelism": f"image-parallel x{world}" + (", RCCL all-reduce of per-triangle grads" if world > 1 else ""),
                    "algorithmic_bytes_per_step": alg["total"],
@@ -207,7 +211,7 @@ def main():
         else:
             result["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(s, state["image"].detach().cpu().numpy())
+            result["cpu_baseline"] = cpu_baseline(s, state["image"].detach().cpu().numpy(), 3 if args.rasterizer == "3D" else 2)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -223,7 +227,7 @@ def hbm_traffic(kernel):
         return None
 
 
-def cpu_baseline(s, hip_image):
+def cpu_baseline(s, hip_image, variant=2):
     """The CPU oracle (a port of the reference algorithm, OpenMP over tiles, all host cores) on the same scene:
     one fwd+bwd.  The full 1M-triangle / 1080p step is ~15-20 s on 8 cores, which is the bounded sample."""
     from oracle import ts2d_oracle as O
@@ -234,7 +238,7 @@ def cpu_baseline(s, hip_image):
 
     cores = O.num_threads()
     t0 = time.perf_counter()
-    of = helpers.oracle_forward(s, rich_info=True)
+    of = helpers.oracle_forward(s, rich_info=True, variant=variant)
     t1 = time.perf_counter()
     helpers.oracle_backward(s, of, rich_info=True)
     t2 = time.perf_counter()

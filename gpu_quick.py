@@ -6,13 +6,15 @@ import numpy as np, torch
 import synthetic, helpers
 from oracle import ts2d_oracle as O
 
+VARIANT = int(os.environ.get('TS_VARIANT', '2'))
+
 def run(P, W, H, D, rich=True, gamma=1.0, **kw):
     s = synthetic.scene(P, W, H, D, **kw); s["gamma"] = gamma
-    t = time.time(); of = helpers.oracle_forward(s, rich); ob = helpers.oracle_backward(s, of, rich); to = time.time() - t
-    hf = helpers.hip_forward_backward(s, rich)
+    t = time.time(); of = helpers.oracle_forward(s, rich, variant=VARIANT); ob = helpers.oracle_backward(s, of, rich); to = time.time() - t
+    hf = helpers.hip_forward_backward(s, rich, variant=VARIANT)
     print(f"--- P={P} {W}x{H} D={D} rich={rich} gamma={gamma} N(oracle)={of['num_rendered']} N(hip)={hf['num_rendered']} oracle {to:.2f}s")
     st = of["state"]
-    for name, oname in [("tiles_touched","tiles_touched"),(("vals","vals"),("keys","keys"),("ranges","ranges"),("n_contrib","n_contrib")]:
+    for name, oname in [("tiles_touched","tiles_touched"),("vals","vals"),("keys","keys"),("ranges","ranges"),("n_contrib","n_contrib")]:
         a = helpers.hip_state(hf, s, name); b = st.field(oname)
         a = a.astype(np.int64).reshape(-1); b = b.astype(np.int64).reshape(-1)
         if name == "keys": b = st.field("keys").view(np.int64).reshape(-1)

@@ -52,6 +52,9 @@ extern "C" {
 #define TS2D_FLAG_RICH_INFO 0x2u    /* R2D settings.rich_info: depth, normal, contrib_sum/max + their grads */
 #define TS2D_FLAG_DEBUG 0x4u        /* R2D settings.debug: synchronise + check after every kernel (auxiliary.h:358-367) */
 #define TS2D_FLAG_USE_SHS 0x8u      /* colour from SH coefficients (extension_interface.cu:44) instead of `feature` */
+#define TS2D_FLAG_3D 0x10u          /* rasterizer_type "3D": the ray/plane variant, submodules/diff-triangle-rasterization-3D
+                                       (same entry points and argument lists, R3D/src/extension_interface.cu:14-276;
+                                       R3D has no `contiguous` check, its forward.cu/backward.cu replace the 2D maths) */
 
 #define TS2D_MAX_CHANNELS 3 /* R2D/src/config.h:3 */
 #define TS2D_TILE 16        /* R2D/src/config.h:4-5 (BLOCK_X = BLOCK_Y = 16) */
@@ -150,7 +153,8 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
  *   7 instance offsets in depth order (P u32)  8 tiles_touched (P u32)  9 rect (P*4 u32: minx miny maxx maxy)
  *   10 sorted keys (N u64)   11 sorted triangle ids (N u32)   12 ranges (T*2 u32)
  *   13 n_contrib (H*W u32)   14 final_T (H*W f32)   15 unsorted tile ids (N u32)  16 unsorted ids (N u32)
- *   17 triangle ids in (depth, id) order (P u32) */
+ *   17 triangle ids in (depth, id) order (P u32)   18 raw render records (P*16 f32; with TS2D_FLAG_3D: v1_view v2_view
+ *   v3_view normal_view opacity rgb -- fields 0-3 and 5 decode the 2D record layout only) */
 int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t num_rendered, int32_t width, int32_t height,
                           int32_t field, void *dst, size_t dst_bytes, void *stream);
 

@@ -189,6 +189,9 @@ static inline f3 dnormvdv3(f3 v, f3 dv)
 typedef struct ts2d_oracle_state
 {
     int W, H, P, C, grid_x, grid_y, rich_info;
+    int variant; /* 2 = R2D (screen-space barycentrics), 3 = R3D (view-space ray/plane barycentrics) */
+    float tan_fovx, tan_fovy; /* R3D blend kernels need them (R3D/src/rasterizer.cu:232-233) */
+    f3 *v1_view, *v2_view, *v3_view; /* R3D GeometryState, R3D/src/param_struct.h:46-48 */
     int64_t N; /* num_rendered */
     /* GeometryState, param_struct.h:46-58 */
     f2 *v1_2D, *v2_2D, *v3_2D;
@@ -217,7 +220,7 @@ void ts2d_oracle_free(ts2d_oracle_state *s)
     free(s->v_depth); free(s->depth); free(s->rgb); free(s->clamped); free(s->point_offsets);
     free(s->tiles_touched); free(s->rect_min); free(s->rect_max); free(s->keys_unsorted);
     free(s->keys); free(s->vals_unsorted); free(s->vals); free(s->ranges); free(s->n_contrib);
-    free(s->final_T);
+    free(s->final_T); free(s->v1_view); free(s->v2_view); free(s->v3_view);
     free(s);
 }
 
@@ -451,6 +454,66 @@ static void bin_and_sort(ts2d_oracle_state *s)
     }
 }
 
+/* ---- R3D variant (submodules/diff-triangle-rasterization-3D, "R3D"): same host pipeline, different preprocess and
+ * per-pixel mathematics.  R3D/src/auxiliary.h:35-43 */
+static inline float proj_to_pix(float v, int S) { return (v + 1.0f) * S * 0.5f - 0.5f; }
+static inline float pix_to_proj(float v, int S) { return (2.0f * v - S + 1.0f) / (float)(S); }
+
+/* R3D/src/forward.cu:60-146 */
+static void preprocess_forward_3d(ts2d_oracle_state *s, int D, int M, int use_shs, int back_culling, const float *view,
+                                  const float *proj, const float *campos, const float *vertex, const float *shs, int *radii)
+{
+    const int W = s->W, H = s->H, P = s->P;
+    const int gx = s->grid_x, gy = s->grid_y;
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++)
+    {
+        radii[idx] = 0;
+        s->tiles_touched[idx] = 0;
+        const f3 v1 = {vertex[9 * (size_t)idx], vertex[9 * (size_t)idx + 1], vertex[9 * (size_t)idx + 2]};
+        const f3 v2 = {vertex[9 * (size_t)idx + 3], vertex[9 * (size_t)idx + 4], vertex[9 * (size_t)idx + 5]};
+        const f3 v3 = {vertex[9 * (size_t)idx + 6], vertex[9 * (size_t)idx + 7], vertex[9 * (size_t)idx + 8]};
+        const f3 v1_view = xform_point_4x3(v1, view), v2_view = xform_point_4x3(v2, view), v3_view = xform_point_4x3(v3, view);
+        const f3 center_view = f3_div(f3_add(f3_add(v1_view, v2_view), v3_view), 3.0f);
+        const f3 normal_view = f3_cross(f3_sub(v2_view, v1_view), f3_sub(v3_view, v1_view));
+        if (f3_norm(normal_view) < TS_EPS) continue;           /* forward.cu:99 */
+        if (back_culling && normal_view.z >= 0) continue;      /* forward.cu:101 */
+
+        const float dilation = 3.0f;
+        const f3 center = f3_div(f3_add(f3_add(v1, v2), v3), 3.0f);
+        const f3 d1 = f3_add(center, f3_lscale(dilation, f3_sub(v1, center)));
+        const f3 d2 = f3_add(center, f3_lscale(dilation, f3_sub(v2, center)));
+        const f3 d3 = f3_add(center, f3_lscale(dilation, f3_sub(v3, center)));
+        const f3 p1 = project_point(d1, proj), p2 = project_point(d2, proj), p3 = project_point(d3, proj);
+        if (p1.z <= 0 || p2.z <= 0 || p3.z <= 0) continue;     /* near culling, forward.cu:114 */
+
+        const f2 q1 = {proj_to_pix(p1.x, W), proj_to_pix(p1.y, H)};
+        const f2 q2 = {proj_to_pix(p2.x, W), proj_to_pix(p2.y, H)};
+        const f2 q3 = {proj_to_pix(p3.x, W), proj_to_pix(p3.y, H)};
+        const f2 v_min = {fminf(fminf(q1.x, q2.x), q3.x), fminf(fminf(q1.y, q2.y), q3.y)};
+        const f2 v_max = {fmaxf(fmaxf(q1.x, q2.x), q3.x), fmaxf(fmaxf(q1.y, q2.y), q3.y)};
+        const int rminx = imin(gx, imax(0, f2i_sat(v_min.x / TS_BLOCK_X)));
+        const int rminy = imin(gy, imax(0, f2i_sat(v_min.y / TS_BLOCK_Y)));
+        const int rmaxx = imin(gx, imax(0, f2i_sat((v_max.x + TS_BLOCK_X - 1) / TS_BLOCK_X)));
+        const int rmaxy = imin(gy, imax(0, f2i_sat((v_max.y + TS_BLOCK_Y - 1) / TS_BLOCK_Y)));
+        if (rmaxx <= rminx || rmaxy <= rminy) continue;
+
+        if (use_shs)
+        {
+            const f3 cp = {campos[0], campos[1], campos[2]};
+            f3 rgb = rgb_from_sh(idx, D, M, center, cp, shs, s->clamped);
+            s->rgb[idx * 3 + 0] = rgb.x; s->rgb[idx * 3 + 1] = rgb.y; s->rgb[idx * 3 + 2] = rgb.z;
+        }
+        s->v1_view[idx] = v1_view; s->v2_view[idx] = v2_view; s->v3_view[idx] = v3_view;
+        s->normal_view[idx] = normal_view; /* NOT normalised in R3D */
+        s->depth[idx] = center_view.z;
+        s->tiles_touched[idx] = (uint32_t)(rmaxx - rminx) * (uint32_t)(rmaxy - rminy);
+        s->rect_min[2 * idx] = rminx; s->rect_min[2 * idx + 1] = rminy;
+        s->rect_max[2 * idx] = rmaxx; s->rect_max[2 * idx + 1] = rmaxy;
+        radii[idx] = f2i_sat(fmaxf(ceilf((v_max.x - v_min.x) * 0.5f), ceilf((v_max.y - v_min.y) * 0.5f)));
+    }
+}
+
 static inline void atomic_add_d(double *p, double v)
 {
 #pragma omp atomic
@@ -537,6 +600,257 @@ static void render_forward(ts2d_oracle_state *s, float gamma, const float *featu
     }
 }
 
+static void rgb_from_sh_backward(int idx, int deg, int max_coeffs, f3 pos, f3 campos, const float *shs,
+                                 const uint8_t *clamped, const f3 *dL_dfeature, f3 *dL_dshs, f3 *dL_dpos);
+
+/* R3D/src/forward.cu:151-306 -- per-pixel ray / triangle-plane intersection in view space */
+static void render_forward_3d(ts2d_oracle_state *s, float gamma, const float *feature, const float *opacity,
+                              float background_depth, const float *background, float *out_feature, float *out_depth,
+                              float *out_normal, double *contrib_sum_d, float *contrib_max)
+{
+    const int W = s->W, H = s->H, C = s->C, rich = s->rich_info;
+    const int ntiles = s->grid_x * s->grid_y;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < ntiles; tile++)
+    {
+        const int tx = tile % s->grid_x, ty = tile / s->grid_x;
+        const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        for (int ly = 0; ly < TS_BLOCK_Y; ly++)
+            for (int lx = 0; lx < TS_BLOCK_X; lx++)
+            {
+                const uint32_t px = tx * TS_BLOCK_X + lx, py = ty * TS_BLOCK_Y + ly;
+                if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
+                const uint32_t pix_id = W * py + px;
+                const f3 p_ray = {s->tan_fovx * pix_to_proj((float)px, W), s->tan_fovy * pix_to_proj((float)py, H), 1.0f};
+                float T = 1.0f;
+                uint32_t contributor = 0, last_contributor = 0;
+                float accum_feature[TS_MAX_CHANNELS] = {0, 0, 0};
+                f3 accum_normal = {0, 0, 0};
+                float accum_depth = 0.0f;
+                for (uint32_t k = r0; k < r1; k++)
+                {
+                    contributor++;
+                    last_contributor = contributor;
+                    const uint32_t id = s->vals[k];
+                    const f3 v1 = s->v1_view[id], v2 = s->v2_view[id], v3 = s->v3_view[id], n = s->normal_view[id];
+                    const float p_ray_dot_n = f3_dot(p_ray, n);
+                    if (fabsf(p_ray_dot_n) < TS_EPS) continue;
+                    const float depth = f3_dot(v1, n) / p_ray_dot_n;
+                    const f3 p_view = f3_lscale(depth, p_ray);
+                    const f3 p_v1 = f3_sub(v1, p_view), p_v2 = f3_sub(v2, p_view), p_v3 = f3_sub(v3, p_view);
+                    const float inv_n_dot_n = 1.0f / f3_dot(n, n);
+                    const float a1 = f3_dot(f3_cross(p_v2, p_v3), n) * inv_n_dot_n;
+                    const float a2 = f3_dot(f3_cross(p_v3, p_v1), n) * inv_n_dot_n;
+                    const float a3 = 1.0f - a1 - a2;
+                    const float ecc = 1.0f - 3.0f * fminf(fminf(a1, a2), a3);
+                    if (ecc < 0.0f || ecc > 10.0f) continue;
+                    const float power = -0.5f * powf(ecc, 2.0f * gamma);
+                    const float alpha = fminf(0.99f, opacity[id] * expf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    const float contrib = alpha * T;
+                    T *= (1.0f - alpha);
+                    for (int ch = 0; ch < C; ch++) accum_feature[ch] += feature[id * C + ch] * contrib;
+                    if (rich)
+                    {
+                        atomic_add_d(&contrib_sum_d[id], (double)contrib);
+                        atomic_max_f(&contrib_max[id], contrib);
+                        accum_normal.x += n.x * contrib; accum_normal.y += n.y * contrib; accum_normal.z += n.z * contrib;
+                        accum_depth += depth * contrib;
+                    }
+                    if (T <= 0.0001f) break;
+                }
+                s->final_T[pix_id] = T;
+                s->n_contrib[pix_id] = last_contributor;
+                for (int ch = 0; ch < C; ch++) out_feature[(size_t)ch * H * W + pix_id] = accum_feature[ch] + T * background[ch];
+                if (rich)
+                {
+                    out_depth[pix_id] = accum_depth + T * background_depth;
+                    out_normal[pix_id] = accum_normal.x;
+                    out_normal[(size_t)H * W + pix_id] = accum_normal.y;
+                    out_normal[2 * (size_t)H * W + pix_id] = accum_normal.z;
+                }
+            }
+    }
+}
+
+/* R3D/src/backward.cu:216-454.  g_v: P*9 (v1,v2,v3 view-space), g_normal: P*3, g_feature: P*C, g_opacity: P.
+ * Keeps the reference's quirk that the skip test here is on G, not on alpha (backward.cu:351 vs forward.cu:265). */
+static void render_backward_3d(const ts2d_oracle_state *s, float gamma, const float *feature, const float *opacity,
+                               float background_depth, const float *background, const float *dL_dout_feature,
+                               const float *dL_dout_depth, const float *dL_dout_normal, double *g_v, double *g_normal,
+                               double *g_feature, double *g_opacity)
+{
+    const int W = s->W, H = s->H, C = s->C, rich = s->rich_info;
+    const int ntiles = s->grid_x * s->grid_y;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int tile = 0; tile < ntiles; tile++)
+    {
+        const int tx = tile % s->grid_x, ty = tile / s->grid_x;
+        const uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        for (int ly = 0; ly < TS_BLOCK_Y; ly++)
+            for (int lx = 0; lx < TS_BLOCK_X; lx++)
+            {
+                const uint32_t px = tx * TS_BLOCK_X + lx, py = ty * TS_BLOCK_Y + ly;
+                if (!(px < (uint32_t)W && py < (uint32_t)H)) continue;
+                const uint32_t pix_id = W * py + px;
+                const f3 p_ray = {s->tan_fovx * pix_to_proj((float)px, W), s->tan_fovy * pix_to_proj((float)py, H), 1.0f};
+                float T = s->final_T[pix_id];
+                const uint32_t last_contributor = s->n_contrib[pix_id];
+                uint32_t contributor = r1 - r0;
+                float accum_feature[TS_MAX_CHANNELS] = {0, 0, 0};
+                f3 accum_normal = {0, 0, 0};
+                float accum_depth = background_depth;
+                float dL_dfeature_pixel[TS_MAX_CHANNELS] = {0, 0, 0};
+                f3 dL_dnormal_pixel = {0, 0, 0};
+                float dL_ddepth_pixel = 0;
+                for (int i = 0; i < C; i++)
+                {
+                    accum_feature[i] = background[i];
+                    dL_dfeature_pixel[i] = dL_dout_feature[(size_t)i * H * W + pix_id];
+                }
+                if (rich)
+                {
+                    dL_dnormal_pixel.x = dL_dout_normal[pix_id];
+                    dL_dnormal_pixel.y = dL_dout_normal[(size_t)W * H + pix_id];
+                    dL_dnormal_pixel.z = dL_dout_normal[2 * (size_t)W * H + pix_id];
+                    dL_ddepth_pixel = dL_dout_depth[pix_id];
+                }
+                for (uint32_t kk = r1; kk > r0; kk--)
+                {
+                    contributor--;
+                    if (contributor >= last_contributor) continue;
+                    const uint32_t id = s->vals[kk - 1];
+                    const f3 v1 = s->v1_view[id], v2 = s->v2_view[id], v3 = s->v3_view[id], n = s->normal_view[id];
+                    const float p_ray_dot_n = f3_dot(p_ray, n);
+                    if (fabsf(p_ray_dot_n) < TS_EPS) continue;
+                    const float inv_p_ray_dot_n = 1.0f / p_ray_dot_n;
+                    const float depth = f3_dot(v1, n) * inv_p_ray_dot_n;
+                    const f3 p_view = f3_lscale(depth, p_ray);
+                    const f3 p_v1 = f3_sub(v1, p_view), p_v2 = f3_sub(v2, p_view), p_v3 = f3_sub(v3, p_view);
+                    const float inv_n_dot_n = 1.0f / f3_dot(n, n);
+                    const float a1 = f3_dot(f3_cross(p_v2, p_v3), n) * inv_n_dot_n;
+                    const float a2 = f3_dot(f3_cross(p_v3, p_v1), n) * inv_n_dot_n;
+                    const float a3 = 1.0f - a1 - a2;
+                    const float ecc = 1.0f - 3.0f * fminf(fminf(a1, a2), a3);
+                    if (ecc < 0.0f || ecc > 10.0f) continue;
+                    const float power = -0.5f * powf(ecc, 2.0f * gamma);
+                    const float op = opacity[id];
+                    const float G = expf(power);
+                    const float alpha = fminf(0.99f, op * G);
+                    if (G < 1.0f / 255.0f) continue; /* sic: G, backward.cu:351 */
+
+                    T /= (1.0f - alpha);
+                    const float contrib = alpha * T;
+                    float dL_dcontrib = 0.0f;
+                    f3 dL_dnormal = {0, 0, 0};
+                    float dL_ddepth = 0.0f;
+                    for (int ch = 0; ch < C; ch++)
+                    {
+                        atomic_add_d(&g_feature[(size_t)id * C + ch], (double)(dL_dfeature_pixel[ch] * contrib));
+                        const float feat = feature[id * C + ch];
+                        dL_dcontrib += dL_dfeature_pixel[ch] * (feat - accum_feature[ch]);
+                        accum_feature[ch] = alpha * feat + (1.0f - alpha) * accum_feature[ch];
+                    }
+                    if (rich)
+                    {
+                        dL_dnormal = f3_add(dL_dnormal, f3_scale(dL_dnormal_pixel, contrib));
+                        dL_dcontrib += f3_dot(dL_dnormal_pixel, f3_sub(n, accum_normal));
+                        accum_normal = f3_add(f3_lscale(alpha, n), f3_lscale(1.0f - alpha, accum_normal));
+                        dL_ddepth += dL_ddepth_pixel * contrib;
+                        dL_dcontrib += dL_ddepth_pixel * (depth - accum_depth);
+                        accum_depth = alpha * depth + (1.0f - alpha) * accum_depth;
+                    }
+                    const float dL_dalpha = dL_dcontrib * T;
+                    const float dL_dpower = (op * G < 0.99f) ? (dL_dalpha * alpha) : 0.0f;
+                    const float dL_decc = dL_dpower * 2 * gamma * power / (ecc + TS_EPS);
+                    f3 decc_da = {0, 0, 0};
+                    if (a1 <= a2 && a1 <= a3) decc_da.x = -3.0f;
+                    else if (a2 <= a1 && a2 <= a3) decc_da.y = -3.0f;
+                    else decc_da.z = -3.0f;
+                    const f3 dL_da = f3_lscale(dL_decc, decc_da);
+
+                    const f3 zero = {0, 0, 0};
+                    const f3 da1_dv1 = zero;
+                    const f3 da1_dv2 = f3_scale(f3_cross(p_v3, n), inv_n_dot_n);
+                    const f3 da1_dv3 = f3_scale(f3_cross(n, p_v2), inv_n_dot_n);
+                    const f3 da1_dn = f3_scale(f3_sub(f3_cross(p_v2, p_v3), f3_lscale(2.0f * a1, n)), inv_n_dot_n);
+                    const float da1_dd = f3_dot(n, f3_cross(f3_sub(v3, v2), p_ray)) * inv_n_dot_n;
+                    const f3 da2_dv1 = f3_scale(f3_cross(n, p_v3), inv_n_dot_n);
+                    const f3 da2_dv2 = zero;
+                    const f3 da2_dv3 = f3_scale(f3_cross(p_v1, n), inv_n_dot_n);
+                    const f3 da2_dn = f3_scale(f3_sub(f3_cross(p_v3, p_v1), f3_lscale(2.0f * a2, n)), inv_n_dot_n);
+                    const float da2_dd = f3_dot(n, f3_cross(f3_sub(v1, v3), p_ray)) * inv_n_dot_n;
+                    const f3 neg1 = {-da1_dv1.x, -da1_dv1.y, -da1_dv1.z}, neg2 = {-da1_dv2.x, -da1_dv2.y, -da1_dv2.z};
+                    const f3 neg3 = {-da1_dv3.x, -da1_dv3.y, -da1_dv3.z}, negn = {-da1_dn.x, -da1_dn.y, -da1_dn.z};
+                    const f3 da3_dv1 = f3_sub(neg1, da2_dv1), da3_dv2 = f3_sub(neg2, da2_dv2), da3_dv3 = f3_sub(neg3, da2_dv3);
+                    const f3 da3_dn = f3_sub(negn, da2_dn);
+                    const float da3_dd = -da1_dd - da2_dd;
+
+                    dL_ddepth += dL_da.x * da1_dd + dL_da.y * da2_dd + dL_da.z * da3_dd;
+                    const f3 ddepth_dv1 = f3_scale(n, inv_p_ray_dot_n);
+                    const f3 ddepth_dn = f3_scale(f3_sub(v1, f3_lscale(depth, p_ray)), inv_p_ray_dot_n);
+
+                    const f3 gv1 = f3_add(f3_add(f3_add(f3_lscale(dL_da.x, da1_dv1), f3_lscale(dL_da.y, da2_dv1)), f3_lscale(dL_da.z, da3_dv1)),
+                                          f3_lscale(dL_ddepth, ddepth_dv1));
+                    const f3 gv2 = f3_add(f3_add(f3_lscale(dL_da.x, da1_dv2), f3_lscale(dL_da.y, da2_dv2)), f3_lscale(dL_da.z, da3_dv2));
+                    const f3 gv3 = f3_add(f3_add(f3_lscale(dL_da.x, da1_dv3), f3_lscale(dL_da.y, da2_dv3)), f3_lscale(dL_da.z, da3_dv3));
+                    dL_dnormal = f3_add(dL_dnormal, f3_add(f3_add(f3_add(f3_lscale(dL_da.x, da1_dn), f3_lscale(dL_da.y, da2_dn)),
+                                                                  f3_lscale(dL_da.z, da3_dn)), f3_lscale(dL_ddepth, ddepth_dn)));
+                    double *gv = g_v + 9 * (size_t)id;
+                    atomic_add_d(gv + 0, gv1.x); atomic_add_d(gv + 1, gv1.y); atomic_add_d(gv + 2, gv1.z);
+                    atomic_add_d(gv + 3, gv2.x); atomic_add_d(gv + 4, gv2.y); atomic_add_d(gv + 5, gv2.z);
+                    atomic_add_d(gv + 6, gv3.x); atomic_add_d(gv + 7, gv3.y); atomic_add_d(gv + 8, gv3.z);
+                    atomic_add_d(g_normal + 3 * (size_t)id + 0, dL_dnormal.x);
+                    atomic_add_d(g_normal + 3 * (size_t)id + 1, dL_dnormal.y);
+                    atomic_add_d(g_normal + 3 * (size_t)id + 2, dL_dnormal.z);
+                    atomic_add_d(&g_opacity[id], (double)(dL_dalpha * G));
+                }
+            }
+    }
+}
+
+/* R3D/src/backward.cu:144-214 */
+static void preprocess_backward_3d(const ts2d_oracle_state *s, int D, int M, int use_shs, const float *view, const float *campos,
+                                   const float *vertex, const float *shs, const int *radii, const float *g_v,
+                                   const float *g_normal, const float *dL_dfeature, float *dL_dvertex, float *dL_dcenter2D,
+                                   float *dL_dshs)
+{
+    const int P = s->P;
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < P; idx++)
+    {
+        if (radii[idx] <= 0) continue;
+        const f3 v1_view = s->v1_view[idx], v2_view = s->v2_view[idx], v3_view = s->v3_view[idx];
+        f3 g1 = {g_v[9 * (size_t)idx + 0], g_v[9 * (size_t)idx + 1], g_v[9 * (size_t)idx + 2]};
+        f3 g2 = {g_v[9 * (size_t)idx + 3], g_v[9 * (size_t)idx + 4], g_v[9 * (size_t)idx + 5]};
+        f3 g3 = {g_v[9 * (size_t)idx + 6], g_v[9 * (size_t)idx + 7], g_v[9 * (size_t)idx + 8]};
+        const f3 gn = {g_normal[3 * (size_t)idx], g_normal[3 * (size_t)idx + 1], g_normal[3 * (size_t)idx + 2]};
+        g1 = f3_add(g1, f3_cross(f3_sub(v2_view, v3_view), gn));
+        g2 = f3_add(g2, f3_cross(f3_sub(v3_view, v1_view), gn));
+        g3 = f3_add(g3, f3_cross(f3_sub(v1_view, v2_view), gn));
+        f3 dL_dv1 = xform_vec_4x3_T(g1, view), dL_dv2 = xform_vec_4x3_T(g2, view), dL_dv3 = xform_vec_4x3_T(g3, view);
+        if (use_shs)
+        {
+            const f3 v1 = {vertex[9 * (size_t)idx], vertex[9 * (size_t)idx + 1], vertex[9 * (size_t)idx + 2]};
+            const f3 v2 = {vertex[9 * (size_t)idx + 3], vertex[9 * (size_t)idx + 4], vertex[9 * (size_t)idx + 5]};
+            const f3 v3 = {vertex[9 * (size_t)idx + 6], vertex[9 * (size_t)idx + 7], vertex[9 * (size_t)idx + 8]};
+            const f3 center = f3_div(f3_add(f3_add(v1, v2), v3), 3.0f);
+            const f3 cp = {campos[0], campos[1], campos[2]};
+            f3 dsh;
+            rgb_from_sh_backward(idx, D, M, center, cp, shs, s->clamped, (const f3 *)dL_dfeature, (f3 *)dL_dshs, &dsh);
+            const f3 third = f3_div(dsh, 3.0f);
+            dL_dv1 = f3_add(dL_dv1, third); dL_dv2 = f3_add(dL_dv2, third); dL_dv3 = f3_add(dL_dv3, third);
+        }
+        float *o = dL_dvertex + 9 * (size_t)idx;
+        o[0] = dL_dv1.x; o[1] = dL_dv1.y; o[2] = dL_dv1.z;
+        o[3] = dL_dv2.x; o[4] = dL_dv2.y; o[5] = dL_dv2.z;
+        o[6] = dL_dv3.x; o[7] = dL_dv3.y; o[8] = dL_dv3.z;
+        const f3 dcv = xform_vec_4x3(f3_add(f3_add(dL_dv1, dL_dv2), dL_dv3), view);
+        dL_dcenter2D[2 * (size_t)idx] = dcv.x;
+        dL_dcenter2D[2 * (size_t)idx + 1] = dcv.y;
+    }
+}
+
 /*
  * Forward entry.  Mirrors rasterizeTrianglesForward (R2D/src/extension_interface.cu:19-152) +
  * Rasterizer::forward (R2D/src/rasterizer.cu:101-267).  Outputs are caller-allocated and are
@@ -547,12 +861,13 @@ int ts2d_oracle_forward(int W, int H, float tan_fovx, float tan_fovy, const floa
                         float background_depth, const float *background, const float *vertex,
                         const float *shs, const float *feature, const float *opacity, int back_culling,
                         int rich_info, float *out_feature, int *radii, float *out_depth, float *out_normal,
-                        float *contrib_sum, float *contrib_max, ts2d_oracle_state **state_out)
+                        float *contrib_sum, float *contrib_max, int variant, ts2d_oracle_state **state_out)
 {
     if (C > TS_MAX_CHANNELS || C < 0) return 1;
     if (gamma < 0.0f) return 2;
     ts2d_oracle_state *s = (ts2d_oracle_state *)zalloc(sizeof(*s));
     s->W = W; s->H = H; s->P = P; s->C = C; s->rich_info = rich_info;
+    s->variant = (variant == 3) ? 3 : 2; s->tan_fovx = tan_fovx; s->tan_fovy = tan_fovy;
     s->grid_x = (W + TS_BLOCK_X - 1) / TS_BLOCK_X;
     s->grid_y = (H + TS_BLOCK_Y - 1) / TS_BLOCK_Y;
     const size_t npix = (size_t)W * H, nt = (size_t)s->grid_x * s->grid_y;
@@ -575,15 +890,20 @@ int ts2d_oracle_forward(int W, int H, float tan_fovx, float tan_fovy, const floa
     s->ranges = zalloc(sizeof(uint32_t) * 2 * nt);
     s->n_contrib = zalloc(sizeof(uint32_t) * npix);
     s->final_T = zalloc(sizeof(float) * npix);
+    if (s->variant == 3) { s->v1_view = zalloc(sizeof(f3) * P); s->v2_view = zalloc(sizeof(f3) * P); s->v3_view = zalloc(sizeof(f3) * P); }
     *state_out = s;
     if (P == 0) return 0; /* extension_interface.cu:130 */
 
-    preprocess_forward(s, D, M, use_shs, back_culling, tan_fovx, tan_fovy, view, proj, campos, vertex, shs, radii);
+    if (s->variant == 3) preprocess_forward_3d(s, D, M, use_shs, back_culling, view, proj, campos, vertex, shs, radii);
+    else preprocess_forward(s, D, M, use_shs, back_culling, tan_fovx, tan_fovy, view, proj, campos, vertex, shs, radii);
     bin_and_sort(s);
 
     const float *feat = use_shs ? s->rgb : feature; /* rasterizer.cu:244 */
     double *csum = rich_info ? (double *)zalloc(sizeof(double) * P) : NULL;
-    render_forward(s, gamma, feat, opacity, background_depth, background, out_feature, out_depth, out_normal, csum, contrib_max);
+    if (s->variant == 3)
+        render_forward_3d(s, gamma, feat, opacity, background_depth, background, out_feature, out_depth, out_normal, csum, contrib_max);
+    else
+        render_forward(s, gamma, feat, opacity, background_depth, background, out_feature, out_depth, out_normal, csum, contrib_max);
     if (rich_info)
     {
         for (int i = 0; i < P; i++) contrib_sum[i] = (float)csum[i];
@@ -955,6 +1275,23 @@ int ts2d_oracle_backward(const ts2d_oracle_state *s, float tan_fovx, float tan_f
     memset(dL_dfeature, 0, sizeof(float) * (size_t)C * P);
     memset(dL_dopacity, 0, sizeof(float) * (size_t)P);
     if (P == 0) return 0;
+    if (s->variant == 3)
+    {
+        double *gv3 = zalloc(sizeof(double) * 9 * P), *gn3 = zalloc(sizeof(double) * 3 * P);
+        double *gf3 = zalloc(sizeof(double) * (size_t)C * P), *go3 = zalloc(sizeof(double) * P);
+        const float *feat3 = use_shs ? s->rgb : feature;
+        render_backward_3d(s, gamma, feat3, opacity, background_depth, background, dL_dout_feature, dL_dout_depth,
+                           dL_dout_normal, gv3, gn3, gf3, go3);
+        float *gvf3 = zalloc(sizeof(float) * 9 * P), *gnf3 = zalloc(sizeof(float) * 3 * P);
+        for (size_t i = 0; i < 9 * (size_t)P; i++) gvf3[i] = (float)gv3[i];
+        for (size_t i = 0; i < 3 * (size_t)P; i++) gnf3[i] = (float)gn3[i];
+        for (size_t i = 0; i < (size_t)C * P; i++) dL_dfeature[i] = (float)gf3[i];
+        for (size_t i = 0; i < (size_t)P; i++) dL_dopacity[i] = (float)go3[i];
+        preprocess_backward_3d(s, D, M, use_shs, view, campos, vertex, shs, radii, gvf3, gnf3, dL_dfeature, dL_dvertex,
+                               dL_dcenter2D, dL_dshs);
+        free(gv3); free(gn3); free(gf3); free(go3); free(gvf3); free(gnf3);
+        return 0;
+    }
 
     double *gv = zalloc(sizeof(double) * 6 * P), *gn = zalloc(sizeof(double) * 3 * P), *gd = zalloc(sizeof(double) * 3 * P);
     double *gf = zalloc(sizeof(double) * (size_t)C * P), *go = zalloc(sizeof(double) * P);
@@ -1005,6 +1342,7 @@ const void *ts2d_oracle_field(const ts2d_oracle_state *s, int field)
     case 11: return s->rect_min; case 12: return s->rect_max; case 13: return s->keys_unsorted;
     case 14: return s->keys; case 15: return s->vals_unsorted; case 16: return s->vals;
     case 17: return s->ranges; case 18: return s->n_contrib; case 19: return s->final_T;
+    case 20: return s->v1_view; case 21: return s->v2_view; case 22: return s->v3_view;
     default: return NULL;
     }
 }

@@ -30,6 +30,7 @@ _FIELDS = {
     "keys_unsorted": (13, np.uint64, "N"), "keys": (14, np.uint64, "N"),
     "vals_unsorted": (15, np.uint32, "N"), "vals": (16, np.uint32, "N"),
     "ranges": (17, np.uint32, "T2"), "n_contrib": (18, np.uint32, "HW"), "final_T": (19, np.float32, "HW"),
+    "v1_view": (20, np.float32, "P3"), "v2_view": (21, np.float32, "P3"), "v3_view": (22, np.float32, "P3"),
 }
 
 
@@ -50,7 +51,7 @@ def lib():
         L.ts2d_oracle_forward.restype = C.c_int
         L.ts2d_oracle_forward.argtypes = [C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, C.c_int, C.c_int,
                                           C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, fp, fp, fp, fp, fp,
-                                          C.c_int, C.c_int, fp, ip, fp, fp, fp, fp, C.POINTER(vp)]
+                                          C.c_int, C.c_int, fp, ip, fp, fp, fp, fp, C.c_int, C.POINTER(vp)]
         L.ts2d_oracle_backward.restype = C.c_int
         L.ts2d_oracle_backward.argtypes = [vp, C.c_float, C.c_float, fp, fp, fp, C.c_int, C.c_int, C.c_int,
                                            C.c_float, C.c_float, fp, fp, fp, fp, fp, ip, fp, fp, fp, fp, fp, fp,
@@ -132,7 +133,7 @@ class OracleState:
 
 def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree,
                         gamma, scale_modifier, background_depth, background, vertex, shs, feature, opacity,
-                        back_culling, rich_info, debug=False):
+                        back_culling, rich_info, debug=False, variant=2):
     """Oracle counterpart of `_C.rasterize_triangles` (R2D/src/extension_interface.cu:19-152).
 
     Returns (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max, state)."""
@@ -175,7 +176,7 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
                                    _fp(background), _fp(vertex), _fp(shs), _fp(feature), _fp(opacity),
                                    int(bool(back_culling)), int(bool(rich_info)), _fp(out_feature),
                                    radii.ctypes.data_as(C.POINTER(C.c_int)), _fp(depth), _fp(normal), _fp(csum),
-                                   _fp(cmax), C.byref(h))
+                                   _fp(cmax), int(variant), C.byref(h))
     if rc != 0:
         raise RuntimeError(f"ts2d_oracle_forward failed with code {rc}")
     st = OracleState(h, P, W, H, bool(rich_info))

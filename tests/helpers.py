@@ -16,13 +16,13 @@ def rel_l2(a, b):
     return d / n if n > 0 else d
 
 
-def oracle_forward(s, rich_info=True, back_culling=False, use_feature=False):
+def oracle_forward(s, rich_info=True, back_culling=False, use_feature=False, variant=2):
     shs = None if use_feature else s["shs"]
     feature = s["feature"] if use_feature else None
     n, img, radii, depth, normal, csum, cmax, st = O.rasterize_triangles(
         s["image_width"], s["image_height"], s["tanfovx"], s["tanfovy"], s["viewmatrix"], s["projmatrix"], s["campos"],
         s["sh_degree"], s["gamma"], s["scale_modifier"], s["background_depth"], s["background"], s["vertex"], shs,
-        feature, s["opacity"], back_culling, rich_info)
+        feature, s["opacity"], back_culling, rich_info, variant=variant)
     return dict(num_rendered=n, out_feature=img, radii=radii, depth=depth, normal=normal, contrib_sum=csum,
                 contrib_max=cmax, state=st)
 
@@ -49,10 +49,14 @@ def hip_settings(s, rich_info=True, back_culling=False, debug=False, device="cud
         background=t(s["background"]), back_culling=back_culling, rich_info=rich_info, debug=debug)
 
 
-def hip_forward_backward(s, rich_info=True, back_culling=False, use_feature=False, backward=True, device="cuda", debug=False):
+def hip_forward_backward(s, rich_info=True, back_culling=False, use_feature=False, backward=True, device="cuda", debug=False,
+                         variant=2):
     """Runs the HIP path through the drop-in autograd module.  Returns numpy outputs + grads + raw state."""
     import torch
-    from diff_triangle_rasterization_2D import TriangleRasterizer, _C
+    if variant == 3:
+        from diff_triangle_rasterization_3D import TriangleRasterizer
+    else:
+        from diff_triangle_rasterization_2D import TriangleRasterizer
 
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     rs = hip_settings(s, rich_info, back_culling, debug, device)

@@ -1,0 +1,141 @@
+"""GPU parity tests of the 3D variant (rasterizer_type "3D"): the HIP path selected by
+TS2D_FLAG_3D (through diff_triangle_rasterization_3D -> ctypes -> C ABI) against the CPU oracle's variant=3.
+
+Same bars as test_parity_gpu.py.  The blend kernels evaluate the barycentrics as N_k(q)/Den(q) with N_k, Den affine
+in the pixel offset (render3d.hip) where the oracle follows the reference's per-pixel ray/plane expressions, so
+floating-point outputs are compared with tolerances; all integer state must match bit for bit."""
+import numpy as np
+import pytest
+
+import helpers
+import ref3d_f64
+import synthetic
+
+pytestmark = pytest.mark.gpu
+
+IMG_TOL = 1e-4
+GRAD_TOL = 1e-3
+OUTLIER_FRAC = 2e-4
+
+
+def _check_state3d(s, hf, of, use_feature=False):
+    st = of["state"]
+    assert hf["num_rendered"] == of["num_rendered"]
+    assert np.array_equal(hf["radii"], of["radii"])
+    for name in ("tiles_touched", "vals", "ranges"):
+        a = helpers.hip_state(hf, s, name).astype(np.int64).reshape(-1)
+        b = st.field(name).astype(np.int64).reshape(-1)
+        assert np.array_equal(a, b), name
+    assert np.array_equal(helpers.hip_state(hf, s, "keys").reshape(-1), st.field("keys").view(np.int64).reshape(-1))
+    vis = of["radii"] > 0
+    rec = helpers.hip_state(hf, s, "records")
+    ora = np.concatenate([st.field("v1_view"), st.field("v2_view"), st.field("v3_view"), st.field("normal_view"),
+                          s["opacity"].reshape(-1, 1), s["feature"] if use_feature else st.field("rgb")], axis=1)
+    assert np.array_equal(rec[vis], ora[vis])  # contraction-free preprocess: bit-exact
+    assert np.array_equal(helpers.hip_state(hf, s, "depth")[vis], st.field("depth")[vis])
+    nc_h = helpers.hip_state(hf, s, "n_contrib").astype(np.int64)
+    nc_o = st.field("n_contrib").astype(np.int64)
+    assert (nc_h != nc_o).mean() <= OUTLIER_FRAC
+
+
+GRAZING_COS = 0.03  # triangles seen within ~1.7 degrees of edge-on
+TIE_GAP = 2e-5  # fp32 rounding level of the barycentrics (|a| ~ 1, a few ulp of the ~1e1 intermediate terms)
+
+
+def _grazing_cos(st, i):
+    """|cos| of the angle between the view direction to the triangle and its normal (0 = seen edge-on)."""
+    c = sum(st.field(f"v{k}_view")[i].astype(np.float64) for k in (1, 2, 3)) / 3.0
+    n = st.field("normal_view")[i].astype(np.float64)
+    return abs(c @ n) / (np.linalg.norm(c) * np.linalg.norm(n))
+
+
+def _check_geometry_grads(s, of, hip, ora, name):
+    """rel-L2 < GRAD_TOL over all triangles, except the few whose fp32 gradient is ill-conditioned in the REFERENCE's
+    own arithmetic, each of which must be explained by one of
+      * an argmin near-tie: min(a1, a2, a3) is a tie at some pixel to within rounding, so which vertices receive that
+        pixel's gradient (R3D backward.cu:388-401) is decided by rounding;
+      * a grazing view: depth = v1.n / p_ray.n (R3D backward.cu:322-325) loses a factor 1/cos of precision, and the
+        intersection point (magnitude ~ depth) a further depth/edge.
+      * a sharp window (gamma >= 10, end of the training schedule): alpha = o exp(-ecc^(2 gamma) / 2) turns
+        d(alpha)/d(ecc) into ~2 gamma ecc^(2 gamma - 1), so the ~1e-5 fp32 rounding of the 3D barycentrics moves the
+        handful of edge pixels that carry the whole geometric gradient by per cents (the 2D variant's screen-space
+        barycentrics are ~100x more exact, which is why test_parity_gpu.py needs no such clause);
+    and must stay within 5 % (20 % for a sharp window) of its own gradient norm unless it is a tie."""
+    sharp = float(s["gamma"]) >= 10.0
+    P = hip.shape[0]
+    st = of["state"]
+    err = np.linalg.norm((hip.astype(np.float64) - ora).reshape(P, -1), axis=1)
+    own = np.linalg.norm(ora.astype(np.float64).reshape(P, -1), axis=1)
+    ref = np.linalg.norm(own)
+    suspects = np.nonzero(err > 0.1 * GRAD_TOL * ref)[0]
+    assert len(suspects) <= max(3, P // 500), (name, len(suspects))
+    for i in suspects:
+        tie = ref3d_f64.min_tie_gap(s, st, int(i)) < TIE_GAP
+        grazing = _grazing_cos(st, int(i)) < GRAZING_COS and err[i] < 0.05 * own[i]
+        assert tie or grazing or (sharp and err[i] < 0.2 * own[i]), (name, int(i), err[i] / ref, err[i] / own[i])
+    keep = np.ones(P, bool)
+    keep[suspects] = False
+    assert np.sqrt((err[keep] ** 2).sum()) / ref < GRAD_TOL, name
+
+
+def _check_outputs(s, hf, of, ob, rich, use_feature=False):
+    assert helpers.rel_l2(hf["out_feature"], of["out_feature"]) < IMG_TOL
+    if rich:
+        for k in ("depth", "normal", "contrib_sum", "contrib_max"):
+            assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k
+    for k in ["dL_dopacity", "dL_dfeature" if use_feature else "dL_dshs"]:
+        assert helpers.rel_l2(hf[k], ob[k]) < GRAD_TOL, k
+    for k in ["dL_dvertex", "dL_dcenter2D"]:
+        _check_geometry_grads(s, of, hf[k], ob[k], k)
+
+
+CASES = [
+    (300, 64, 64, 3, True, 1.0, False, {}),
+    (2000, 128, 96, 3, True, 1.0, False, {}),
+    (10000, 256, 256, 0, True, 1.0, False, {}),
+    (10000, 256, 256, 3, False, 1.0, False, {}),
+    (5000, 200, 120, 2, True, 2.5, False, {}),
+    (5000, 200, 120, 1, True, 50.0, True, {}),
+    (1000, 320, 240, 3, True, 1.0, False, {"mode": "maincu"}),
+    (20000, 96, 96, 1, True, 1.0, False, {"edge_px": 2.0}),
+]
+
+
+@pytest.mark.parametrize("P,W,H,D,rich,gamma,back_culling,kw", CASES)
+def test_hip3d_matches_oracle(P, W, H, D, rich, gamma, back_culling, kw):
+    s = synthetic.scene(P, W, H, D, seed=4321 + P, **kw)
+    s["gamma"] = gamma
+    of = helpers.oracle_forward(s, rich, back_culling, variant=3)
+    ob = helpers.oracle_backward(s, of, rich)
+    hf = helpers.hip_forward_backward(s, rich, back_culling, variant=3)
+    _check_state3d(s, hf, of)
+    _check_outputs(s, hf, of, ob, rich)
+
+
+def test_feature_mode_3d():
+    s = synthetic.scene(3000, 160, 100, 0, seed=5)
+    s["feature"] = np.random.default_rng(5).random((3000, 3), dtype=np.float32)
+    s["background"] = np.array([0.3, 0.6, 0.1], np.float32)
+    s["background_depth"] = 7.5
+    of = helpers.oracle_forward(s, True, False, use_feature=True, variant=3)
+    ob = helpers.oracle_backward(s, of, True, use_feature=True)
+    hf = helpers.hip_forward_backward(s, True, False, use_feature=True, variant=3)
+    _check_state3d(s, hf, of, use_feature=True)
+    _check_outputs(s, hf, of, ob, True, use_feature=True)
+
+
+def test_3d_accepts_non_contiguous_inputs():
+    """R3D/src/extension_interface.cu:82-92 takes .contiguous() of its inputs where the 2D module raises."""
+    import torch
+    from diff_triangle_rasterization_3D import TriangleRasterizer
+
+    s = synthetic.scene(500, 64, 64, 0, seed=9)
+    s["feature"] = np.random.default_rng(9).random((500, 3), dtype=np.float32)
+    rs = helpers.hip_settings(s, rich_info=False)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    vertex = t(s["vertex"]).transpose(1, 2).contiguous().transpose(1, 2)  # same values, non-contiguous strides
+    assert not vertex.is_contiguous()
+    c2d = torch.zeros((500, 2), device="cuda")
+    img, radii = TriangleRasterizer(rs)(vertex, c2d, t(s["opacity"]), feature=t(s["feature"]))
+    img2, radii2 = TriangleRasterizer(rs)(vertex.contiguous(), c2d, t(s["opacity"]), feature=t(s["feature"]))
+    assert torch.equal(img, img2) and torch.equal(radii, radii2)

@@ -193,7 +193,8 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     const PreprocessArgs a = make_pre(cam, geom, flags);
     {
         ProfScope ps("preprocess_fwd", s);
-        ts_launch_preprocess_fwd(a, radii, g, s);
+        if (flags & TS2D_FLAG_3D) ts_launch_preprocess3d_fwd(a, radii, g, s);
+        else ts_launch_preprocess_fwd(a, radii, g, s);
     }
     TS_CHECK(flags, s, "preprocess_fwd");
     {
@@ -265,7 +266,10 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     }
     {
         ProfScope ps("render_fwd", s);
-        if (r.refstruct)
+        if (flags & TS2D_FLAG_3D)
+            ts_launch_render3d_fwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
+                                   out->contrib_sum, out->contrib_max, s);
+        else if (r.refstruct)
             ts_launch_refstruct_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
         else
             ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
@@ -310,7 +314,10 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     if (N > 0)
     {
         ProfScope ps("render_bwd", s);
-        if (r.refstruct)
+        if (flags & TS2D_FLAG_3D)
+            ts_launch_render3d_bwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
+                                   loss->dL_dout_normal, grad_rec, s);
+        else if (r.refstruct)
             ts_launch_refstruct_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
         else
             ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
@@ -319,8 +326,12 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     {
         ProfScope ps("preprocess_bwd", s);
         const PreprocessArgs a = make_pre(cam, geom, flags);
-        ts_launch_preprocess_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, out->dL_dshs, out->dL_dfeature,
-                                 out->dL_dopacity, s);
+        if (flags & TS2D_FLAG_3D)
+            ts_launch_preprocess3d_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, out->dL_dshs,
+                                       out->dL_dfeature, out->dL_dopacity, s);
+        else
+            ts_launch_preprocess_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, out->dL_dshs, out->dL_dfeature,
+                                     out->dL_dopacity, s);
     }
     TS_CHECK(flags, s, "preprocess_bwd");
     return TS2D_OK;
@@ -411,6 +422,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
     case 15: src = b.tile_unsorted; bytes = (size_t)N * 4; break;
     case 16: src = b.vals_unsorted; bytes = (size_t)N * 4; break;
     case 17: src = g.perm; bytes = (size_t)P * 4; break;
+    case 18: src = g.rec; bytes = (size_t)P * TS_REC_FLOATS * 4; break; // raw 64-byte render records (2D or 3D layout)
     default: return fail(TS2D_ERR_INVALID, "unknown field %d", field);
     }
     if (dst_bytes < bytes) return fail(TS2D_ERR_CAPACITY, "dst too small");

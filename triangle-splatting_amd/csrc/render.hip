@@ -26,183 +26,10 @@
 // pixel of the quadrant can pass the reference's own tests (0 <= ecc <= 10 and alpha >= 1/255), and
 // n_contrib / termination are tracked by list position exactly as the reference counts them.
 #include "ts2d_common.h"
+#include "ts2d_wave.h"
 
 namespace
 {
-__device__ __forceinline__ float bcast(float v, int j)
-{
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), j));
-}
-__device__ __forceinline__ uint32_t bcast(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
-
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float dpp(float v)
-{
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-constexpr int DPP_XOR1 = 0xB1;        // quad_perm:[1,0,3,2]
-constexpr int DPP_XOR2 = 0x4E;        // quad_perm:[2,3,0,1]
-constexpr int DPP_ROR8 = 0x128;       // row_ror:8  (lane ^ 8 inside a row of 16)
-constexpr int DPP_HALF_MIRROR = 0x141; // lane -> 7 - lane inside each group of 8
-constexpr int DPP_MIRROR = 0x140;     // lane -> 15 - lane inside a row of 16
-constexpr int DPP_BCAST15 = 0x142;    // lane 15 of row r -> all lanes of row r+1
-constexpr int DPP_BCAST31 = 0x143;    // lane 31 -> all lanes of rows 2,3
-
-// Full 64-lane reductions; result valid in lane 63 (read back with bcast(v, 63)).
-__device__ __forceinline__ float wave_sum63(float v)
-{
-    v += dpp<DPP_XOR1>(v);
-    v += dpp<DPP_XOR2>(v);
-    v += dpp<DPP_HALF_MIRROR>(v);
-    v += dpp<DPP_MIRROR>(v);
-    v += dpp<DPP_BCAST15, 0xA>(v);
-    v += dpp<DPP_BCAST31, 0xC>(v);
-    return v;
-}
-__device__ __forceinline__ float wave_max63_nonneg(float v) // inputs >= 0 (masked-off rows contribute 0)
-{
-    v = fmaxf(v, dpp<DPP_XOR1>(v));
-    v = fmaxf(v, dpp<DPP_XOR2>(v));
-    v = fmaxf(v, dpp<DPP_HALF_MIRROR>(v));
-    v = fmaxf(v, dpp<DPP_MIRROR>(v));
-    v = fmaxf(v, dpp<DPP_BCAST15, 0xA>(v));
-    v = fmaxf(v, dpp<DPP_BCAST31, 0xC>(v));
-    return v;
-}
-
-__device__ __forceinline__ void swap32(float &a, float &b) // a <- [a.lo | b.lo], b <- [a.hi | b.hi]
-{
-    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void swap16(float &a, float &b) // odd rows of a <-> even rows of b
-{
-    auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
-    a = __uint_as_float(r[0]);
-    b = __uint_as_float(r[1]);
-}
-
-// Transpose-reduce: 16 values per lane x 64 lanes -> each lane returns the complete 64-lane reduction of ONE of
-// the 16 values; the four lanes of a quad hold the same value and the 16 quads hold the 16 different values.
-// Which value a lane ends up with is discovered once per wave by reducing indicator inputs (slot_of_lane()).
-struct OpAdd { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
-struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
-
-template <typename Op>
-__device__ __forceinline__ float reduce16(float (&v)[16], int lane, Op op)
-{
-#pragma unroll
-    for (int i = 0; i < 8; i++) // 64 -> 32 lanes per value, two values per register
-    {
-        swap32(v[2 * i], v[2 * i + 1]);
-        v[i] = op(v[2 * i], v[2 * i + 1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; i++) // 32 -> 16 lanes per value, one value per row
-    {
-        swap16(v[2 * i], v[2 * i + 1]);
-        v[i] = op(v[2 * i], v[2 * i + 1]);
-    }
-    const bool b3 = lane & 8, b2 = lane & 4;
-#pragma unroll
-    for (int i = 0; i < 2; i++) // 16 -> 8 lanes per value
-    {
-        const float own = b3 ? v[2 * i + 1] : v[2 * i];
-        const float oth = b3 ? v[2 * i] : v[2 * i + 1];
-        v[i] = op(own, dpp<DPP_ROR8>(oth));
-    }
-    {
-        const float own = b2 ? v[1] : v[0]; // 8 -> 4 lanes per value
-        const float oth = b2 ? v[0] : v[1];
-        v[0] = op(own, dpp<DPP_HALF_MIRROR>(oth));
-    }
-    float r = v[0];
-    r = op(r, dpp<DPP_XOR1>(r));
-    r = op(r, dpp<DPP_XOR2>(r));
-    return r;
-}
-__device__ __forceinline__ float reduce16(float (&v)[16], int lane) { return reduce16(v, lane, OpAdd()); }
-
-// Same idea for 8 values: each lane returns the complete reduction of ONE of the 8 values, the 8 lanes of a group
-// (lane >> 3) share it.  Used by the forward's contribution statistics (8 parked entries per flush).
-template <typename Op>
-__device__ __forceinline__ float reduce8(float (&v)[8], int lane, Op op)
-{
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-    {
-        swap32(v[2 * i], v[2 * i + 1]);
-        v[i] = op(v[2 * i], v[2 * i + 1]);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-    {
-        swap16(v[2 * i], v[2 * i + 1]);
-        v[i] = op(v[2 * i], v[2 * i + 1]);
-    }
-    const bool b3 = lane & 8;
-    const float own = b3 ? v[1] : v[0];
-    const float oth = b3 ? v[0] : v[1];
-    float r = op(own, dpp<DPP_ROR8>(oth));
-    r = op(r, dpp<DPP_HALF_MIRROR>(r));
-    r = op(r, dpp<DPP_XOR1>(r));
-    r = op(r, dpp<DPP_XOR2>(r));
-    return r;
-}
-__device__ __forceinline__ int slot8_of_lane(int lane)
-{
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) v[i] = (lane == 0) ? (float)i : 0.0f;
-    return (int)reduce8(v, lane, OpAdd());
-}
-
-__device__ __forceinline__ int slot_of_lane(int lane)
-{
-    float v[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) v[i] = (lane == 0) ? (float)i : 0.0f;
-    return (int)reduce16(v, lane);
-}
-
-// x^y for x >= 0, y >= 0 via v_log_f32 / v_exp_f32 (x = 0 -> 0, y = 0 -> 1 like powf).
-__device__ __forceinline__ float pow_nonneg(float x, float y)
-{
-    const float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
-    return y == 0.0f ? 1.0f : r;
-}
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-
-// blockIdx -> tile so that each XCD (block b runs on XCD b % 8) owns one contiguous band of row-major tiles:
-// neighbouring tiles gather mostly the same triangle records, which then stay in that XCD's 4 MiB L2.
-__device__ __forceinline__ int tile_of_block(int b, int ntiles)
-{
-    const int q = ntiles >> 3, r = ntiles & 7, x = b & 7, i = b >> 3;
-    return x * q + min(x, r) + i;
-}
-
-// ---- reduce4: 4 values per lane x 64 lanes -> every lane of row r returns the complete sum of value map[r] ----
-__device__ __forceinline__ float reduce4(float x0, float x1, float x2, float x3)
-{
-    swap32(x0, x1);
-    x0 += x1;
-    swap32(x2, x3);
-    x2 += x3;
-    swap16(x0, x2);
-    float r = x0 + x2;
-    r += dpp<DPP_XOR1>(r);
-    r += dpp<DPP_XOR2>(r);
-    r += dpp<DPP_HALF_MIRROR>(r);
-    r += dpp<DPP_MIRROR>(r);
-    return r;
-}
-__device__ __forceinline__ int slot4_of_lane(int lane)
-{
-    const float i = (lane == 0) ? 1.0f : 0.0f;
-    return (int)reduce4(0.0f, i, 2.0f * i, 3.0f * i);
-}
-
 // Per-entry constants travel from the lane that owns the entry to all 64 pixel lanes through a wave-private LDS
 // table read with uniform addresses (ds_read_b128 broadcast): that costs no VALU issue slots, whereas one
 // v_readlane per constant costs ~4.3 cycles each (profiles/r01_valu_microbench.txt) in kernels that are VALU-bound.

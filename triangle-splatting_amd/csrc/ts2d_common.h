@@ -176,3 +176,17 @@ void ts_launch_refstruct_bwd(const RenderArgs &a, const GeometryStateView &g, co
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                               float *dL_dfeature, float *dL_dopacity, hipStream_t s);
+
+// ---- 3D variant (TS2D_FLAG_3D): same states and binning, its own record contents and blend maths -----------------
+// Render record: [0..8] v1_view v2_view v3_view   [9..11] normal_view (unnormalised)   [12] opacity   [13..15] r g b
+// Gradient record: [0..8] dL/dv{1,2,3}_view   [9..11] dL/dnormal_view   [12] dL/dopacity   [13..15] dL/drgb
+void ts_launch_preprocess3d_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s);
+void ts_launch_preprocess3d_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
+                                const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
+                                float *dL_dfeature, float *dL_dopacity, hipStream_t s);
+void ts_launch_render3d_fwd(const RenderArgs &a, float tan_fovx, float tan_fovy, const GeometryStateView &g,
+                            const BinningStateView &b, const ImageStateView &im, float *out_feature, float *out_depth,
+                            float *out_normal, float *contrib_sum, float *contrib_max, hipStream_t s);
+void ts_launch_render3d_bwd(const RenderArgs &a, float tan_fovx, float tan_fovy, const GeometryStateView &g,
+                            const BinningStateView &b, const ImageStateView &im, const float *dL_dout_feature,
+                            const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec, hipStream_t s);

@@ -34,7 +34,7 @@ if not os.path.exists(_LIB_PATH):
     )
 _lib = C.CDLL(_LIB_PATH)
 
-FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS = 1, 2, 4, 8
+FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS, FLAG_3D = 1, 2, 4, 8, 16
 MAX_CHANNELS = 3
 
 _fp = C.c_void_p
@@ -157,7 +157,8 @@ def _state(geometryBuffer, binningBuffer, imageBuffer) -> _State:
 
 def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma,
                         scale_modifier, background_depth, background, vertex, shs, feature, opacity, back_culling,
-                        rich_info, debug):
+                        rich_info, debug, *, variant=2):
+    """`variant=3` selects the 3D rasterizer (TS2D_FLAG_3D; used by the sibling package diff_triangle_rasterization_3D)."""
     P = vertex.size(0)
     H, W = int(image_height), int(image_width)
     use_shs = _use_shs(shs, feature)
@@ -177,7 +178,11 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
         raise RuntimeError("background must have the same number of channels as feature")
     if gamma < 0.0:
         raise RuntimeError("gamma must be larger than 0")
-    _contiguous_or_raise(viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity)
+    if variant == 3:  # R3D/src/extension_interface.cu:82-92 takes .contiguous() of every input instead of raising
+        viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity = (
+            t.contiguous() for t in (viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity))
+    else:
+        _contiguous_or_raise(viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity)
     _require_device(vertex)
     _f32_or_raise(viewmatrix, projmatrix, campos, background, vertex, shs if use_shs else None,
                   None if use_shs else feature, opacity)
@@ -206,7 +211,7 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
                     torch.empty((0,), **u8), torch.empty((0,), **u8))
 
         flags = ((FLAG_BACK_CULLING if back_culling else 0) | (FLAG_RICH_INFO if rich_info else 0) |
-                 (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0))
+                 (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) | (FLAG_3D if variant == 3 else 0))
         cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
         geometryBuffer = torch.empty((_lib.ts2d_geometry_state_bytes(P),), **u8)
@@ -229,12 +234,16 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
 def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                                  background_depth, background, vertex, shs, feature, opacity, num_rendered, radii,
                                  geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
-                                 dL_dout_normal, rich_info, debug):
+                                 dL_dout_normal, rich_info, debug, *, variant=2):
     P = vertex.size(0)
     H, W = dL_dout_feature.size(1), dL_dout_feature.size(2)  # extension_interface.cu:182-183
     use_shs = _use_shs(shs, feature)
     Cn = 3 if use_shs else feature.size(1)
     M = shs.size(1) if (shs.size(0) != 0 and shs.dim() >= 2) else 0
+    if variant == 3:  # R3D/src/extension_interface.cu:186-206: .contiguous() instead of the 2D module's error
+        (viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity, radii, dL_dout_feature, dL_dout_depth,
+         dL_dout_normal) = (t.contiguous() for t in (viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity,
+                                                     radii, dL_dout_feature, dL_dout_depth, dL_dout_normal))
     _contiguous_or_raise(viewmatrix, projmatrix, campos, background, vertex, shs, feature, opacity, radii, geometryBuffer,
                          binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth, dL_dout_normal)
     _require_device(vertex)
@@ -252,7 +261,8 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
         dL_dopacity = alloc((P, 1), **opts)
         if P == 0:
             return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
-        flags = ((FLAG_RICH_INFO if rich_info else 0) | (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0))
+        flags = ((FLAG_RICH_INFO if rich_info else 0) | (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) |
+                 (FLAG_3D if variant == 3 else 0))
         cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
         st = _state(geometryBuffer, binningBuffer, imageBuffer)
@@ -277,6 +287,7 @@ _FIELD_SPEC = {
     "ranges": (12, torch.int32, lambda P, N, T, HW: (T, 2)), "n_contrib": (13, torch.int32, lambda P, N, T, HW: HW),
     "final_T": (14, torch.float32, lambda P, N, T, HW: HW), "tile_unsorted": (15, torch.int32, lambda P, N, T, HW: (N,)),
     "vals_unsorted": (16, torch.int32, lambda P, N, T, HW: (N,)), "depth_perm": (17, torch.int32, lambda P, N, T, HW: (P,)),
+    "records": (18, torch.float32, lambda P, N, T, HW: (P, 16)),
 }
 
 

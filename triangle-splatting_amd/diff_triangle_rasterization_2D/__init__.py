@@ -78,6 +78,9 @@ class _RasterizeTriangles(torch.autograd.Function):
     """autograd inputs: (vertex, center2D, shs, feature, opacity, raster_settings); center2D is a gradient
     sink only and is never sent to the native side (reference :52-60, :156-164)."""
 
+    _variant = 2  # the sibling package diff_triangle_rasterization_3D subclasses this with _variant = 3
+                  # (ctx is an instance of the generated backward node; ctx._forward_cls is the class .apply ran on)
+
     @staticmethod
     def forward(ctx, vertex, center2D, shs, feature, opacity, raster_settings):
         rs = raster_settings
@@ -88,7 +91,7 @@ class _RasterizeTriangles(torch.autograd.Function):
             vertex, shs, feature, opacity, rs.back_culling, rs.rich_info, rs.debug)
         with _snapshot_on_error("rasterize_triangles", native_args, rs.debug):
             (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max,
-             geometryBuffer, binningBuffer, imageBuffer) = _C.rasterize_triangles(*native_args)
+             geometryBuffer, binningBuffer, imageBuffer) = _C.rasterize_triangles(*native_args, variant=ctx._forward_cls._variant)
 
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
@@ -113,7 +116,8 @@ class _RasterizeTriangles(torch.autograd.Function):
             vertex, shs, feature, opacity, ctx.num_rendered, radii, geometryBuffer, binningBuffer, imageBuffer,
             g_feature.contiguous(), g_depth.contiguous(), g_normal.contiguous(), rs.rich_info, rs.debug)
         with _snapshot_on_error("rasterize_triangles_backward", native_args, rs.debug):
-            g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(*native_args)
+            g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(
+                *native_args, variant=ctx._forward_cls._variant)
         # The placeholder standing in for the unused one of shs/feature is a CPU `torch.Tensor([])`
         # (reference :183-184) that never requires grad; hand autograd None for it.
         if not ctx.needs_input_grad[2]:
@@ -124,6 +128,8 @@ class _RasterizeTriangles(torch.autograd.Function):
 
 
 class TriangleRasterizer(nn.Module):
+    _function = _RasterizeTriangles
+
     def __init__(self, raster_settings: TriangleRasterizationSettings):
         super().__init__()
         self.raster_settings = raster_settings
@@ -133,7 +139,7 @@ class TriangleRasterizer(nn.Module):
             # same exception type and message as the reference (:180-181)
             raise Exception("Please provide excatly one of either SHs or feature!")
         placeholder = torch.Tensor([])  # stays on the CPU like the reference's; never dereferenced
-        return _RasterizeTriangles.apply(
+        return self._function.apply(
             vertex, center2D, placeholder if shs is None else shs, placeholder if feature is None else feature,
             opacity, self.raster_settings)
 
