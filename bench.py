@@ -78,6 +78,8 @@ def main():
                     help="refstruct = reference-structured blend kernels (measurement aid, BASELINE.md section 3)")
     ap.add_argument("--rasterizer", default="2D", choices=["2D", "3D"],
                     help="2D = the headline path (BASELINE.json); 3D = the ray/plane variant (SURVEY.md 8f rank 1), not the headline")
+    ap.add_argument("--dense-exchange", action="store_true",
+                    help="N > 1: all-reduce the dense dL_dshs (60 floats/triangle) instead of the factored exchange (15 + 3 per view)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
@@ -88,16 +90,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the rasterizer has no CPU fallback)")
+    # TS2D_BENCH_BACKEND=gloo is a functional check of the N > 1 code path on a box with fewer GPUs than ranks (ranks
+    # then share devices and tensors travel through the host); measurements use the default, RCCL.
+    backend = os.environ.get("TS2D_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev if backend == "nccl" else None)
 
     import synthetic
     from diff_triangle_rasterization_2D import TriangleRasterizationSettings, TriangleRasterizer, _C
     if args.rasterizer == "3D":
         from diff_triangle_rasterization_3D import TriangleRasterizer
+    from diff_triangle_rasterization_2D import parallel
     from diff_triangle_rasterization_2D.parallel import GradBucket
 
     P, W, H, D = args.triangles, args.width, args.height, args.sh_degree
@@ -122,17 +129,30 @@ def main():
     opacity = t(s["opacity"]).requires_grad_(True)
     g_feat, g_depth, g_norm = t(s["dL_dout_feature"]), t(s["dL_dout_depth"]), t(s["dL_dout_normal"])
     bucket = None
+    factored = world > 1 and not args.dense_exchange
+    M = shs.shape[1]
     if world > 1:
-        bucket = GradBucket([vertex.shape, shs.shape, opacity.shape, torch.Size((P, 2))], dev)
+        shapes = [vertex.shape, opacity.shape, torch.Size((P, 2))] + ([] if factored else [shs.shape])
+        bucket = GradBucket(shapes, dev)
+    sink = parallel.ShGradSink()
 
     state = {}
 
     def step():
         center2D = torch.zeros((P, 2), device=dev, requires_grad=True)  # like triangle_renderer.py:67
-        out = raster(vertex, center2D, opacity, shs=shs)
-        torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
-        if bucket is not None:
-            bucket.all_reduce([vertex.grad, shs.grad, opacity.grad, center2D.grad])
+        if factored:  # SH gradients leave the backward as (dL_dRGB, campos) factors, see parallel.py
+            with parallel.factored_sh_grads(sink):
+                out = raster(vertex, center2D, opacity, shs=shs)
+                torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
+            bucket.pack([vertex.grad, opacity.grad, center2D.grad])
+            bucket.all_reduce_async()
+            state["shs_grad"] = parallel.exchange_factored_sh_grads(sink, vertex, D, M)  # summed over all ranks' views
+            bucket.wait()
+        else:
+            out = raster(vertex, center2D, opacity, shs=shs)
+            torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
+            if bucket is not None:
+                bucket.all_reduce([vertex.grad, opacity.grad, center2D.grad, shs.grad])
         state["num_rendered"] = out[0].grad_fn.num_rendered
         state["image"] = out[0]
         vertex.grad = None
@@ -189,7 +209,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"mode": args.mode, "rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
                    "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N,
-                   "parallelism": f"image-parallel x{world}" + (", RCCL all-reduce of per-triangle grads" if world > 1 else ""),
+                   "parallelism": f"image-parallel x{world}" + ((", RCCL all-reduce of 12 floats/triangle + all-gather of factored SH grads (3 floats/triangle/view)" if factored
+                                       else ", RCCL all-reduce of dense per-triangle grads (60 floats/triangle)") if world > 1 else ""),
                    "algorithmic_bytes_per_step": alg["total"],
                    "achieved_hbm_gbs_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9, 2),
                    "hbm_roofline_frac_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},

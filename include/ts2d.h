@@ -56,6 +56,10 @@ extern "C" {
                                        (same entry points and argument lists, R3D/src/extension_interface.cu:14-276;
                                        R3D has no `contiguous` check, its forward.cu/backward.cu replace the 2D maths) */
 
+#define TS2D_FLAG_SH_FACTORED 0x20u  /* ts2d_backward only, SH mode: do not write dL_dshs (may be null); dL_dfeature receives
+                                       the clamp-masked colour gradient dL_dRGB (P*3) from which ts2d_sh_grad_expand
+                                       rebuilds dL_dshs -- the multi-GPU exchange format (new; no reference counterpart) */
+
 #define TS2D_MAX_CHANNELS 3 /* R2D/src/config.h:3 */
 #define TS2D_TILE 16        /* R2D/src/config.h:4-5 (BLOCK_X = BLOCK_Y = 16) */
 
@@ -145,6 +149,15 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
 int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t num_rendered,
                   const int32_t *radii, const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch,
                   size_t scratch_bytes, const ts2d_backward_out *out, void *stream);
+
+/* Multi-GPU gradient exchange helper (new capability, BASELINE.json north_star "image-parallel"; the reference has no
+ * distributed path).  Each view's dL_dshs is basis(dir) x dL_dRGB per triangle (R2D/src/backward.cu:9-119), so ranks
+ * exchange dL_dRGB (3 floats per triangle and view, from ts2d_backward with TS2D_FLAG_SH_FACTORED) plus the camera
+ * centres instead of 3*M floats, and rebuild the sum over `num_views` views here:
+ *   dL_dshs[i,k,:] = sum_v basis_k(normalize(centroid_i - campos[v])) * dL_dcolor[v,i,:]        (zeros for k >= (D+1)^2)
+ * vertex: P*9, campos: num_views*3, dL_dcolor: num_views*P*3, dL_dshs: P*M*3 (fully written).  Asynchronous. */
+int ts2d_sh_grad_expand(int32_t P, int32_t sh_degree, int32_t M, int32_t num_views, const float *vertex, const float *campos,
+                        const float *dL_dcolor, float *dL_dshs, void *stream);
 
 /* Test/diagnostic access to the private state: copies field `field` into host memory `dst`
  * (dst_bytes must be large enough), synchronising `stream`.  Fields:

@@ -73,3 +73,84 @@ def test_single_process_is_a_noop(hip_lib_built):
     g = torch.arange(6.0).view(3, 2)
     assert torch.equal(b.all_reduce([g])[0], g)
     assert shard_views(4, 0, 1) == [0, 1, 2, 3]
+
+
+# ---- factored SH-gradient exchange (protocol over gloo; the HIP expand kernel itself is covered by the GPU suite) ----
+def _expand_reference(vertex, campos, colors, sh_degree, M):
+    """float64 torch restatement of csrc/shgrad.hip (degree <= 1 is enough to exercise the protocol)."""
+    assert sh_degree <= 1
+    c = vertex.double().mean(1)
+    out = torch.zeros((vertex.shape[0], M, 3), dtype=torch.float64)
+    C0, C1 = 0.28209479177387814, 0.4886025119029199
+    for v in range(campos.shape[0]):
+        d = c - campos[v].double()
+        d = d / d.norm(dim=-1, keepdim=True)
+        g = colors[v].double()
+        out[:, 0] += C0 * g
+        if sh_degree > 0:
+            out[:, 1] += -C1 * d[:, 1:2] * g
+            out[:, 2] += C1 * d[:, 2:3] * g
+            out[:, 3] += -C1 * d[:, 0:1] * g
+    return out.float()
+
+
+def _factored_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diff_triangle_rasterization_2D import parallel
+
+        P, M, V = 29, 4, 2  # two views per rank
+        gv = torch.Generator().manual_seed(7)
+        vertex = torch.rand((P, 3, 3), generator=gv) * 10
+
+        def factors(r):
+            g = torch.Generator().manual_seed(500 + r)
+            return [(torch.rand((P, 3), generator=g), torch.rand(3, generator=g) * 50 + 20) for _ in range(V)]
+
+        sink = parallel.ShGradSink()
+        for col, cp in factors(rank):
+            sink.append(col, cp)
+        got = parallel.exchange_factored_sh_grads(sink, vertex, 1, M, expand_fn=_expand_reference)
+        allf = [f for r in range(world) for f in factors(r)]
+        want = _expand_reference(vertex, torch.stack([cp for _, cp in allf]), torch.stack([c for c, _ in allf]), 1, M)
+        ok = torch.allclose(got, want, atol=1e-6) and not sink.colors
+        # mean mode divides by the world size
+        for col, cp in factors(rank):
+            sink.append(col, cp)
+        got_mean = parallel.exchange_factored_sh_grads(sink, vertex, 1, M, mean=True, expand_fn=_expand_reference)
+        ok = ok and torch.allclose(got_mean, want / world, atol=1e-6)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_factored_sh_exchange_world2(hip_lib_built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_factored_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
+def test_factored_sink_context_and_errors(hip_lib_built):
+    import diff_triangle_rasterization_2D as pkg
+    from diff_triangle_rasterization_2D import parallel
+
+    assert pkg._sh_grad_sink is None
+    with parallel.factored_sh_grads() as sink:
+        assert pkg._sh_grad_sink is sink
+    assert pkg._sh_grad_sink is None
+    with pytest.raises(RuntimeError):
+        parallel.exchange_factored_sh_grads(parallel.ShGradSink(), torch.zeros((1, 3, 3)), 0, 1)
+    # the default expand is the HIP kernel: CPU tensors are refused, there is no CPU fallback
+    sink = parallel.ShGradSink()
+    sink.append(torch.zeros((1, 3)), torch.zeros(3))
+    with pytest.raises(RuntimeError):
+        parallel.exchange_factored_sh_grads(sink, torch.zeros((1, 3, 3)), 0, 1)

@@ -28,6 +28,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-a
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "preprocess3d.hip": ["-ffp-contract=off"],
+    "shgrad.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],

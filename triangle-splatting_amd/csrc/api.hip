@@ -290,7 +290,8 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     if (P == 0) return TS2D_OK; // extension_interface.cu:242
     if (!loss->dL_dout_feature || (rich && (!loss->dL_dout_depth || !loss->dL_dout_normal)))
         return fail(TS2D_ERR_INVALID, "upstream gradients are null");
-    if (!out->dL_dvertex || !out->dL_dcenter2D || !out->dL_dfeature || !out->dL_dopacity || (use_shs && !out->dL_dshs))
+    const bool factored = use_shs && (flags & TS2D_FLAG_SH_FACTORED);
+    if (!out->dL_dvertex || !out->dL_dcenter2D || !out->dL_dfeature || !out->dL_dopacity || (use_shs && !factored && !out->dL_dshs))
         return fail(TS2D_ERR_INVALID, "gradient outputs are null");
     if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
     if (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P)) return fail(TS2D_ERR_CAPACITY, "backward scratch too small");
@@ -327,13 +328,31 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
         ProfScope ps("preprocess_bwd", s);
         const PreprocessArgs a = make_pre(cam, geom, flags);
         if (flags & TS2D_FLAG_3D)
-            ts_launch_preprocess3d_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, out->dL_dshs,
+            ts_launch_preprocess3d_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, factored ? nullptr : out->dL_dshs,
                                        out->dL_dfeature, out->dL_dopacity, s);
         else
-            ts_launch_preprocess_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, out->dL_dshs, out->dL_dfeature,
-                                     out->dL_dopacity, s);
+            ts_launch_preprocess_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, factored ? nullptr : out->dL_dshs,
+                                     out->dL_dfeature, out->dL_dopacity, s);
     }
     TS_CHECK(flags, s, "preprocess_bwd");
+    return TS2D_OK;
+}
+
+int ts2d_sh_grad_expand(int32_t P, int32_t sh_degree, int32_t M, int32_t num_views, const float *vertex, const float *campos,
+                        const float *dL_dcolor, float *dL_dshs, void *stream)
+{
+    if (P < 0 || num_views < 0) return fail(TS2D_ERR_INVALID, "P / num_views must be >= 0");
+    if (sh_degree < 0 || sh_degree > 3) return fail(TS2D_ERR_INVALID, "sh_degree must be in 0..3");
+    if ((sh_degree + 1) * (sh_degree + 1) > M) return fail(TS2D_ERR_INVALID, "shs holds fewer coefficients than sh_degree needs");
+    if (P == 0) return TS2D_OK;
+    if (!vertex || !dL_dshs || (num_views > 0 && (!campos || !dL_dcolor))) return fail(TS2D_ERR_INVALID, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope ps("sh_grad_expand", s);
+        ts_launch_sh_grad_expand(P, sh_degree, M, num_views, vertex, campos, dL_dcolor, dL_dshs, s);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(TS2D_ERR_HIP, "sh_grad_expand: %s", hipGetErrorString(e));
     return TS2D_OK;
 }
 

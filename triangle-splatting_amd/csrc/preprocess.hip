@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, c
     const float4 g0 = gr[0], g1 = gr[1], g2 = gr[2], g3 = gr[3];
     const f2 dL_dv1_2D = {g0.x, g0.y}, dL_dv2_2D = {g0.z, g0.w}, dL_dv3_2D = {g1.x, g1.y};
     const float dL_dop = g1.z;
-    const f3 dL_drgb = {g1.w, g2.x, g2.y};
+    f3 dL_drgb = {g1.w, g2.x, g2.y};
     const f3 dL_dnormal_view = {g2.z, g2.w, g3.x};
     const f3 dL_dv_depth = {g3.y, g3.z, g3.w};
 
@@ -237,7 +237,9 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, c
         dL_dRGB.y *= (cl & 2) ? 0.0f : 1.0f;
         dL_dRGB.z *= (cl & 4) ? 0.0f : 1.0f;
         const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
-        const f3 dsh = sh_backward(a.D, a.M, a.shs + (size_t)idx * a.M * 3, center, cp, dL_dRGB, dL_dshs + (size_t)idx * a.M * 3);
+        const f3 dsh = sh_backward(a.D, a.M, a.shs + (size_t)idx * a.M * 3, center, cp, dL_dRGB,
+                                   dL_dshs ? dL_dshs + (size_t)idx * a.M * 3 : nullptr);
+        if (!dL_dshs) dL_drgb = dL_dRGB; // factored exchange (TS2D_FLAG_SH_FACTORED): hand out the clamp-masked colour gradient
         dL_dcenter = add(dL_dcenter, dsh);
     }
 

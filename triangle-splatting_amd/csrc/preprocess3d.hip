@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(256) preprocess3d_bwd_kernel(PreprocessArgs a,
     const f3 gn = {g2.y, g2.z, g2.w};
     const float gop = g3.x;
     const f3 grgb = {g3.y, g3.z, g3.w};
+    f3 grgb_out = grgb;
 
     gv1 = add(gv1, cross(sub(v2_view, v3_view), gn)); // R3D backward.cu:176-178
     gv2 = add(gv2, cross(sub(v3_view, v1_view), gn));
@@ -150,7 +151,9 @@ __global__ void __launch_bounds__(256) preprocess3d_bwd_kernel(PreprocessArgs a,
         dL_dRGB.y *= (cl & 2) ? 0.0f : 1.0f;
         dL_dRGB.z *= (cl & 4) ? 0.0f : 1.0f;
         const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
-        const f3 dsh = sh_backward(a.D, a.M, a.shs + (size_t)idx * a.M * 3, center, cp, dL_dRGB, dL_dshs + (size_t)idx * a.M * 3);
+        const f3 dsh = sh_backward(a.D, a.M, a.shs + (size_t)idx * a.M * 3, center, cp, dL_dRGB,
+                                   dL_dshs ? dL_dshs + (size_t)idx * a.M * 3 : nullptr);
+        if (!dL_dshs) grgb_out = dL_dRGB; // factored exchange (TS2D_FLAG_SH_FACTORED)
         const f3 third = divf(dsh, 3.0f); // R3D backward.cu:196-198
         dL_dv1 = add(dL_dv1, third); dL_dv2 = add(dL_dv2, third); dL_dv3 = add(dL_dv3, third);
     }
@@ -161,9 +164,9 @@ __global__ void __launch_bounds__(256) preprocess3d_bwd_kernel(PreprocessArgs a,
     oc[0] = dcv.x; oc[1] = dcv.y;
     dL_dopacity[idx] = gop;
     float *of = dL_dfeature + (size_t)idx * a.C;
-    if (a.C > 0) of[0] = grgb.x;
-    if (a.C > 1) of[1] = grgb.y;
-    if (a.C > 2) of[2] = grgb.z;
+    if (a.C > 0) of[0] = grgb_out.x;
+    if (a.C > 1) of[1] = grgb_out.y;
+    if (a.C > 2) of[2] = grgb_out.z;
 }
 } // namespace
 

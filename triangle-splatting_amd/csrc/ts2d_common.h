@@ -190,3 +190,7 @@ void ts_launch_render3d_fwd(const RenderArgs &a, float tan_fovx, float tan_fovy,
 void ts_launch_render3d_bwd(const RenderArgs &a, float tan_fovx, float tan_fovy, const GeometryStateView &g,
                             const BinningStateView &b, const ImageStateView &im, const float *dL_dout_feature,
                             const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec, hipStream_t s);
+
+// ---- factored SH-gradient exchange (multi-GPU, shgrad.hip) ---------------------------------------------------------
+void ts_launch_sh_grad_expand(int P, int D, int M, int V, const float *vertex, const float *campos, const float *dL_dcolor,
+                              float *dL_dshs, hipStream_t s);

@@ -45,33 +45,50 @@ __device__ __forceinline__ f3 sh_to_rgb(int deg, const float *sh, f3 pos, f3 cam
 
 __device__ __forceinline__ void st3(float *p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 
-// backward.cu:9-119.  Writes all M coefficient gradients (zeros above the active degree).
+// d(colour)/d(sh_k) for the active coefficients, in the reference's expression order (backward.cu:20-85: the scalar
+// factor each dL_dsh[k] = factor * dL_dRGB is formed first, left to right).  Returns the number of active coefficients.
+__device__ __forceinline__ int sh_basis(int deg, f3 dir, float *b)
+{
+    const float x = dir.x, y = dir.y, z = dir.z;
+    b[0] = SH_C0;
+    if (deg < 1) return 1;
+    b[1] = -SH_C1 * y; b[2] = SH_C1 * z; b[3] = -SH_C1 * x;
+    if (deg < 2) return 4;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = SH_C2_0 * xy; b[5] = SH_C2_1 * yz; b[6] = SH_C2_2 * (2.f * zz - xx - yy); b[7] = SH_C2_3 * xz;
+    b[8] = SH_C2_4 * (xx - yy);
+    if (deg < 3) return 9;
+    b[9] = SH_C3_0 * y * (3.f * xx - yy); b[10] = SH_C3_1 * xy * z; b[11] = SH_C3_2 * y * (4.f * zz - xx - yy);
+    b[12] = SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy); b[13] = SH_C3_4 * x * (4.f * zz - xx - yy);
+    b[14] = SH_C3_5 * z * (xx - yy); b[15] = SH_C3_6 * x * (xx - 3.f * yy);
+    return 16;
+}
+
+// backward.cu:9-119.  Writes all M coefficient gradients (zeros above the active degree) unless dL_dsh is null (the
+// factored multi-GPU exchange rebuilds them from dL_dRGB, see shgrad.hip).  Returns dL/d(pos).
 __device__ __forceinline__ f3 sh_backward(int deg, int M, const float *sh, f3 pos, f3 campos, f3 dL_dRGB, float *dL_dsh)
 {
     const f3 dir_orig = sub(pos, campos);
     const f3 dir = divf(dir_orig, norm(dir_orig));
     f3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
     const float x = dir.x, y = dir.y, z = dir.z;
-    st3(dL_dsh, scale(SH_C0, dL_dRGB));
-    int written = 1;
+    if (dL_dsh)
+    {
+        float b[16];
+        const int written = sh_basis(deg, dir, b);
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (k < written) st3(dL_dsh + 3 * k, scale(b[k], dL_dRGB));
+        for (int k = written * 3; k < M * 3; k++) dL_dsh[k] = 0.0f;
+    }
     if (deg > 0)
     {
-        st3(dL_dsh + 3, scale(-SH_C1 * y, dL_dRGB));
-        st3(dL_dsh + 6, scale(SH_C1 * z, dL_dRGB));
-        st3(dL_dsh + 9, scale(-SH_C1 * x, dL_dRGB));
-        written = 4;
         dRGBdx = scale(-SH_C1, ld3(sh + 9));
         dRGBdy = scale(-SH_C1, ld3(sh + 3));
         dRGBdz = scale(SH_C1, ld3(sh + 6));
         if (deg > 1)
         {
             const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
-            st3(dL_dsh + 12, scale(SH_C2_0 * xy, dL_dRGB));
-            st3(dL_dsh + 15, scale(SH_C2_1 * yz, dL_dRGB));
-            st3(dL_dsh + 18, scale(SH_C2_2 * (2.f * zz - xx - yy), dL_dRGB));
-            st3(dL_dsh + 21, scale(SH_C2_3 * xz, dL_dRGB));
-            st3(dL_dsh + 24, scale(SH_C2_4 * (xx - yy), dL_dRGB));
-            written = 9;
             const f3 s4 = ld3(sh + 12), s5 = ld3(sh + 15), s6 = ld3(sh + 18), s7 = ld3(sh + 21), s8 = ld3(sh + 24);
             f3 t; // backward.cu:66-68, sums left to right
             t = scale(SH_C2_0 * y, s4);
@@ -90,14 +107,6 @@ __device__ __forceinline__ f3 sh_backward(int deg, int M, const float *sh, f3 po
             dRGBdz = add(dRGBdz, t);
             if (deg > 2)
             {
-                st3(dL_dsh + 27, scale(SH_C3_0 * y * (3.f * xx - yy), dL_dRGB));
-                st3(dL_dsh + 30, scale(SH_C3_1 * xy * z, dL_dRGB));
-                st3(dL_dsh + 33, scale(SH_C3_2 * y * (4.f * zz - xx - yy), dL_dRGB));
-                st3(dL_dsh + 36, scale(SH_C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy), dL_dRGB));
-                st3(dL_dsh + 39, scale(SH_C3_4 * x * (4.f * zz - xx - yy), dL_dRGB));
-                st3(dL_dsh + 42, scale(SH_C3_5 * z * (xx - yy), dL_dRGB));
-                st3(dL_dsh + 45, scale(SH_C3_6 * x * (xx - 3.f * yy), dL_dRGB));
-                written = 16;
                 const f3 s9 = ld3(sh + 27), s10 = ld3(sh + 30), s11 = ld3(sh + 33), s12 = ld3(sh + 36), s13 = ld3(sh + 39),
                          s14 = ld3(sh + 42), s15 = ld3(sh + 45);
                 // backward.cu:87-107: `c * sh * s1 * s2` is ((c*sh)*s1)*s2; sums left to right
@@ -126,7 +135,6 @@ __device__ __forceinline__ f3 sh_backward(int deg, int M, const float *sh, f3 po
             }
         }
     }
-    for (int k = written * 3; k < M * 3; k++) dL_dsh[k] = 0.0f;
     const f3 dL_ddir = {dot(dL_dRGB, dRGBdx), dot(dL_dRGB, dRGBdy), dot(dL_dRGB, dRGBdz)};
     return dnormvdv(dir_orig, dL_ddir); // backward.cu:118
 }

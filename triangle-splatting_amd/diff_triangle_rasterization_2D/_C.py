@@ -34,7 +34,7 @@ if not os.path.exists(_LIB_PATH):
     )
 _lib = C.CDLL(_LIB_PATH)
 
-FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS, FLAG_3D = 1, 2, 4, 8, 16
+FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS, FLAG_3D, FLAG_SH_FACTORED = 1, 2, 4, 8, 16, 32
 MAX_CHANNELS = 3
 
 _fp = C.c_void_p
@@ -88,6 +88,8 @@ _lib.ts2d_forward_render.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C
 _lib.ts2d_backward.restype = C.c_int
 _lib.ts2d_backward.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, C.c_int64, _fp,
                                C.POINTER(_State), C.POINTER(_LossGrads), _fp, C.c_size_t, C.POINTER(_BackwardOut), _fp]
+_lib.ts2d_sh_grad_expand.restype = C.c_int
+_lib.ts2d_sh_grad_expand.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp]
 _lib.ts2d_debug_read_state.restype = C.c_int
 _lib.ts2d_debug_read_state.argtypes = [C.POINTER(_State), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp,
                                        C.c_size_t, _fp]
@@ -234,7 +236,9 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
 def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                                  background_depth, background, vertex, shs, feature, opacity, num_rendered, radii,
                                  geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
-                                 dL_dout_normal, rich_info, debug, *, variant=2):
+                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False):
+    """`sh_factored=True` (SH mode only; TS2D_FLAG_SH_FACTORED): dL_dshs is not formed (returned as None) and the fourth
+    result holds the clamp-masked colour gradient dL_dRGB (P, 3) for `sh_grad_expand` -- see parallel.py."""
     P = vertex.size(0)
     H, W = dL_dout_feature.size(1), dL_dout_feature.size(2)  # extension_interface.cu:182-183
     use_shs = _use_shs(shs, feature)
@@ -256,13 +260,17 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
         opts = dict(device=dev, dtype=vertex.dtype)
         dL_dvertex = alloc((P, 3, 3), **opts)
         dL_dcenter2D = alloc((P, 2), **opts)
-        dL_dshs = alloc((P, M, 3), **opts) if use_shs else torch.zeros((P, M, 3), **opts)
+        sh_factored = bool(sh_factored and use_shs)
+        if sh_factored:
+            dL_dshs = None
+        else:
+            dL_dshs = alloc((P, M, 3), **opts) if use_shs else torch.zeros((P, M, 3), **opts)
         dL_dfeature = alloc((P, Cn), **opts)
         dL_dopacity = alloc((P, 1), **opts)
         if P == 0:
             return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
         flags = ((FLAG_RICH_INFO if rich_info else 0) | (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) |
-                 (FLAG_3D if variant == 3 else 0))
+                 (FLAG_3D if variant == 3 else 0) | (FLAG_SH_FACTORED if sh_factored else 0))
         cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
         st = _state(geometryBuffer, binningBuffer, imageBuffer)
@@ -274,6 +282,23 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
                                   C.byref(loss), _ptr(scratch), scratch.numel(), C.byref(out), stream),
                "rasterize_triangles_backward")
     return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
+
+
+def sh_grad_expand(vertex, campos, dL_dcolor, sh_degree, M, out=None):
+    """dL_dshs (P, M, 3) = sum over views v of basis(normalize(centroid - campos[v])) x dL_dcolor[v]  (ts2d_sh_grad_expand).
+    vertex (P,3,3), campos (V,3), dL_dcolor (V,P,3): contiguous float32 on one HIP device."""
+    _require_device(vertex)
+    _contiguous_or_raise(vertex, campos, dL_dcolor, out)
+    _f32_or_raise(vertex, campos, dL_dcolor, out)
+    P, V = vertex.size(0), campos.size(0)
+    if dL_dcolor.shape != (V, P, 3):
+        raise RuntimeError("dL_dcolor must have dimensions (num_views, num_points, 3)")
+    with torch.cuda.device(vertex.device):
+        if out is None:
+            out = (torch.zeros if P == 0 else torch.empty)((P, int(M), 3), device=vertex.device, dtype=torch.float32)
+        _check(_lib.ts2d_sh_grad_expand(P, int(sh_degree), int(M), V, _ptr(vertex), _ptr(campos), _ptr(dL_dcolor), _ptr(out),
+                                        torch.cuda.current_stream().cuda_stream), "sh_grad_expand")
+    return out
 
 
 # ---- diagnostics used by tests and bench.py (not part of the reference's surface) ---------------------------

@@ -74,6 +74,12 @@ def _camera_and_geometry_args(rs: TriangleRasterizationSettings, background_dept
     )
 
 
+# Set by parallel.factored_sh_grads(): while a sink is installed, backward passes in SH mode do not form the dense
+# dL_dshs; they append (dL_dRGB (P,3), campos (3,)) to the sink and return no gradient for `shs` (parallel.py rebuilds the
+# sum over all ranks' views from the exchanged factors).
+_sh_grad_sink = None
+
+
 class _RasterizeTriangles(torch.autograd.Function):
     """autograd inputs: (vertex, center2D, shs, feature, opacity, raster_settings); center2D is a gradient
     sink only and is never sent to the native side (reference :52-60, :156-164)."""
@@ -116,8 +122,11 @@ class _RasterizeTriangles(torch.autograd.Function):
             vertex, shs, feature, opacity, ctx.num_rendered, radii, geometryBuffer, binningBuffer, imageBuffer,
             g_feature.contiguous(), g_depth.contiguous(), g_normal.contiguous(), rs.rich_info, rs.debug)
         with _snapshot_on_error("rasterize_triangles_backward", native_args, rs.debug):
+            sink = _sh_grad_sink if (ctx.needs_input_grad[2] and shs.numel() > 0) else None
             g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(
-                *native_args, variant=ctx._forward_cls._variant)
+                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None)
+            if sink is not None:
+                sink.append(g_feat, rs.campos)
         # The placeholder standing in for the unused one of shs/feature is a CPU `torch.Tensor([])`
         # (reference :183-184) that never requires grad; hand autograd None for it.
         if not ctx.needs_input_grad[2]:

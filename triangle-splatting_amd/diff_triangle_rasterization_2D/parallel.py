@@ -110,3 +110,83 @@ def reduce_render_stats(stats: Dict[str, torch.Tensor], group=None) -> Dict[str,
         dist.all_reduce(v, op=dist.ReduceOp.SUM if "count" in k else dist.ReduceOp.MAX, group=group)
         out[k] = v
     return out
+
+
+# ---- factored SH-gradient exchange ---------------------------------------------------------------------------------
+# Per view, dL/dshs of a triangle is the rank-1 product basis_k(dir) * dL_dRGB (R2D/src/backward.cu:9-119): 3 M floats
+# that carry 3 floats of information plus the camera centre.  With M = 16 the dense all-reduce bucket is 60 floats per
+# triangle (240 MB at 1 M triangles), 48 of them SH; xGMI links are the scarce resource (7 x ~153 GB/s point-to-point
+# per GPU), so the SH part travels factored: every rank all-gathers (dL_dRGB, campos) -- 3 floats per triangle and view
+# -- and rebuilds sum_v basis(dir_v) x dL_dRGB_v locally with one HBM-bound kernel (csrc/shgrad.hip).  The rest
+# (vertex 9 + opacity 1 + center2D 2 floats) stays on the flat all-reduce bucket.  Wire volume per GPU at 8 ranks:
+# 2 * 7/8 * 240 MB = 420 MB dense  ->  2 * 7/8 * 48 MB + 7 * 12 MB = 168 MB factored.
+
+class ShGradSink:
+    """Collects (dL_dRGB (P,3), campos (3,)) of every SH-mode backward pass run under `factored_sh_grads()`."""
+
+    def __init__(self):
+        self.colors: List[torch.Tensor] = []
+        self.campos: List[torch.Tensor] = []
+
+    def append(self, dL_dcolor: torch.Tensor, campos: torch.Tensor):
+        self.colors.append(dL_dcolor)
+        self.campos.append(campos.detach().reshape(3).to(dL_dcolor.device, torch.float32))
+
+    def clear(self):
+        self.colors.clear()
+        self.campos.clear()
+
+
+class factored_sh_grads:
+    """Context manager: backward passes of TriangleRasterizer (2D and 3D packages) run inside it hand their SH gradients
+    to the returned sink in factored form and leave `shs.grad` untouched; `exchange_factored_sh_grads` finishes the job."""
+
+    def __init__(self, sink: Optional[ShGradSink] = None):
+        self.sink = sink if sink is not None else ShGradSink()
+
+    def __enter__(self) -> ShGradSink:
+        import diff_triangle_rasterization_2D as pkg
+        self._prev = pkg._sh_grad_sink
+        pkg._sh_grad_sink = self.sink
+        return self.sink
+
+    def __exit__(self, *exc):
+        import diff_triangle_rasterization_2D as pkg
+        pkg._sh_grad_sink = self._prev
+        return False
+
+
+def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree: int, M: int, group=None,
+                               mean: bool = False, expand_fn=None) -> torch.Tensor:
+    """All-gathers the sink's factors over the ranks and returns the dense dL_dshs (P, M, 3) summed over every view of
+    every rank (divided by the world size with mean=True, like GradBucket).  Every rank must hold the same number of
+    views.  `expand_fn(vertex, campos (V,3), dL_dcolor (V,P,3), sh_degree, M)` defaults to the HIP kernel behind
+    `_C.sh_grad_expand`; the CPU tests inject a reference implementation to exercise the protocol over gloo."""
+    if not sink.colors:
+        raise RuntimeError("no SH-mode backward pass ran under factored_sh_grads()")
+    if expand_fn is None:
+        from . import _C
+        expand_fn = _C.sh_grad_expand
+    P = vertex.shape[0]
+    V = len(sink.colors)
+    # one flat message per rank: V * (3 P colour floats + 3 camera floats, padded to 4)
+    local = torch.empty((V, 3 * P + 4), device=sink.colors[0].device, dtype=torch.float32)
+    for v, (c, cp) in enumerate(zip(sink.colors, sink.campos)):
+        local[v, :3 * P] = c.reshape(-1)
+        local[v, 3 * P:3 * P + 3] = cp
+        local[v, 3 * P + 3] = 0.0
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world > 1:
+        gathered = torch.empty((world * V, 3 * P + 4), device=local.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(gathered, local, group=group)
+    else:
+        gathered = local
+    colors = gathered[:, :3 * P].reshape(world * V, P, 3)
+    campos = gathered[:, 3 * P:3 * P + 3]
+    if not colors.is_contiguous() or not campos.is_contiguous():
+        colors, campos = colors.contiguous(), campos.contiguous()
+    out = expand_fn(vertex.detach(), campos, colors, sh_degree, M)
+    if mean and world > 1:
+        out.div_(world)
+    sink.clear()
+    return out
