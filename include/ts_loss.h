@@ -1,0 +1,41 @@
+/* ts_loss.h -- C ABI of the fused photometric loss (L1 + SSIM) that feeds the rasterizer's dL_dout_feature.
+ *
+ * the step either side of the hot path.  Replaces, for one image pair, the reference's
+ *     l1_loss   = L1(image, gt_image)                       src/diff_recon/trainers/trainer_utils.py:323-324
+ *     ssim_loss = ssimLoss(image, gt_image)                 trainer_utils.py:9-103 (GaussianSmoothing2D 11x11 sigma 1.5,
+ *                                                           zero padding, C1 = 0.01^2, C2 = 0.03^2, mean over all elements)
+ *     img_loss  = w_L1 * l1_loss + w_ssim * ssim_loss       src/diff_recon/trainers/VanillaTS_trainer.py:80-81,111
+ * and their autograd backward (ten eager torch kernels forward, more backward) with two HIP kernels each way.
+ * Exported by the same libts2d.so as include/ts2d.h.  All pointers are device pointers; images are planar float32
+ * (C, H, W) -- a leading batch dimension folds into C, exactly as the reference's depthwise conv + global mean does.
+ * Every call enqueues on `stream` and returns TS2D_OK (0) or an error code of ts2d.h with ts2d_last_error() set. */
+#ifndef TS_LOSS_H
+#define TS_LOSS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Bytes of device scratch the forward fills and the backward reads (three per-element derivative maps + per-block
+ * partial sums). */
+size_t tsl_workspace_bytes(int32_t channels, int32_t height, int32_t width);
+
+/* Forward.  out[0] = w_l1 * L1 + w_ssim * (1 - SSIM), out[1] = L1 = mean|image - gt|, out[2] = 1 - mean(ssim_map)
+ * (three floats in device memory).  `need_grad` = 0 skips writing the derivative maps (evaluation). */
+int tsl_photometric_forward(const float *image, const float *gt, int32_t channels, int32_t height, int32_t width,
+                            float w_l1, float w_ssim, int32_t need_grad, void *workspace, size_t workspace_bytes, float *out,
+                            void *stream);
+
+/* Backward of out[0] with respect to `image`: dL_dimage (C, H, W) fully written.  `grad_out` is a device scalar
+ * (upstream gradient of the loss) or NULL for 1.  `workspace` must be the buffer the matching forward filled. */
+int tsl_photometric_backward(const float *image, const float *gt, int32_t channels, int32_t height, int32_t width,
+                             float w_l1, float w_ssim, const void *workspace, size_t workspace_bytes, const float *grad_out,
+                             float *dL_dimage, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

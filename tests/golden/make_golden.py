@@ -13,8 +13,16 @@ Fixtures are data only (inputs + expected outputs):
   gamma_rescale.npz : gamma -> the triangle rescale ratio of src/diff_recon/models/VanillaTS_model.py:615-617
                 (restated formula 1/sqrt(2^beta * beta * Gamma(beta)), beta = 1/gamma, evaluated with scipy like the
                  reference; the model class itself is not importable here).
+  photometric.npz : image pairs, (w_L1, w_ssim) -> L1, ssimLoss, img_loss and d img_loss / d image (torch autograd) of
+                src/diff_recon/trainers/trainer_utils.py:9-103,323-324 combined as VanillaTS_trainer.py:80-81,111.
+                trainer_utils.py imports two third-party packages at module level that this image lacks and that the
+                loss code never touches (torchmetrics' LPIPS class, simple_knn); empty placeholder modules are
+                registered for those two names so the file imports -- every line that produces the vectors
+                (GaussianSmoothing2D, SSIM, SSIMLoss, L1) is the reference's own.
 """
 import importlib.util
+import sys
+import types
 import math
 import os
 
@@ -32,10 +40,53 @@ def load(name):
     return mod
 
 
+def load_trainer_utils():
+    for name, attrs in (("torchmetrics", {}), ("torchmetrics.image", {}),
+                        ("torchmetrics.image.lpip", {"LearnedPerceptualImagePatchSimilarity": lambda **kw: None}),
+                        ("simple_knn", {"nearestNeighbor": None})):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__dict__.update(attrs)
+            sys.modules[name] = m
+    spec = importlib.util.spec_from_file_location(
+        "ref_trainer_utils", "/root/reference/src/diff_recon/trainers/trainer_utils.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def photometric(rng):
+    tu = load_trainer_utils()
+    out = {}
+    cases = [(3, 37, 53, 0.8, 0.2), (3, 64, 48, 0.5, 0.5), (1, 20, 70, 1.0, 0.0), (3, 12, 9, 0.0, 1.0)]
+    for i, (C, H, W, w1, ws) in enumerate(cases):
+        gt = rng.uniform(0, 1, size=(C, H, W)).astype(np.float32)
+        # smooth-ish render: gt blurred by noise mix, so SSIM is neither ~0 nor ~1
+        img = np.clip(0.6 * gt + 0.4 * rng.uniform(0, 1, size=(C, H, W)), 0, 1).astype(np.float32)
+        res = {}
+        for dt, tag in ((torch.float64, "f64"), (torch.float32, "f32")):
+            x = torch.tensor(img, dtype=dt, requires_grad=True)
+            g = torch.tensor(gt, dtype=dt)
+            ssim_mod = tu.SSIMLoss()
+            if dt == torch.float64:  # same code, evaluated in double: only the dtype of the (float32-built) window changes
+                ssim_mod.ssim.window.kernel = ssim_mod.ssim.window.kernel.double()
+            l1 = tu.L1(x, g)
+            sl = ssim_mod(x, g)
+            loss = w1 * l1 + ws * sl
+            loss.backward()
+            res[tag] = (float(l1), float(sl), float(loss), x.grad.numpy().astype(np.float64))
+        out.update({f"img{i}": img, f"gt{i}": gt, f"w{i}": np.array([w1, ws]),
+                    f"l1_{i}": res["f64"][0], f"ssim_loss_{i}": res["f64"][1], f"loss_{i}": res["f64"][2],
+                    f"grad_{i}": res["f64"][3], f"loss_f32_{i}": res["f32"][2], f"grad_f32_{i}": res["f32"][3].astype(np.float32)})
+    out["n"] = len(cases)
+    np.savez_compressed(os.path.join(HERE, "photometric.npz"), **out)
+
+
 def main():
     sh_utils = load("sh_utils")
     camera = load("camera")
     rng = np.random.default_rng(20250927)
+    photometric(np.random.default_rng(77))
 
     # ---- SH colour polynomial
     n = 256

@@ -1,0 +1,45 @@
+"""CPU tests of the photometric-loss oracle (oracle/ts_loss_oracle.py) against golden vectors produced by the
+REFERENCE's own SSIM / L1 classes and torch autograd (tests/golden/photometric.npz, generator tests/golden/make_golden.py),
+plus the host-side argument checks of the drop-in module."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ts_loss_oracle as LO
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "photometric.npz"))
+
+
+@pytest.mark.parametrize("i", range(int(GOLD["n"])))
+def test_oracle_matches_reference_loss_and_autograd(i):
+    img, gt = GOLD[f"img{i}"], GOLD[f"gt{i}"]
+    w1, ws = GOLD[f"w{i}"]
+    loss, l1, sl, grad = LO.photometric_loss(img, gt, w1, ws)
+    assert abs(l1 - float(GOLD[f"l1_{i}"])) < 1e-12
+    # the window is built in float32 (trainer_utils.py:17-29); torch's and numpy's fp32 exp differ in the last bit,
+    # which bounds the agreement of everything downstream at ~1e-7
+    assert abs(sl - float(GOLD[f"ssim_loss_{i}"])) < 5e-7
+    assert abs(loss - float(GOLD[f"loss_{i}"])) < 5e-7
+    g_ref = GOLD[f"grad_{i}"]
+    assert np.abs(grad - g_ref).max() <= 1e-5 * np.abs(g_ref).max()
+    # the reference's own float32 evaluation stays within fp32 noise of the float64 one
+    assert abs(float(GOLD[f"loss_f32_{i}"]) - loss) < 1e-5
+    assert np.linalg.norm(GOLD[f"grad_f32_{i}"] - g_ref) <= 1e-4 * np.linalg.norm(g_ref)
+
+
+def test_window_is_zero_padded_and_normalised():
+    k = LO.gaussian_kernel_2d()
+    assert k.shape == (11, 11) and abs(k.sum() - 1.0) < 1e-6 and np.allclose(k, k.T)
+    x = np.ones((1, 30, 30))
+    w = LO.window(x)
+    assert abs(w[0, 15, 15] - 1.0) < 1e-6          # interior: full window
+    assert abs(w[0, 0, 0] - k[5:, 5:].astype(np.float64).sum()) < 1e-9  # corner: only the in-image quadrant contributes (zero padding)
+
+
+def test_batched_input_folds_into_channels():
+    rng = np.random.default_rng(0)
+    a, b = rng.random((2, 3, 16, 18)), rng.random((2, 3, 16, 18))
+    l4 = LO.photometric_loss(a, b, 0.8, 0.2)
+    l3 = LO.photometric_loss(a.reshape(6, 16, 18), b.reshape(6, 16, 18), 0.8, 0.2)
+    assert abs(l4[0] - l3[0]) < 1e-15 and np.array_equal(l4[3].reshape(6, 16, 18), l3[3])

@@ -29,13 +29,15 @@ SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "preprocess3d.hip": ["-ffp-contract=off"],
     "shgrad.hip": ["-ffp-contract=off"],
+    "photometric.hip": [],
     "binning.hip": [],
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "refstruct.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],  # measurement aid (TS2D_MODE=refstruct)
     "api.hip": [],
 }
-HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", os.path.join("..", "..", "include", "ts2d.h")]
+HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", os.path.join("..", "..", "include", "ts2d.h"),
+           os.path.join("..", "..", "include", "ts_loss.h")]
 
 
 def hipcc() -> str:

@@ -6,6 +6,7 @@
 // stream), the only host synchronisation is the num_rendered read-back, outputs need no pre-zeroing, and the
 // zero-filled scratch of the backward is one 64-byte-per-triangle gradient record array.
 #include "../../include/ts2d.h"
+#include "../../include/ts_loss.h"
 #include "ts2d_common.h"
 
 #include <cstdarg>
@@ -353,6 +354,41 @@ int ts2d_sh_grad_expand(int32_t P, int32_t sh_degree, int32_t M, int32_t num_vie
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(TS2D_ERR_HIP, "sh_grad_expand: %s", hipGetErrorString(e));
+    return TS2D_OK;
+}
+
+// ---- include/ts_loss.h ------------------------------------------------------------------------------------------------
+size_t tsl_workspace_bytes(int32_t channels, int32_t height, int32_t width) { return ts_loss_workspace_bytes(channels, height, width); }
+
+static int loss_args_ok(const float *image, const float *gt, int32_t C, int32_t H, int32_t W, const void *ws, size_t ws_bytes)
+{
+    if (C <= 0 || H <= 0 || W <= 0) return fail(TS2D_ERR_INVALID, "image dimensions must be positive");
+    if (C > 65535 || (H + 15) / 16 > 65535) return fail(TS2D_ERR_INVALID, "image too large");
+    if (!image || !gt) return fail(TS2D_ERR_INVALID, "null image");
+    if (!ws || ws_bytes < ts_loss_workspace_bytes(C, H, W)) return fail(TS2D_ERR_CAPACITY, "loss workspace too small");
+    return TS2D_OK;
+}
+
+int tsl_photometric_forward(const float *image, const float *gt, int32_t channels, int32_t height, int32_t width, float w_l1,
+                            float w_ssim, int32_t need_grad, void *workspace, size_t workspace_bytes, float *out, void *stream)
+{
+    if (int rc = loss_args_ok(image, gt, channels, height, width, workspace, workspace_bytes)) return rc;
+    if (!out) return fail(TS2D_ERR_INVALID, "null output");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("photometric_fwd", s);
+    TS_HIP(ts_loss_forward(image, gt, channels, height, width, w_l1, w_ssim, need_grad != 0, workspace, out, s));
+    return TS2D_OK;
+}
+
+int tsl_photometric_backward(const float *image, const float *gt, int32_t channels, int32_t height, int32_t width, float w_l1,
+                             float w_ssim, const void *workspace, size_t workspace_bytes, const float *grad_out, float *dL_dimage,
+                             void *stream)
+{
+    if (int rc = loss_args_ok(image, gt, channels, height, width, workspace, workspace_bytes)) return rc;
+    if (!dL_dimage) return fail(TS2D_ERR_INVALID, "null output");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("photometric_bwd", s);
+    TS_HIP(ts_loss_backward(image, gt, channels, height, width, w_l1, w_ssim, workspace, grad_out, dL_dimage, s));
     return TS2D_OK;
 }
 

@@ -194,3 +194,10 @@ void ts_launch_render3d_bwd(const RenderArgs &a, float tan_fovx, float tan_fovy,
 // ---- factored SH-gradient exchange (multi-GPU, shgrad.hip) ---------------------------------------------------------
 void ts_launch_sh_grad_expand(int P, int D, int M, int V, const float *vertex, const float *campos, const float *dL_dcolor,
                               float *dL_dshs, hipStream_t s);
+
+// ---- fused photometric loss (photometric.hip, include/ts_loss.h) ----------------------------------------------------
+size_t ts_loss_workspace_bytes(int C, int H, int W);
+hipError_t ts_loss_forward(const float *image, const float *gt, int C, int H, int W, float w_l1, float w_ssim, bool need_grad,
+                           void *workspace, float *out, hipStream_t s);
+hipError_t ts_loss_backward(const float *image, const float *gt, int C, int H, int W, float w_l1, float w_ssim, const void *workspace,
+                            const float *grad_out, float *dL_dimage, hipStream_t s);

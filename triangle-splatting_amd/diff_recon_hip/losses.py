@@ -1,0 +1,118 @@
+"""Photometric losses backed by the fused HIP kernels of libts2d.so (include/ts_loss.h).
+
+Same call surface as the reference's `L1`, `SSIMLoss`, `ssimLoss` (src/diff_recon/trainers/trainer_utils.py:323-324, 96-103,
+349): `L1(t1, t2)` and `ssimLoss(img1, img2)` return 0-dim tensors and are differentiable with respect to their FIRST
+argument (the render; the ground truth never requires grad in the trainers).  Inputs of 2, 3 or 4 dimensions are accepted
+like `normalize_shape` (trainer_utils.py:80-93); a batch dimension folds into channels, which is what the reference's
+depthwise convolution + global mean computes.
+
+`PhotometricLoss(w_L1, w_ssim)(image, gt)` / `photometric_loss(image, gt, w_L1, w_ssim)` evaluate
+    w_L1 * L1(image, gt) + w_ssim * ssimLoss(image, gt)          (VanillaTS_trainer.py:80-81,111)
+in ONE forward launch (+ a one-block finisher) and ONE backward launch; the reference spends ~20 eager kernels on it.
+The maintainer-side change is three lines in VanillaTS_trainer.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+from torch import nn
+
+from diff_triangle_rasterization_2D import _C as _native
+
+_lib = _native._lib
+_fp = C.c_void_p
+_lib.tsl_workspace_bytes.restype = C.c_size_t
+_lib.tsl_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+_lib.tsl_photometric_forward.restype = C.c_int
+_lib.tsl_photometric_forward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, _fp,
+                                         C.c_size_t, _fp, _fp]
+_lib.tsl_photometric_backward.restype = C.c_int
+_lib.tsl_photometric_backward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_float, _fp, C.c_size_t,
+                                          _fp, _fp, _fp]
+
+
+def _chw(img1: torch.Tensor, img2: torch.Tensor):
+    """normalize_shape of the reference (trainer_utils.py:80-93), folded to (C, H, W)."""
+    if img1.size() != img2.size():
+        raise ValueError("Input images must have the same dimensions.")
+    if img1.dim() == 4:
+        c = img1.size(0) * img1.size(1)
+    elif img1.dim() == 3:
+        c = img1.size(0)
+    elif img1.dim() == 2:
+        c = 1
+    else:
+        raise ValueError("Input images must have 2, 3, or 4 dimensions.")
+    return c, img1.size(-2), img1.size(-1)
+
+
+def _check_inputs(image: torch.Tensor, gt: torch.Tensor):
+    if not image.is_cuda or not gt.is_cuda:
+        raise RuntimeError("the photometric loss (MI355X build) needs tensors on a HIP device; there is no CPU fallback")
+    if image.dtype != torch.float32 or gt.dtype != torch.float32:
+        raise RuntimeError("expected scalar type Float")
+
+
+class _Photometric(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, image, gt, w_l1, w_ssim):
+        c, h, w = _chw(image, gt)
+        _check_inputs(image, gt)
+        image_c, gt_c = image.contiguous(), gt.contiguous()
+        dev = image.device
+        need_grad = bool(image.requires_grad)
+        with torch.cuda.device(dev):
+            nbytes = _lib.tsl_workspace_bytes(c, h, w)
+            ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
+            out = torch.empty((3,), device=dev, dtype=torch.float32)
+            _native._check(_lib.tsl_photometric_forward(image_c.data_ptr(), gt_c.data_ptr(), c, h, w, float(w_l1), float(w_ssim),
+                                                        int(need_grad), ws.data_ptr(), nbytes, out.data_ptr(),
+                                                        torch.cuda.current_stream().cuda_stream), "photometric_loss")
+        ctx.dims = (c, h, w)
+        ctx.weights = (float(w_l1), float(w_ssim))
+        ctx.save_for_backward(image_c, gt_c, ws)
+        ctx.parts = out  # out[1] = L1, out[2] = 1 - SSIM (detached diagnostics)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        image, gt, ws = ctx.saved_tensors
+        c, h, w = ctx.dims
+        w_l1, w_ssim = ctx.weights
+        with torch.cuda.device(image.device):
+            g = torch.empty_like(image)
+            go = grad_out.contiguous().to(torch.float32)
+            _native._check(_lib.tsl_photometric_backward(image.data_ptr(), gt.data_ptr(), c, h, w, w_l1, w_ssim, ws.data_ptr(),
+                                                         ws.numel(), go.data_ptr(), g.data_ptr(),
+                                                         torch.cuda.current_stream().cuda_stream), "photometric_loss backward")
+        return g, None, None, None
+
+
+def photometric_loss(image: torch.Tensor, gt: torch.Tensor, w_L1: float, w_ssim: float) -> torch.Tensor:
+    """w_L1 * mean|image - gt| + w_ssim * (1 - SSIM(image, gt)), fused (VanillaTS_trainer.py:80-81,111)."""
+    return _Photometric.apply(image, gt, w_L1, w_ssim)
+
+
+def L1(t1: torch.Tensor, t2: torch.Tensor) -> torch.Tensor:
+    """trainer_utils.py:323-324 for image-shaped inputs (2-4 dims)."""
+    return _Photometric.apply(t1, t2, 1.0, 0.0)
+
+
+class SSIMLoss(nn.Module):
+    """trainer_utils.py:96-103: 1 - SSIM with the 11x11, sigma 1.5 Gaussian window and zero padding."""
+
+    def forward(self, img1: torch.Tensor, img2: torch.Tensor) -> torch.Tensor:
+        return _Photometric.apply(img1, img2, 0.0, 1.0)
+
+
+ssimLoss = SSIMLoss()  # trainer_utils.py:349
+
+
+class PhotometricLoss(nn.Module):
+    def __init__(self, w_L1: float, w_ssim: float):
+        super().__init__()
+        self.w_L1, self.w_ssim = float(w_L1), float(w_ssim)
+
+    def forward(self, image: torch.Tensor, gt_image: torch.Tensor) -> torch.Tensor:
+        return _Photometric.apply(image, gt_image, self.w_L1, self.w_ssim)

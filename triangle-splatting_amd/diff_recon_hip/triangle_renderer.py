@@ -1,0 +1,39 @@
+"""`TriangleRenderer` with the reference's constructor and `render` contract
+(src/diff_recon/renderer/triangle_renderer.py:15-95), on top of the HIP rasterizer packages.
+
+`cam` is duck-typed like the reference's `Camera` (src/diff_recon/utils/camera.py:70-117): it needs `image_width`,
+`image_height`, `tan_fovx`, `tan_fovy`, `world_view_transform`, `full_proj_transform`, `camera_center`, `device`."""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+_PACKAGES = {"2D": "diff_triangle_rasterization_2D", "3D": "diff_triangle_rasterization_3D"}
+
+
+class TriangleRenderer:
+    def __init__(self, cam, bg_depth: float = 5000.0, bg_color: torch.Tensor = torch.Tensor([0, 0, 0]),
+                 scaling_modifier: float = 1.0, sh_degree: int = 0, gamma: float = 1.0, back_culling: bool = False,
+                 rich_info: bool = False, debug: bool = False, rasterizer_type: str = "3D"):
+        if rasterizer_type not in _PACKAGES:  # reference :35-36
+            raise ValueError(f"Unknown rasterizer type: {rasterizer_type}. Use '2D' or '3D'.")
+        pkg = __import__(_PACKAGES[rasterizer_type])
+        settings = pkg.TriangleRasterizationSettings(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfovx=cam.tan_fovx,
+            tanfovy=cam.tan_fovy, viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+            campos=cam.camera_center, sh_degree=sh_degree, gamma=gamma, scale_modifier=scaling_modifier,
+            background_depth=bg_depth, background=bg_color.to(cam.device), back_culling=back_culling,
+            rich_info=rich_info, debug=debug)
+        self.cam = cam
+        self.rasterizer = pkg.TriangleRasterizer(raster_settings=settings)
+
+    def render(self, vertex: torch.Tensor, shs: Optional[torch.Tensor], color: Optional[torch.Tensor],
+               opacity: torch.Tensor) -> Dict[str, torch.Tensor]:
+        # gradient sink for the screen-space (2D) / view-space (3D) triangle centres, reference :67
+        center2D = torch.zeros((vertex.shape[0], 2), device=vertex.device, dtype=vertex.dtype, requires_grad=True)
+        out = self.rasterizer.forward(vertex=vertex, center2D=center2D, opacity=opacity, shs=shs, feature=color)
+        pkg = {"render": out[0], "radii": out[1], "center2D": center2D}
+        if self.rasterizer.raster_settings.rich_info:
+            pkg.update(depth=out[2], normal=out[3], contrib_sum=out[4], contrib_max=out[5])
+        return pkg
