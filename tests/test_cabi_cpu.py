@@ -9,6 +9,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "ts2d.h")
+HEADERS = [os.path.join(ROOT, "include", n) for n in sorted(os.listdir(os.path.join(ROOT, "include"))) if n.endswith(".h")]
 
 
 @pytest.fixture(scope="module")
@@ -17,16 +18,19 @@ def lib(hip_lib_built):
 
 
 def _declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(ts2d_[a-z0-9_]+)\s*\(", src)))
+    names = set()
+    for h in HEADERS:  # every header under include/: ts2d.h (rasterizer) and ts_loss.h (photometric loss)
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b((?:ts2d|tsl)_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_declares_the_expected_entry_points():
     names = _declared_functions()
     for must in ("ts2d_forward_bin", "ts2d_forward_render", "ts2d_backward", "ts2d_geometry_state_bytes",
                  "ts2d_binning_state_bytes", "ts2d_image_state_bytes", "ts2d_backward_scratch_bytes", "ts2d_last_error",
-                 "ts2d_version", "ts2d_debug_read_state"):
+                 "ts2d_version", "ts2d_debug_read_state", "ts2d_sh_grad_expand", "tsl_workspace_bytes",
+                 "tsl_photometric_forward", "tsl_photometric_backward"):
         assert must in names
 
 
