@@ -43,3 +43,23 @@ def test_batched_input_folds_into_channels():
     l4 = LO.photometric_loss(a, b, 0.8, 0.2)
     l3 = LO.photometric_loss(a.reshape(6, 16, 18), b.reshape(6, 16, 18), 0.8, 0.2)
     assert abs(l4[0] - l3[0]) < 1e-15 and np.array_equal(l4[3].reshape(6, 16, 18), l3[3])
+
+
+# ---- host logic of diff_recon_hip.model_forward (pure torch helpers; the render itself is covered by the GPU suite) ----
+def test_model_forward_helpers(hip_lib_built):
+    import torch
+    from diff_recon_hip import gamma_rescale_ratio, rescale_triangles, ste_opacity
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "gamma_rescale.npz"))
+    for gamma, ratio in zip(g["gamma"], g["ratio"]):  # fixture from the reference's formula evaluated with scipy
+        assert abs(gamma_rescale_ratio(float(gamma)) - float(ratio)) < 1e-12
+    v = torch.rand((5, 3, 3), dtype=torch.float64)
+    r = rescale_triangles(v, 0.5)
+    assert torch.allclose(r.mean(1), v.mean(1)) and torch.allclose(r - r.mean(1, keepdim=True), 0.5 * (v - v.mean(1, keepdim=True)))
+    rt = rescale_triangles(v, torch.full((5,), 2.0, dtype=torch.float64))
+    assert torch.allclose(rt - rt.mean(1, keepdim=True), 2.0 * (v - v.mean(1, keepdim=True)))
+    o = torch.tensor([[0.2], [0.7]], requires_grad=True)
+    s = ste_opacity(o, 0.5)
+    assert s.tolist() == [[0.0], [1.0]]
+    s.sum().backward()
+    assert o.grad.tolist() == [[1.0], [1.0]]  # straight-through

@@ -102,3 +102,58 @@ def test_triangle_renderer_shim():
         assert set(r2.render(t(s["vertex"]), t(s["shs"]), None, t(s["opacity"]))) == {"render", "radii", "center2D"}
     with pytest.raises(ValueError):
         TriangleRenderer(Cam, rasterizer_type="4D")
+
+
+def test_render_view_shim_matches_manual_pipeline():
+    """diff_recon_hip.render_view (VanillaTS_model.py:585-694): up-scaled render + bilinear resize, gamma rescale, STE
+    opacity and bg_depth must equal the same steps done by hand around the rasterizer package."""
+    import copy
+    import torch
+    import torch.nn.functional as F
+    import synthetic
+    from diff_recon_hip import TriangleRenderer, gamma_rescale_ratio, render_view
+
+    s = synthetic.scene(1500, 80, 48, 1, seed=12, max_degree=2)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    class Cam:
+        pass
+
+    cam = Cam()
+    cam.image_width, cam.image_height = 80, 48
+    cam.tan_fovx, cam.tan_fovy = s["tanfovx"], s["tanfovy"]
+    cam.world_view_transform, cam.full_proj_transform, cam.camera_center = t(s["viewmatrix"]), t(s["projmatrix"]), t(s["campos"])
+    cam.device = "cuda"
+    vertex = t(s["vertex"]).requires_grad_(True)
+    shs = t(s["shs"])
+    f_dc, f_rest = shs[:, :1].clone().requires_grad_(True), shs[:, 1:].clone().requires_grad_(True)
+    raw_op = torch.logit(t(s["opacity"]).clamp(0.02, 0.98)).requires_grad_(True)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+    kw = dict(bg_color=bg, gamma=2.0, active_sh_degree=1, max_sh_degree=2, gamma_rescale=True, ste_threshold=0.3,
+              render_up_scale=2, rasterizer_type="2D")
+    pkg = render_view(cam, vertex, f_dc, f_rest, raw_op, is_training=True, **kw)
+    assert pkg["render"].shape == (3, 48, 80) and pkg["depth"].shape == (48, 80) and pkg["normal"].shape == (3, 48, 80)
+    assert set(pkg) == {"render", "radii", "center2D", "contrib_sum", "contrib_max", "depth", "normal", "opacity", "vertex",
+                        "visible_mask"}
+    # by hand
+    op = torch.sigmoid(raw_op)
+    ratio = gamma_rescale_ratio(2.0)
+    c = vertex.mean(1, keepdim=True)
+    v2 = (vertex - c) * ratio + c
+    o2 = ((op > 0.3).float() - op).detach() + op
+    cam2 = copy.copy(cam)
+    cam2.image_width, cam2.image_height = 160, 96
+    bgd = (cam.camera_center.view(1, 1, 3) - vertex).norm(dim=-1).max()
+    r = TriangleRenderer(cam2, bg_depth=bgd, bg_color=bg, sh_degree=1, gamma=2.0, rich_info=True, rasterizer_type="2D")
+    out = r.render(v2, torch.cat((f_dc, f_rest), 1), None, o2)
+    want = F.interpolate(out["render"].unsqueeze(0), size=(48, 80), mode="bilinear").squeeze(0)
+    assert helpers.rel_l2(pkg["render"].detach().cpu().numpy(), want.detach().cpu().numpy()) < 1e-6
+    assert torch.equal(pkg["radii"], out["radii"] // 2)
+    # gradients flow to the model tensors through rescale / STE / sigmoid and to center2D
+    pkg["render"].sum().backward()
+    assert vertex.grad.abs().sum() > 0 and raw_op.grad.abs().sum() > 0 and f_dc.grad.abs().sum() > 0
+    assert f_rest.grad[:, 3:].abs().sum() == 0  # coefficients above the active degree receive exact zeros
+    assert pkg["center2D"].grad is not None
+    # evaluation mode: 2-tuple path, only the image
+    ev = render_view(cam, vertex, f_dc, f_rest, raw_op, is_training=False, **kw)
+    assert set(ev) == {"render"}

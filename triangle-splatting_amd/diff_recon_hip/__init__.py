@@ -4,8 +4,11 @@
                           (reference: src/diff_recon/trainers/trainer_utils.py:9-103, 323-324, 349;
                            combined as in src/diff_recon/trainers/VanillaTS_trainer.py:80-81,111)
     triangle_renderer.py  TriangleRenderer (reference: src/diff_recon/renderer/triangle_renderer.py:15-95)
+    model_forward.py      render_view = the argument construction of VanillaTSModel.forward
+                          (reference: src/diff_recon/models/VanillaTS_model.py:585-694)
 
 Native code: libts2d.so (include/ts_loss.h, include/ts2d.h).  No CPU / eager fallback anywhere.
 """
 from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss  # noqa: F401
 from .triangle_renderer import TriangleRenderer  # noqa: F401
+from .model_forward import gamma_rescale_ratio, rescale_triangles, ste_opacity, render_view  # noqa: F401

@@ -1,0 +1,76 @@
+"""Argument construction of the reference model's render call, restated for the HIP rasterizer
+(src/diff_recon/models/VanillaTS_model.py:585-694, "VanillaTSModel.forward").
+
+`render_view` takes the model's tensors explicitly (the reference model class, its config system and logger are out of
+scope) and performs, in the reference's order:
+  * shs = cat(f_dc, f_rest) (:79-80), opacity = sigmoid(raw) (:83-84);
+  * gamma rescale of every triangle about its centroid by 1 / sqrt(2^b b Gamma(b)), b = 1 / gamma (:614-618, :445-446);
+  * straight-through binarised opacity (:620-621);
+  * bg_depth = max |camera_center - vertex| (:623; stays a 0-dim device tensor, converted by the rasterizer package);
+  * render_up_scale: render at s x resolution, bilinear resize of render / depth / normal back, radii // s (:625-659);
+  * rich_info = is_training, sh_degree = min(active, max) (:639-641).
+"""
+from __future__ import annotations
+
+import copy
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .triangle_renderer import TriangleRenderer
+
+
+def gamma_rescale_ratio(gamma: float) -> float:
+    """VanillaTS_model.py:615-617 (scipy.special.gamma == math.gamma for positive reals)."""
+    beta = 1.0 / gamma
+    return 1.0 / math.sqrt(2.0 ** beta * beta * math.gamma(beta))
+
+
+def rescale_triangles(vertex: torch.Tensor, ratio) -> torch.Tensor:
+    """VanillaTS_model.py:441-447: scale each triangle about its centroid; `ratio` float or (P,) tensor."""
+    if isinstance(ratio, torch.Tensor):
+        assert ratio.dim() == 1 and ratio.size(0) == vertex.size(0)
+        ratio = ratio.unsqueeze(1).unsqueeze(1)
+    center = vertex.mean(dim=1, keepdim=True)
+    return (vertex - center) * ratio + center
+
+
+def ste_opacity(opacity: torch.Tensor, threshold: float) -> torch.Tensor:
+    """VanillaTS_model.py:621: forward = hard threshold, backward = identity."""
+    return ((opacity > threshold).float() - opacity).detach() + opacity
+
+
+def render_view(camera, vertex: torch.Tensor, f_dc: torch.Tensor, f_rest: torch.Tensor, raw_opacity: torch.Tensor, *,
+                bg_color: torch.Tensor, gamma: float = 1.0, active_sh_degree: int = 0, max_sh_degree: int = 3,
+                is_training: bool = True, back_culling: bool = False, gamma_rescale: bool = False,
+                ste_threshold: Optional[float] = None, render_up_scale: Optional[int] = None,
+                rasterizer_type: str = "3D") -> Dict[str, torch.Tensor]:
+    shs = torch.cat((f_dc, f_rest), dim=1)
+    opacity = torch.sigmoid(raw_opacity)
+    v_render = rescale_triangles(vertex, gamma_rescale_ratio(gamma)) if gamma_rescale else vertex
+    o_render = ste_opacity(opacity, ste_threshold) if ste_threshold is not None else opacity
+    bg_depth = (camera.camera_center.view(1, 1, 3) - vertex).norm(dim=-1).max()
+
+    w, h = camera.image_width, camera.image_height
+    up = int(render_up_scale) if render_up_scale and render_up_scale > 1 else 1
+    if up > 1:
+        camera = copy.copy(camera)
+        camera.image_width, camera.image_height = w * up, h * up
+
+    renderer = TriangleRenderer(camera, bg_depth=bg_depth, bg_color=bg_color, sh_degree=min(active_sh_degree, max_sh_degree),
+                                gamma=gamma, back_culling=back_culling, rich_info=is_training, rasterizer_type=rasterizer_type)
+    out = renderer.render(v_render, shs, None, o_render)
+    if up > 1:
+        out["render"] = F.interpolate(out["render"].unsqueeze(0), size=(h, w), mode="bilinear").squeeze(0)
+        out["radii"] = out["radii"] // up
+        if "depth" in out:
+            out["depth"] = F.interpolate(out["depth"].unsqueeze(0).unsqueeze(0), size=(h, w), mode="bilinear").squeeze(0).squeeze(0)
+        if "normal" in out:
+            out["normal"] = F.interpolate(out["normal"].unsqueeze(0), size=(h, w), mode="bilinear").squeeze(0)
+    pkg = {"render": out["render"]}
+    if is_training:  # :664-679
+        pkg.update(radii=out["radii"], center2D=out["center2D"], contrib_sum=out["contrib_sum"], contrib_max=out["contrib_max"],
+                   depth=out["depth"], normal=out["normal"], opacity=opacity, vertex=vertex, visible_mask=out["radii"] > 0)
+    return pkg
