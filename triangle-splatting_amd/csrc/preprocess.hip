@@ -12,17 +12,16 @@
 #include "ts2d_common.h"
 #include "ts2d_math.h"
 #include "ts2d_sh.h"
+#include "ts2d_stage.h"
 
 using namespace ts;
 
 namespace
 {
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a, int32_t *__restrict__ radii,
-                                                              GeometryStateView g)
+// One triangle.  `vp` = its 9 vertex floats, `shp` = its SH row (3 M floats); either global memory or an LDS row.
+__device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int32_t *__restrict__ radii, const GeometryStateView &g,
+                                                   int idx, const float *vp, const float *shp)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-
     int out_radius = 0;
     uint32_t out_tiles = 0;
     uint2 out_rect = {0u, 0u};
@@ -32,7 +31,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a, i
 #pragma unroll
     for (int i = 0; i < TS_REC_FLOATS; i++) rec[i] = 0.0f;
 
-    const float *vp = a.vertex + 9 * (size_t)idx;
     const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
     const f3 center = divf(add(add(v1, v2), v3), 3.0f);
     const f3 center_proj = project_point(center, a.projmatrix);
@@ -88,7 +86,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a, i
         if (a.use_shs)
         {
             const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
-            rgb = sh_to_rgb(a.D, a.shs + (size_t)idx * a.M * 3, center, cp);
+            rgb = sh_to_rgb(a.D, shp, center, cp);
             out_clamped = (uint8_t)((rgb.x < 0 ? 1 : 0) | (rgb.y < 0 ? 2 : 0) | (rgb.z < 0 ? 4 : 0)); // forward.cu:55-57
             rgb = {fmaxf(rgb.x, 0.0f), fmaxf(rgb.y, 0.0f), fmaxf(rgb.z, 0.0f)};
         }
@@ -128,6 +126,29 @@ __global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a, i
     r[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
 }
 
+// direct version: any alignment, any M
+__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    preprocess_fwd_one(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
+}
+
+// staged version (ts2d_stage.h): single-wave workgroups, vertex rows always staged, SH rows staged when SHROW = 3 M > 0
+template <int SHROW>
+__global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
+{
+    __shared__ float s_v[64 * 9];
+    __shared__ float s_sh[SHROW > 0 ? 64 * (SHROW + 1) : 1];
+    const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
+    stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
+    if (SHROW > 0) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
+    __syncthreads();
+    if (idx >= a.P) return;
+    const float *shp = SHROW > 0 ? s_sh + lane * (SHROW + 1) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
+    preprocess_fwd_one(a, radii, g, idx, s_v + lane * 9, shp);
+}
+
 // backward.cu:131-142
 __device__ __forceinline__ void project_vec_approx_bwd(f3 p, f3 v, float tx, float ty, f2 dL_dvec_proj, f3 &dL_dp, f3 &dL_dv)
 {
@@ -138,16 +159,14 @@ __device__ __forceinline__ void project_vec_approx_bwd(f3 p, f3 v, float tx, flo
     dL_dp = {-d.x * vz_pz, -d.y * vz_pz, d.x * (2.0f * vz_pz * px_pz - vx_pz) + d.y * (2.0f * vz_pz * py_pz - vy_pz)};
 }
 
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, const int32_t *__restrict__ radii,
-                                                              GeometryStateView g, const float *__restrict__ grad_rec,
-                                                              float *__restrict__ dL_dvertex, float *__restrict__ dL_dcenter2D,
-                                                              float *__restrict__ dL_dshs, float *__restrict__ dL_dfeature,
-                                                              float *__restrict__ dL_dopacity)
+// One triangle.  `vp` / `shp`: its vertex and SH rows (global or LDS); `ov` (9 floats) and `osh` (3 M floats, may be null):
+// where dL_dvertex / dL_dshs of this triangle go (global or LDS rows that the caller flushes).
+__device__ __forceinline__ void preprocess_bwd_one(const PreprocessArgs &a, const int32_t *__restrict__ radii,
+                                                   const GeometryStateView &g, const float *__restrict__ grad_rec, int idx,
+                                                   const float *vp, const float *shp, float *ov, float *osh,
+                                                   float *__restrict__ dL_dcenter2D, float *__restrict__ dL_dfeature,
+                                                   float *__restrict__ dL_dopacity)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-
-    float *ov = dL_dvertex + 9 * (size_t)idx;
     float *oc = dL_dcenter2D + 2 * (size_t)idx;
     if (radii[idx] <= 0) // backward.cu:165; the reference leaves zero-initialised outputs for these
     {
@@ -156,8 +175,8 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, c
         oc[0] = 0.0f; oc[1] = 0.0f;
         dL_dopacity[idx] = 0.0f;
         for (int c = 0; c < a.C; c++) dL_dfeature[(size_t)idx * a.C + c] = 0.0f;
-        if (a.use_shs && dL_dshs)
-            for (int k = 0; k < a.M * 3; k++) dL_dshs[(size_t)idx * a.M * 3 + k] = 0.0f;
+        if (a.use_shs && osh)
+            for (int k = 0; k < a.M * 3; k++) osh[k] = 0.0f;
         return;
     }
 
@@ -169,7 +188,6 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, c
     const f3 dL_dnormal_view = {g2.z, g2.w, g3.x};
     const f3 dL_dv_depth = {g3.y, g3.z, g3.w};
 
-    const float *vp = a.vertex + 9 * (size_t)idx;
     const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
     const f3 center = divf(add(add(v1, v2), v3), 3.0f);
     const f3 center_view = xform_point_4x3(center, a.viewmatrix);
@@ -237,9 +255,10 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, c
         dL_dRGB.y *= (cl & 2) ? 0.0f : 1.0f;
         dL_dRGB.z *= (cl & 4) ? 0.0f : 1.0f;
         const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
-        const f3 dsh = sh_backward(a.D, a.M, a.shs + (size_t)idx * a.M * 3, center, cp, dL_dRGB,
-                                   dL_dshs ? dL_dshs + (size_t)idx * a.M * 3 : nullptr);
-        if (!dL_dshs) dL_drgb = dL_dRGB; // factored exchange (TS2D_FLAG_SH_FACTORED): hand out the clamp-masked colour gradient
+        // when osh aliases shp (LDS row, staged kernel) the coefficients must be consumed before the gradients are written
+        const f3 dsh = sh_backward(a.D, a.M, shp, center, cp, dL_dRGB, nullptr);
+        if (osh) sh_grad_store(a.D, a.M, center, cp, dL_dRGB, osh);
+        if (!osh) dL_drgb = dL_dRGB; // factored exchange (TS2D_FLAG_SH_FACTORED): hand out the clamp-masked colour gradient
         dL_dcenter = add(dL_dcenter, dsh);
     }
 
@@ -257,19 +276,115 @@ __global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, c
     if (a.C > 1) of[1] = dL_drgb.y;
     if (a.C > 2) of[2] = dL_drgb.z;
 }
+
+__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, const int32_t *__restrict__ radii,
+                                                              GeometryStateView g, const float *__restrict__ grad_rec,
+                                                              float *__restrict__ dL_dvertex, float *__restrict__ dL_dcenter2D,
+                                                              float *__restrict__ dL_dshs, float *__restrict__ dL_dfeature,
+                                                              float *__restrict__ dL_dopacity)
+{
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= a.P) return;
+    preprocess_bwd_one(a, radii, g, grad_rec, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr,
+                       dL_dvertex + 9 * (size_t)idx, dL_dshs ? dL_dshs + (size_t)idx * a.M * 3 : nullptr, dL_dcenter2D,
+                       dL_dfeature, dL_dopacity);
+}
+
+// staged version: SHROW = 3 M > 0 stages the SH rows in AND the dL_dshs rows out through the same LDS rows
+template <int SHROW, bool SH_IN, bool WRITE_SH>
+__global__ void __launch_bounds__(64) preprocess_bwd_staged_kernel(PreprocessArgs a, const int32_t *__restrict__ radii,
+                                                                    GeometryStateView g, const float *__restrict__ grad_rec,
+                                                                    float *__restrict__ dL_dvertex, float *__restrict__ dL_dcenter2D,
+                                                                    float *__restrict__ dL_dshs, float *__restrict__ dL_dfeature,
+                                                                    float *__restrict__ dL_dopacity)
+{
+    __shared__ float s_v[64 * 9];
+    __shared__ float s_sh[SHROW > 0 ? 64 * (SHROW + 1) : 1];
+    const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
+    stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
+    if (SHROW > 0 && SH_IN) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
+    __syncthreads();
+    if (idx < a.P)
+    {
+        float *row = SHROW > 0 ? s_sh + lane * (SHROW + 1) : nullptr;
+        const float *shp = (SHROW > 0 && SH_IN) ? row : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
+        preprocess_bwd_one(a, radii, g, grad_rec, idx, s_v + lane * 9, shp, s_v + lane * 9, WRITE_SH ? row : nullptr, dL_dcenter2D,
+                           dL_dfeature, dL_dopacity);
+    }
+    __syncthreads();
+    stage_rows_out<9, 9>(s_v, dL_dvertex, row0, a.P, lane);
+    if (SHROW > 0 && WRITE_SH) stage_rows_out<SHROW, SHROW + 1>(s_sh, dL_dshs, row0, a.P, lane);
+}
 } // namespace
+
+// Staging policy: vertex rows whenever the pointers are 16-byte aligned; SH rows in when at least half of each row is
+// active (otherwise the direct strided read of the active prefix moves fewer bytes); dL_dshs rows out always (every
+// element is written).
+static int staged_shrow(const PreprocessArgs &a) { return (a.use_shs && (a.M == 1 || a.M == 4 || a.M == 9 || a.M == 16)) ? 3 * a.M : 0; }
 
 void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s)
 {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g);
+    const int shrow = staged_shrow(a);
+    const bool sh_in = shrow > 0 && 2 * (a.D + 1) * (a.D + 1) >= a.M && aligned16(a.shs);
+    if (!aligned16(a.vertex))
+    {
+        hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g);
+        return;
+    }
+    const dim3 grid((a.P + 63) / 64), block(64);
+    switch (sh_in ? shrow : 0)
+    {
+    case 48: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<48>, grid, block, 0, s, a, radii, g); break;
+    case 27: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<27>, grid, block, 0, s, a, radii, g); break;
+    case 12: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<12>, grid, block, 0, s, a, radii, g); break;
+    case 3: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<3>, grid, block, 0, s, a, radii, g); break;
+    default: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<0>, grid, block, 0, s, a, radii, g); break;
+    }
 }
+
+#define TS_BWD_STAGED(SHROW, SH_IN, WRITE_SH)                                                                          \
+    hipLaunchKernelGGL((preprocess_bwd_staged_kernel<SHROW, SH_IN, WRITE_SH>), grid, block, 0, s, a, radii, g, grad_rec, \
+                       dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity)
 
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                               float *dL_dfeature, float *dL_dopacity, hipStream_t s)
 {
     if (a.P <= 0) return;
-    hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g, grad_rec,
-                       dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity);
+    const int shrow = staged_shrow(a);
+    const bool write_sh = a.use_shs && dL_dshs != nullptr;
+    const bool ok = aligned16(a.vertex) && aligned16(dL_dvertex) && (!a.use_shs || aligned16(a.shs)) &&
+                    (!write_sh || aligned16(dL_dshs));
+    if (!ok)
+    {
+        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g, grad_rec,
+                           dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity);
+        return;
+    }
+    const dim3 grid((a.P + 63) / 64), block(64);
+    const bool sh_in = shrow > 0 && 2 * (a.D + 1) * (a.D + 1) >= a.M;
+    // the LDS rows exist when they carry something: SH in, dL_dshs out, or both
+    const int rows = (sh_in || write_sh) ? shrow : 0;
+    switch (rows)
+    {
+    case 48:
+        if (sh_in && write_sh) TS_BWD_STAGED(48, true, true); else if (sh_in) TS_BWD_STAGED(48, true, false); else TS_BWD_STAGED(48, false, true);
+        break;
+    case 27:
+        if (sh_in && write_sh) TS_BWD_STAGED(27, true, true); else if (sh_in) TS_BWD_STAGED(27, true, false); else TS_BWD_STAGED(27, false, true);
+        break;
+    case 12:
+        if (sh_in && write_sh) TS_BWD_STAGED(12, true, true); else if (sh_in) TS_BWD_STAGED(12, true, false); else TS_BWD_STAGED(12, false, true);
+        break;
+    case 3:
+        if (sh_in && write_sh) TS_BWD_STAGED(3, true, true); else if (sh_in) TS_BWD_STAGED(3, true, false); else TS_BWD_STAGED(3, false, true);
+        break;
+    default:
+        if (write_sh) // M outside {1,4,9,16}: only the vertex rows are staged, dL_dshs written directly
+            hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g, grad_rec, dL_dvertex,
+                               dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity);
+        else TS_BWD_STAGED(0, false, false);
+        break;
+    }
 }

@@ -64,6 +64,19 @@ __device__ __forceinline__ int sh_basis(int deg, f3 dir, float *b)
     return 16;
 }
 
+// dL_dsh[k] = basis_k * dL_dRGB for the active coefficients, zeros above (backward.cu:20-85).
+__device__ __forceinline__ void sh_grad_store(int deg, int M, f3 pos, f3 campos, f3 dL_dRGB, float *dL_dsh)
+{
+    const f3 dir_orig = sub(pos, campos);
+    const f3 dir = divf(dir_orig, norm(dir_orig));
+    float b[16];
+    const int written = sh_basis(deg, dir, b);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+        if (k < written) st3(dL_dsh + 3 * k, scale(b[k], dL_dRGB));
+    for (int k = written * 3; k < M * 3; k++) dL_dsh[k] = 0.0f;
+}
+
 // backward.cu:9-119.  Writes all M coefficient gradients (zeros above the active degree) unless dL_dsh is null (the
 // factored multi-GPU exchange rebuilds them from dL_dRGB, see shgrad.hip).  Returns dL/d(pos).
 __device__ __forceinline__ f3 sh_backward(int deg, int M, const float *sh, f3 pos, f3 campos, f3 dL_dRGB, float *dL_dsh)
@@ -72,15 +85,7 @@ __device__ __forceinline__ f3 sh_backward(int deg, int M, const float *sh, f3 po
     const f3 dir = divf(dir_orig, norm(dir_orig));
     f3 dRGBdx = {0, 0, 0}, dRGBdy = {0, 0, 0}, dRGBdz = {0, 0, 0};
     const float x = dir.x, y = dir.y, z = dir.z;
-    if (dL_dsh)
-    {
-        float b[16];
-        const int written = sh_basis(deg, dir, b);
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (k < written) st3(dL_dsh + 3 * k, scale(b[k], dL_dRGB));
-        for (int k = written * 3; k < M * 3; k++) dL_dsh[k] = 0.0f;
-    }
+    if (dL_dsh) sh_grad_store(deg, M, pos, campos, dL_dRGB, dL_dsh);
     if (deg > 0)
     {
         dRGBdx = scale(-SH_C1, ld3(sh + 9));
