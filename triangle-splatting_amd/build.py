@@ -25,6 +25,7 @@ ARCH = "gfx950"
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
           "-Wno-unused-result", "-DNDEBUG"]
+COMMON += os.environ.get("TS2D_EXTRA_FLAGS", "").split()  # profiling builds: -DTS2D_ABLATION, -DTS2D_STATS (use --force)
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
     "preprocess3d.hip": ["-ffp-contract=off"],

@@ -122,6 +122,17 @@ __device__ __forceinline__ void publish_entry_fwd(float *row, const EntrySetup &
     if (RICH) q[3] = make_float4(r3.x, r3.y, r3.z, r3.w);
 }
 
+#ifdef TS2D_STATS
+// Profiling builds only (-DTS2D_STATS): culling / occupancy statistics of render_fwd, read with ts2d_stats_read().
+// [0] list entries visited  [1] entries surviving the setup cull  [2] entries with a stage-1 hit  [3] entries blended
+// [4] (pixel, entry) pairs blended  [5] quadrants (waves)  [6] / [7] iterations if the four 4x4 blocks / two 8x4 halves of a
+// quadrant walked their own blended entries in lockstep (sum over batches of the per-group maximum)
+__device__ unsigned long long g_stats[8];
+#define TS_STAT(i, v) st[i] += (unsigned long long)(v)
+#else
+#define TS_STAT(i, v)
+#endif
+
 template <bool RICH, bool GAMMA1>
 __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                           const uint32_t *__restrict__ point_list,
@@ -180,12 +191,16 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
         staged = 0;
     };
 
+#ifdef TS2D_STATS
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 1, 0, 0};
+#endif
     unsigned long long alive = __ballot(!done); // pixels that still blend (wave-uniform copy of !done)
     for (int base = 0; base < len; base += 64)
     {
         if (alive == 0) break;
         const int k = base + lane;
         const bool valid = k < len;
+        TS_STAT(0, __popcll(__ballot(valid)));
         uint32_t id = 0;
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
         if (valid)
@@ -197,8 +212,12 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
         }
         const EntrySetup s = entry_setup<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
         unsigned long long mask = __ballot(valid && s.overlap);
+        TS_STAT(1, __popcll(mask));
         if (mask == 0) continue;
         publish_entry_fwd<RICH>(cst + lane * CSTF, s, r1, r2, r3);
+#ifdef TS2D_STATS
+        int cg4[4] = {0, 0, 0, 0}, cg2[2] = {0, 0};
+#endif
 
         while (mask)
         {
@@ -211,6 +230,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
             const float ecc = 1.0f - 3.0f * fminf(fminf(a1, a2), a3);
             bool hit = !done && ecc >= 0.0f && ecc <= 10.0f; // forward.cu:307
             if (__ballot(hit) == 0) continue;
+            TS_STAT(2, 1);
             const float4 c2 = *(const float4 *)(cst + jc * CSTF + 8);
             float4 c3 = make_float4(0, 0, 0, 0);
             if (RICH) c3 = *(const float4 *)(cst + jc * CSTF + 12);
@@ -218,6 +238,20 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
             const float alpha = fminf(0.99f, c1.z * fast_exp(-0.5f * pw)); // forward.cu:311-312
             hit = hit && alpha >= 1.0f / 255.0f;                           // forward.cu:313
             if (__ballot(hit) == 0) continue;
+            TS_STAT(3, 1);
+            TS_STAT(4, __popcll(__ballot(hit)));
+#ifdef TS2D_STATS
+            {
+                const unsigned long long hb = __ballot(hit);
+                // lanes are ly * 8 + lx: 4x4 blocks and 8x4 halves of the quadrant
+                if (hb & 0x000000000F0F0F0Full) cg4[0]++;
+                if (hb & 0x00000000F0F0F0F0ull) cg4[1]++;
+                if (hb & 0x0F0F0F0F00000000ull) cg4[2]++;
+                if (hb & 0xF0F0F0F000000000ull) cg4[3]++;
+                if (hb & 0x00000000FFFFFFFFull) cg2[0]++;
+                if (hb & 0xFFFFFFFF00000000ull) cg2[1]++;
+            }
+#endif
             // Branch-free blend: lanes that do not hit run with alpha = 0, which leaves every accumulator and T
             // bit-unchanged (x + c*0 == x, T*1 == T).
             const float al = hit ? alpha : 0.0f;
@@ -249,8 +283,16 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
                 base = len; // leave both loops
             }
         }
+#ifdef TS2D_STATS
+        st[6] += (unsigned long long)max(max(cg4[0], cg4[1]), max(cg4[2], cg4[3]));
+        st[7] += (unsigned long long)max(cg2[0], cg2[1]);
+#endif
     }
     if (RICH && staged > 0) flush();
+#ifdef TS2D_STATS
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_stats[i], st[i]);
+#endif
 
     if (inside)
     {
@@ -528,3 +570,16 @@ void ts_launch_render_bwd(const RenderArgs &a, const GeometryStateView &g, const
     TS_DISPATCH(render_bwd_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature,
                 dL_dout_depth, dL_dout_normal, grad_rec);
 }
+
+#ifdef TS2D_STATS
+extern "C" int ts2d_stats_read(unsigned long long *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset)
+    {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : 2;
+}
+#endif
