@@ -31,6 +31,7 @@ SOURCES = {
     "preprocess3d.hip": ["-ffp-contract=off"],
     "shgrad.hip": ["-ffp-contract=off"],
     "photometric.hip": [],
+    "knn.hip": [],
     "binning.hip": [],
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
@@ -38,7 +39,8 @@ SOURCES = {
     "api.hip": [],
 }
 HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", "ts2d_stage.h", os.path.join("..", "..", "include", "ts2d.h"),
-           os.path.join("..", "..", "include", "ts_loss.h")]
+           os.path.join("..", "..", "include", "ts_loss.h"),
+           os.path.join("..", "..", "include", "ts_knn.h")]
 
 
 def hipcc() -> str:

@@ -7,6 +7,7 @@
 // zero-filled scratch of the backward is one 64-byte-per-triangle gradient record array.
 #include "../../include/ts2d.h"
 #include "../../include/ts_loss.h"
+#include "../../include/ts_knn.h"
 #include "ts2d_common.h"
 
 #include <cstdarg>
@@ -389,6 +390,36 @@ int tsl_photometric_backward(const float *image, const float *gt, int32_t channe
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("photometric_bwd", s);
     TS_HIP(ts_loss_backward(image, gt, channels, height, width, w_l1, w_ssim, workspace, grad_out, dL_dimage, s));
+    return TS2D_OK;
+}
+
+// ---- include/ts_knn.h -------------------------------------------------------------------------------------------------
+size_t tsk_workspace_bytes(int32_t P) { return ts_knn_workspace_bytes(P); }
+
+int tsk_mean_dist3(int32_t P, const float *points, float *mean_dist2, void *workspace, size_t workspace_bytes, void *stream)
+{
+    if (P < 0) return fail(TS2D_ERR_INVALID, "P must be >= 0");
+    if (P == 0) return TS2D_OK;
+    if (!points || !mean_dist2) return fail(TS2D_ERR_INVALID, "null pointer");
+    if (!workspace || workspace_bytes < ts_knn_workspace_bytes(P)) return fail(TS2D_ERR_CAPACITY, "knn workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("knn_mean_dist3", s);
+    TS_HIP(ts_knn_mean_dist3(P, points, mean_dist2, workspace, s));
+    return TS2D_OK;
+}
+
+int tsk_nearest_other(int32_t P, int32_t batch_size, const float *points, uint32_t *nearest, void *workspace,
+                      size_t workspace_bytes, void *stream)
+{
+    if (P < 0) return fail(TS2D_ERR_INVALID, "P must be >= 0");
+    if (batch_size <= 0) return fail(TS2D_ERR_INVALID, "batch_size must be greater than 0"); // interface.cu:30-33
+    if (P % batch_size != 0) return fail(TS2D_ERR_INVALID, "num_points % batch_size must be 0");
+    if (P == 0) return TS2D_OK;
+    if (!points || !nearest) return fail(TS2D_ERR_INVALID, "null pointer");
+    if (!workspace || workspace_bytes < ts_knn_workspace_bytes(P)) return fail(TS2D_ERR_CAPACITY, "knn workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("knn_nearest_other", s);
+    TS_HIP(ts_knn_nearest_other(P, batch_size, points, nearest, workspace, s));
     return TS2D_OK;
 }
 

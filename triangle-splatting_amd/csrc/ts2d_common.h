@@ -201,3 +201,8 @@ hipError_t ts_loss_forward(const float *image, const float *gt, int C, int H, in
                            void *workspace, float *out, hipStream_t s);
 hipError_t ts_loss_backward(const float *image, const float *gt, int C, int H, int W, float w_l1, float w_ssim, const void *workspace,
                             const float *grad_out, float *dL_dimage, hipStream_t s);
+
+// ---- exact nearest-neighbour helpers (knn.hip, include/ts_knn.h) -------------------------------------------------------
+size_t ts_knn_workspace_bytes(int P);
+hipError_t ts_knn_mean_dist3(int P, const float *points, float *mean_dist2, void *ws, hipStream_t s);
+hipError_t ts_knn_nearest_other(int P, int group, const float *points, uint32_t *nearest, void *ws, hipStream_t s);
