@@ -32,6 +32,7 @@ SOURCES = {
     "shgrad.hip": ["-ffp-contract=off"],
     "photometric.hip": [],
     "knn.hip": [],
+    "model_update.hip": [],
     "binning.hip": [],
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
@@ -40,7 +41,8 @@ SOURCES = {
 }
 HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", "ts2d_stage.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
-           os.path.join("..", "..", "include", "ts_knn.h")]
+           os.path.join("..", "..", "include", "ts_knn.h"),
+           os.path.join("..", "..", "include", "ts_model.h")]
 
 
 def hipcc() -> str:

@@ -8,6 +8,7 @@
 #include "../../include/ts2d.h"
 #include "../../include/ts_loss.h"
 #include "../../include/ts_knn.h"
+#include "../../include/ts_model.h"
 #include "ts2d_common.h"
 
 #include <cstdarg>
@@ -420,6 +421,24 @@ int tsk_nearest_other(int32_t P, int32_t batch_size, const float *points, uint32
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("knn_nearest_other", s);
     TS_HIP(ts_knn_nearest_other(P, batch_size, points, nearest, workspace, s));
+    return TS2D_OK;
+}
+
+// ---- include/ts_model.h -----------------------------------------------------------------------------------------------
+int tsm_training_statistic(int32_t P, int32_t num_views, const int32_t *radii, const float *center2D_grad, const float *contrib_sum,
+                           const float *contrib_max, float *gradient_accum, float *gradient_denom, float *max_radii2D,
+                           float *contrib_sum_state, float *contrib_max_state, float *contrib_denom, void *stream)
+{
+    if (P < 0 || num_views < 0) return fail(TS2D_ERR_INVALID, "P / num_views must be >= 0");
+    if (P == 0 || num_views == 0) return TS2D_OK;
+    if (!radii || !center2D_grad || !gradient_accum || !gradient_denom || !max_radii2D || !contrib_denom)
+        return fail(TS2D_ERR_INVALID, "null pointer");
+    if ((contrib_sum == nullptr) != (contrib_max == nullptr)) return fail(TS2D_ERR_INVALID, "contrib_sum and contrib_max go together");
+    if (contrib_sum && (!contrib_sum_state || !contrib_max_state)) return fail(TS2D_ERR_INVALID, "null contribution state");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("training_statistic", s);
+    TS_HIP(ts_model_training_statistic(P, num_views, radii, center2D_grad, contrib_sum, contrib_max, gradient_accum, gradient_denom,
+                                       max_radii2D, contrib_sum_state, contrib_max_state, contrib_denom, s));
     return TS2D_OK;
 }
 

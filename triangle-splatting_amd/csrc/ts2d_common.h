@@ -206,3 +206,8 @@ hipError_t ts_loss_backward(const float *image, const float *gt, int C, int H, i
 size_t ts_knn_workspace_bytes(int P);
 hipError_t ts_knn_mean_dist3(int P, const float *points, float *mean_dist2, void *ws, hipStream_t s);
 hipError_t ts_knn_nearest_other(int P, int group, const float *points, uint32_t *nearest, void *ws, hipStream_t s);
+
+// ---- per-iteration model-update statistics (model_update.hip, include/ts_model.h) --------------------------------------
+hipError_t ts_model_training_statistic(int P, int V, const int32_t *radii, const float *c2d_grad, const float *csum, const float *cmax,
+                                       float *g_accum, float *g_denom, float *max_radii, float *s_csum, float *s_cmax, float *c_denom,
+                                       hipStream_t s);
