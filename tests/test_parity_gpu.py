@@ -158,15 +158,28 @@ def test_nothing_visible():
     assert np.all(hf["dL_dvertex"] == 0)
 
 
-def test_full_size_properties():
-    """BASELINE.json's headline size (1M triangles, 1920x1080, SH 3) is too slow for the oracle inside a unit test;
-    check size-independent properties instead: sortedness of the instance list, exact tile ranges, colour bounds,
-    transmittance identity (sum of contributions + T_final == 1 via a unit-colour render) and linearity of the
-    backward in the upstream gradient."""
-    import torch
-    from diff_triangle_rasterization_2D import TriangleRasterizer
+FULL_SIZE = [
+    # P, W, H, D, variant  -- bench headline + BASELINE.json configs[1..4] as (P, W, H, D); the oracle is too
+    # slow for these inside a unit test, so size-independent properties are checked instead
+    (1_000_000, 1920, 1080, 3, 2),   # bench.py headline
+    (300_000, 800, 800, 3, 2),       # configs[1]  NerfSynthetic 'lego'
+    (2_000_000, 1920, 1080, 3, 2),   # configs[2]  MipNerf360 'bicycle'
+    (93_000, 1600, 1600, 0, 3),      # configs[3]  VanillaTS_mesh 'ship', 800^2 x render_up_scale 2, 3D rasterizer
+    (5_000_000, 1920, 1080, 0, 3),   # configs[4]  MatrixCity VanillaTS_mesh, 3D rasterizer
+    (1_000_000, 1920, 1080, 3, 3),   # headline scene through the 3D rasterizer
+]
 
-    P, W, H, D = 1_000_000, 1920, 1080, 3
+
+@pytest.mark.parametrize("P,W,H,D,variant", FULL_SIZE)
+def test_full_size_properties(P, W, H, D, variant):
+    """Sortedness of the instance list, exact tile ranges, transmittance identity (sum of contributions + T_final == 1
+    via a unit-colour render) and linearity of the backward in the upstream gradient."""
+    import torch
+    if variant == 3:
+        from diff_triangle_rasterization_3D import TriangleRasterizer
+    else:
+        from diff_triangle_rasterization_2D import TriangleRasterizer
+
     s = synthetic.scene(P, W, H, D, seed=42, with_grads=False)
     rs = helpers.hip_settings(s, rich_info=True)
     t = lambda a: torch.from_numpy(a).cuda()
