@@ -39,7 +39,7 @@ SOURCES = {
     "refstruct.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],  # measurement aid (TS2D_MODE=refstruct)
     "api.hip": [],
 }
-HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", "ts2d_stage.h", os.path.join("..", "..", "include", "ts2d.h"),
+HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
            os.path.join("..", "..", "include", "ts_knn.h"),
            os.path.join("..", "..", "include", "ts_model.h")]

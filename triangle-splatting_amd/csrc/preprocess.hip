@@ -12,7 +12,7 @@
 #include "ts2d_common.h"
 #include "ts2d_math.h"
 #include "ts2d_sh.h"
-#include "ts2d_stage.h"
+#include "ts2d_preprocess_launch.h"
 
 using namespace ts;
 
@@ -124,29 +124,6 @@ __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int3
     r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
     r[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
     r[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
-}
-
-// direct version: any alignment, any M
-__global__ void __launch_bounds__(256) preprocess_fwd_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
-{
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-    preprocess_fwd_one(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
-}
-
-// staged version (ts2d_stage.h): single-wave workgroups, vertex rows always staged, SH rows staged when SHROW = 3 M > 0
-template <int SHROW>
-__global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
-{
-    __shared__ float s_v[64 * 9];
-    __shared__ float s_sh[SHROW > 0 ? 64 * (SHROW + 1) : 1];
-    const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
-    stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
-    if (SHROW > 0) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
-    __syncthreads();
-    if (idx >= a.P) return;
-    const float *shp = SHROW > 0 ? s_sh + lane * (SHROW + 1) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
-    preprocess_fwd_one(a, radii, g, idx, s_v + lane * 9, shp);
 }
 
 // backward.cu:131-142
@@ -277,114 +254,21 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreprocessArgs &a, cons
     if (a.C > 2) of[2] = dL_drgb.z;
 }
 
-__global__ void __launch_bounds__(256) preprocess_bwd_kernel(PreprocessArgs a, const int32_t *__restrict__ radii,
-                                                              GeometryStateView g, const float *__restrict__ grad_rec,
-                                                              float *__restrict__ dL_dvertex, float *__restrict__ dL_dcenter2D,
-                                                              float *__restrict__ dL_dshs, float *__restrict__ dL_dfeature,
-                                                              float *__restrict__ dL_dopacity)
+struct Raster2D
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-    preprocess_bwd_one(a, radii, g, grad_rec, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr,
-                       dL_dvertex + 9 * (size_t)idx, dL_dshs ? dL_dshs + (size_t)idx * a.M * 3 : nullptr, dL_dcenter2D,
-                       dL_dfeature, dL_dopacity);
-}
-
-// staged version: SHROW = 3 M > 0 stages the SH rows in AND the dL_dshs rows out through the same LDS rows
-template <int SHROW, bool SH_IN, bool WRITE_SH>
-__global__ void __launch_bounds__(64) preprocess_bwd_staged_kernel(PreprocessArgs a, const int32_t *__restrict__ radii,
-                                                                    GeometryStateView g, const float *__restrict__ grad_rec,
-                                                                    float *__restrict__ dL_dvertex, float *__restrict__ dL_dcenter2D,
-                                                                    float *__restrict__ dL_dshs, float *__restrict__ dL_dfeature,
-                                                                    float *__restrict__ dL_dopacity)
-{
-    __shared__ float s_v[64 * 9];
-    __shared__ float s_sh[SHROW > 0 ? 64 * (SHROW + 1) : 1];
-    const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
-    stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
-    if (SHROW > 0 && SH_IN) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
-    __syncthreads();
-    if (idx < a.P)
-    {
-        float *row = SHROW > 0 ? s_sh + lane * (SHROW + 1) : nullptr;
-        const float *shp = (SHROW > 0 && SH_IN) ? row : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
-        preprocess_bwd_one(a, radii, g, grad_rec, idx, s_v + lane * 9, shp, s_v + lane * 9, WRITE_SH ? row : nullptr, dL_dcenter2D,
-                           dL_dfeature, dL_dopacity);
-    }
-    __syncthreads();
-    stage_rows_out<9, 9>(s_v, dL_dvertex, row0, a.P, lane);
-    if (SHROW > 0 && WRITE_SH) stage_rows_out<SHROW, SHROW + 1>(s_sh, dL_dshs, row0, a.P, lane);
-}
+    template <class... T> static __device__ __forceinline__ void fwd(T... t) { preprocess_fwd_one(t...); }
+    template <class... T> static __device__ __forceinline__ void bwd(T... t) { preprocess_bwd_one(t...); }
+};
 } // namespace
-
-// Staging policy: vertex rows whenever the pointers are 16-byte aligned; SH rows in when at least half of each row is
-// active (otherwise the direct strided read of the active prefix moves fewer bytes); dL_dshs rows out always (every
-// element is written).
-static int staged_shrow(const PreprocessArgs &a) { return (a.use_shs && (a.M == 1 || a.M == 4 || a.M == 9 || a.M == 16)) ? 3 * a.M : 0; }
 
 void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s)
 {
-    if (a.P <= 0) return;
-    const int shrow = staged_shrow(a);
-    const bool sh_in = shrow > 0 && 2 * (a.D + 1) * (a.D + 1) >= a.M && aligned16(a.shs);
-    if (!aligned16(a.vertex))
-    {
-        hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g);
-        return;
-    }
-    const dim3 grid((a.P + 63) / 64), block(64);
-    switch (sh_in ? shrow : 0)
-    {
-    case 48: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<48>, grid, block, 0, s, a, radii, g); break;
-    case 27: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<27>, grid, block, 0, s, a, radii, g); break;
-    case 12: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<12>, grid, block, 0, s, a, radii, g); break;
-    case 3: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<3>, grid, block, 0, s, a, radii, g); break;
-    default: hipLaunchKernelGGL(preprocess_fwd_staged_kernel<0>, grid, block, 0, s, a, radii, g); break;
-    }
+    launch_preprocess_fwd<Raster2D>(a, radii, g, s);
 }
-
-#define TS_BWD_STAGED(SHROW, SH_IN, WRITE_SH)                                                                          \
-    hipLaunchKernelGGL((preprocess_bwd_staged_kernel<SHROW, SH_IN, WRITE_SH>), grid, block, 0, s, a, radii, g, grad_rec, \
-                       dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity)
 
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                               float *dL_dfeature, float *dL_dopacity, hipStream_t s)
 {
-    if (a.P <= 0) return;
-    const int shrow = staged_shrow(a);
-    const bool write_sh = a.use_shs && dL_dshs != nullptr;
-    const bool ok = aligned16(a.vertex) && aligned16(dL_dvertex) && (!a.use_shs || aligned16(a.shs)) &&
-                    (!write_sh || aligned16(dL_dshs));
-    if (!ok)
-    {
-        hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g, grad_rec,
-                           dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity);
-        return;
-    }
-    const dim3 grid((a.P + 63) / 64), block(64);
-    const bool sh_in = shrow > 0 && 2 * (a.D + 1) * (a.D + 1) >= a.M;
-    // the LDS rows exist when they carry something: SH in, dL_dshs out, or both
-    const int rows = (sh_in || write_sh) ? shrow : 0;
-    switch (rows)
-    {
-    case 48:
-        if (sh_in && write_sh) TS_BWD_STAGED(48, true, true); else if (sh_in) TS_BWD_STAGED(48, true, false); else TS_BWD_STAGED(48, false, true);
-        break;
-    case 27:
-        if (sh_in && write_sh) TS_BWD_STAGED(27, true, true); else if (sh_in) TS_BWD_STAGED(27, true, false); else TS_BWD_STAGED(27, false, true);
-        break;
-    case 12:
-        if (sh_in && write_sh) TS_BWD_STAGED(12, true, true); else if (sh_in) TS_BWD_STAGED(12, true, false); else TS_BWD_STAGED(12, false, true);
-        break;
-    case 3:
-        if (sh_in && write_sh) TS_BWD_STAGED(3, true, true); else if (sh_in) TS_BWD_STAGED(3, true, false); else TS_BWD_STAGED(3, false, true);
-        break;
-    default:
-        if (write_sh) // M outside {1,4,9,16}: only the vertex rows are staged, dL_dshs written directly
-            hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g, grad_rec, dL_dvertex,
-                               dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity);
-        else TS_BWD_STAGED(0, false, false);
-        break;
-    }
+    launch_preprocess_bwd<Raster2D>(a, radii, g, grad_rec, dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity, s);
 }

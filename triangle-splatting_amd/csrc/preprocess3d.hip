@@ -12,6 +12,7 @@
 #include "ts2d_common.h"
 #include "ts2d_math.h"
 #include "ts2d_sh.h"
+#include "ts2d_preprocess_launch.h"
 
 using namespace ts;
 
@@ -19,11 +20,10 @@ namespace
 {
 __device__ __forceinline__ float proj_to_pix(float v, int S) { return (v + 1.0f) * S * 0.5f - 0.5f; } // R3D auxiliary.h:35-38
 
-__global__ void __launch_bounds__(256) preprocess3d_fwd_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
+// One triangle; `vp` / `shp` = its vertex / SH rows (global memory or LDS, ts2d_preprocess_launch.h).
+__device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, int32_t *__restrict__ radii, const GeometryStateView &g,
+                                                     int idx, const float *vp, const float *shp)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-
     int out_radius = 0;
     uint32_t out_tiles = 0;
     uint2 out_rect = {0u, 0u};
@@ -33,7 +33,6 @@ __global__ void __launch_bounds__(256) preprocess3d_fwd_kernel(PreprocessArgs a,
 #pragma unroll
     for (int i = 0; i < TS_REC_FLOATS; i++) rec[i] = 0.0f;
 
-    const float *vp = a.vertex + 9 * (size_t)idx;
     const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
     do
     {
@@ -67,7 +66,7 @@ __global__ void __launch_bounds__(256) preprocess3d_fwd_kernel(PreprocessArgs a,
         if (a.use_shs)
         {
             const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
-            rgb = sh_to_rgb(a.D, a.shs + (size_t)idx * a.M * 3, center, cp);
+            rgb = sh_to_rgb(a.D, shp, center, cp);
             out_clamped = (uint8_t)((rgb.x < 0 ? 1 : 0) | (rgb.y < 0 ? 2 : 0) | (rgb.z < 0 ? 4 : 0));
             rgb = {fmaxf(rgb.x, 0.0f), fmaxf(rgb.y, 0.0f), fmaxf(rgb.z, 0.0f)};
         }
@@ -103,15 +102,13 @@ __global__ void __launch_bounds__(256) preprocess3d_fwd_kernel(PreprocessArgs a,
     r[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
 }
 
-__global__ void __launch_bounds__(256) preprocess3d_bwd_kernel(PreprocessArgs a, const int32_t *__restrict__ radii,
-                                                                GeometryStateView g, const float *__restrict__ grad_rec,
-                                                                float *__restrict__ dL_dvertex, float *__restrict__ dL_dcenter2D,
-                                                                float *__restrict__ dL_dshs, float *__restrict__ dL_dfeature,
-                                                                float *__restrict__ dL_dopacity)
+// One triangle; `ov` (9 floats) / `osh` (3 M floats, may be null) receive dL_dvertex / dL_dshs (global memory or LDS rows).
+__device__ __forceinline__ void preprocess3d_bwd_one(const PreprocessArgs &a, const int32_t *__restrict__ radii,
+                                                     const GeometryStateView &g, const float *__restrict__ grad_rec, int idx,
+                                                     const float *vp, const float *shp, float *ov, float *osh,
+                                                     float *__restrict__ dL_dcenter2D, float *__restrict__ dL_dfeature,
+                                                     float *__restrict__ dL_dopacity)
 {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= a.P) return;
-    float *ov = dL_dvertex + 9 * (size_t)idx;
     float *oc = dL_dcenter2D + 2 * (size_t)idx;
     if (radii[idx] <= 0) // R3D backward.cu:165
     {
@@ -120,10 +117,11 @@ __global__ void __launch_bounds__(256) preprocess3d_bwd_kernel(PreprocessArgs a,
         oc[0] = 0.0f; oc[1] = 0.0f;
         dL_dopacity[idx] = 0.0f;
         for (int c = 0; c < a.C; c++) dL_dfeature[(size_t)idx * a.C + c] = 0.0f;
-        if (a.use_shs && dL_dshs)
-            for (int k = 0; k < a.M * 3; k++) dL_dshs[(size_t)idx * a.M * 3 + k] = 0.0f;
+        if (a.use_shs && osh)
+            for (int k = 0; k < a.M * 3; k++) osh[k] = 0.0f;
         return;
     }
+    const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]}; // before ov (may alias vp) is written
     const float4 *rp = g.rec + 4 * (size_t)idx;
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2];
     const f3 v1_view = {r0.x, r0.y, r0.z}, v2_view = {r0.w, r1.x, r1.y}, v3_view = {r1.z, r1.w, r2.x};
@@ -142,8 +140,6 @@ __global__ void __launch_bounds__(256) preprocess3d_bwd_kernel(PreprocessArgs a,
        dL_dv3 = xform_vec_4x3_T(gv3, a.viewmatrix);
     if (a.use_shs)
     {
-        const float *vp = a.vertex + 9 * (size_t)idx;
-        const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
         const f3 center = divf(add(add(v1, v2), v3), 3.0f);
         const uint8_t cl = g.clamped[idx];
         f3 dL_dRGB = grgb;
@@ -151,9 +147,10 @@ __global__ void __launch_bounds__(256) preprocess3d_bwd_kernel(PreprocessArgs a,
         dL_dRGB.y *= (cl & 2) ? 0.0f : 1.0f;
         dL_dRGB.z *= (cl & 4) ? 0.0f : 1.0f;
         const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
-        const f3 dsh = sh_backward(a.D, a.M, a.shs + (size_t)idx * a.M * 3, center, cp, dL_dRGB,
-                                   dL_dshs ? dL_dshs + (size_t)idx * a.M * 3 : nullptr);
-        if (!dL_dshs) grgb_out = dL_dRGB; // factored exchange (TS2D_FLAG_SH_FACTORED)
+        // when osh aliases shp (LDS row) the coefficients must be consumed before the gradients are written
+        const f3 dsh = sh_backward(a.D, a.M, shp, center, cp, dL_dRGB, nullptr);
+        if (osh) sh_grad_store(a.D, a.M, center, cp, dL_dRGB, osh);
+        if (!osh) grgb_out = dL_dRGB; // factored exchange (TS2D_FLAG_SH_FACTORED)
         const f3 third = divf(dsh, 3.0f); // R3D backward.cu:196-198
         dL_dv1 = add(dL_dv1, third); dL_dv2 = add(dL_dv2, third); dL_dv3 = add(dL_dv3, third);
     }
@@ -168,19 +165,21 @@ __global__ void __launch_bounds__(256) preprocess3d_bwd_kernel(PreprocessArgs a,
     if (a.C > 1) of[1] = grgb_out.y;
     if (a.C > 2) of[2] = grgb_out.z;
 }
+struct Raster3D
+{
+    template <class... T> static __device__ __forceinline__ void fwd(T... t) { preprocess3d_fwd_one(t...); }
+    template <class... T> static __device__ __forceinline__ void bwd(T... t) { preprocess3d_bwd_one(t...); }
+};
 } // namespace
 
 void ts_launch_preprocess3d_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s)
 {
-    if (a.P <= 0) return;
-    hipLaunchKernelGGL(preprocess3d_fwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g);
+    launch_preprocess_fwd<Raster3D>(a, radii, g, s);
 }
 
 void ts_launch_preprocess3d_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                                 const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                                 float *dL_dfeature, float *dL_dopacity, hipStream_t s)
 {
-    if (a.P <= 0) return;
-    hipLaunchKernelGGL(preprocess3d_bwd_kernel, dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g, grad_rec, dL_dvertex,
-                       dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity);
+    launch_preprocess_bwd<Raster3D>(a, radii, g, grad_rec, dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity, s);
 }
