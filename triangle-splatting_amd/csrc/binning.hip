@@ -97,12 +97,17 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t N, const uint3
 }
 } // namespace
 
+// rocPRIM's default switches from merge sort to Onesweep radix sort above 1 Mi items; measured on MI355X (rocprofv3,
+// profiles/r01_final_kernel_stats.csv) the merge path costs ten ~8 us merge passes at P = 1 M, about twice the four
+// Onesweep passes, so the switch-over is lowered.
+using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 128 * 1024>;
+
 size_t ts_scan_temp_bytes(int32_t P)
 {
     size_t scan = 0, sort = 0;
     if (P <= 0) return 0;
     (void)rocprim::inclusive_scan(nullptr, scan, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P, rocprim::plus<uint32_t>());
-    (void)rocprim::radix_sort_pairs(nullptr, sort, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, sort, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                     (uint32_t *)nullptr, (size_t)P, 0u, 32u);
     return scan > sort ? scan : sort;
 }
@@ -111,7 +116,7 @@ size_t ts_sort_temp_bytes(int64_t N, int end_bit)
 {
     size_t bytes = 0;
     if (N <= 0) return 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
+    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
                                     (uint32_t *)nullptr, (size_t)N, 0u, (unsigned)end_bit);
     return bytes;
 }
@@ -122,7 +127,7 @@ hipError_t ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s
 {
     if (P <= 0) return hipSuccess;
     size_t bytes = g.scan_temp_bytes;
-    return rocprim::radix_sort_pairs(g.scan_temp, bytes, (const uint32_t *)g.depth, g.depth_sorted, g.ids, g.perm, (size_t)P,
+    return rocprim::radix_sort_pairs<SortConfig>(g.scan_temp, bytes, (const uint32_t *)g.depth, g.depth_sorted, g.ids, g.perm, (size_t)P,
                                      0u, 32u, s);
 }
 
@@ -146,7 +151,7 @@ hipError_t ts_sort_pairs(const BinningStateView &b, int64_t N, int end_bit, hipS
 {
     if (N <= 0) return hipSuccess;
     size_t bytes = b.sort_temp_bytes;
-    return rocprim::radix_sort_pairs(b.sort_temp, bytes, b.tile_unsorted, b.tile, b.vals_unsorted, b.vals, (size_t)N, 0u,
+    return rocprim::radix_sort_pairs<SortConfig>(b.sort_temp, bytes, b.tile_unsorted, b.tile, b.vals_unsorted, b.vals, (size_t)N, 0u,
                                      (unsigned)end_bit, s);
 }
 
