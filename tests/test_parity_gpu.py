@@ -215,6 +215,18 @@ def test_full_size_properties(P, W, H, D, variant):
         assert float((2.5 * a - b2).norm() / b2.norm()) < 2e-4  # fp32 atomics: summation order differs between runs
 
 
+def test_mfma_backward_variant_matches(monkeypatch):
+    """TS2D_BWD=mfma (render.hip: per-entry sums on the matrix cores through an LDS transposition tile) against the oracle."""
+    monkeypatch.setenv("TS2D_BWD", "mfma")
+    for P, W, H, D, rich, gamma in [(3000, 130, 70, 3, True, 1.0), (4000, 96, 96, 1, False, 2.0)]:
+        s = synthetic.scene(P, W, H, D, seed=77)
+        s["gamma"] = gamma
+        of = helpers.oracle_forward(s, rich)
+        ob = helpers.oracle_backward(s, of, rich)
+        hf = helpers.hip_forward_backward(s, rich)
+        _check_outputs(hf, of, ob, rich)
+
+
 def test_refstruct_mode_matches(monkeypatch):
     """The reference-structured measurement kernels (TS2D_MODE=refstruct, csrc/refstruct.hip) produce the same results
     as the oracle, so timing them is a fair stand-in for 'the reference structure on this hardware'."""

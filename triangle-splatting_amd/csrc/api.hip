@@ -150,6 +150,8 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.rich_info = flags & TS2D_FLAG_RICH_INFO;
     const char *ab = getenv("TS2D_ABLATE");
     r.ablate = ab ? atoi(ab) : 0;
+    const char *bw = getenv("TS2D_BWD");
+    r.bwd_mfma = (bw && strcmp(bw, "mfma") == 0) ? 1 : 0;
     const char *mode = getenv("TS2D_MODE");
     r.refstruct = (mode && strcmp(mode, "refstruct") == 0) ? 1 : 0;
     return r;

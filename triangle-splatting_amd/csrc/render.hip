@@ -322,8 +322,63 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
 // loop therefore only forms 19 products per lane (moments + colour/normal/opacity terms), reduces them across the
 // wave, parks the 19 sums of entry j in LDS, and once per batch the lane that OWNS entry j turns them into the 16
 // gradient values with its own (register-resident) triangle constants and issues the global atomics.
-template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256, 7) render_bwd_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+// MFMA = true (experimental, env TS2D_BWD=mfma): the 19 per-entry sums are formed on the matrix cores instead of by
+// cross-lane VALU reductions.  Measured on MI355X it is ~10 % SLOWER than the VALU path (render_bwd 1.73 vs 1.56 ms,
+// profiles/r01_notes.md): f32 MFMA runs at the f32 vector rate, the padded 16 x 16 x 64 product per 3 entries costs as
+// many matrix cycles (171 per entry) as the reduction network costs VALU cycles, and the LDS tile lowers occupancy from
+// 7 to 4 waves per SIMD.  Kept as the worked answer to "can MFMA help here?" and as a base for a split-f16 variant.  Every sum has the form sum_pixels f(pixel) * g(entry, pixel) with f one of 12 per-pixel constants
+// {1, qx, qy, dL/dpix of r g b nx ny nz, dL/ddepth * {1, qx, qy}} and g one of 5 per-entry fields {contrib, z1, z2, z3,
+// dL_dalpha * G}: a (rows = entry fields) x (K = 64 pixels) x (cols = per-pixel constants) matrix product.  Each
+// processed entry parks its 5 fields as rows of a wave-private LDS tile (the transposition: a field is computed one
+// pixel per lane, the MFMA wants one ROW per lane); every 3 entries (15 rows) sixteen v_mfma_f32_16x16x4_f32 contract
+// the tile with the constant operand held in 16 VGPRs, and the lanes that hold useful elements of D scatter them into
+// the entries' sum slots.  f32 MFMA is exact f32 (an fmaf chain) and replaces 15 permlane swaps + 15 adds + 9 DPP ops
+// + 12 multiplies per entry with 5 ds_write_b32, 4/3 ds_read_b128 and 16/3 MFMA issues.
+constexpr int MROWS = 16, MRS = 68; // LDS tile: 16 rows (3 entries x 5 fields + 1 spare), row stride 68 floats (16-B aligned, bank-staggered)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_16x16x4_f32: lane l supplies A[m = l & 15][k = l >> 4] and B[k = l >> 4][n = l & 15]; chunk c of the 16
+// contracts the pixels {16 k + c}, so that a lane's A elements of all chunks are 16 consecutive floats of its row.
+// D[4 (l >> 4) + i][l & 15] sits in register i of lane l.  Everything is passed by value so that it stays in registers
+// (a by-reference lambda capture sent the constant operand and the counters to scratch memory).
+__device__ __forceinline__ void mfma_reduce_set(const float *mt, float *sums, int lane, float4 B0, float4 B1, float4 B2, float4 B3,
+                                                int t0, int t1, int t2, int t3, int nslot, int jc0, int jc1, int jc2)
+{
+    const float *arow = mt + (lane & 15) * MRS + 16 * (lane >> 4);
+    const float4 q0 = *(const float4 *)(arow), q1 = *(const float4 *)(arow + 4), q2 = *(const float4 *)(arow + 8),
+                 q3 = *(const float4 *)(arow + 12);
+    f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.x, B0.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.y, B0.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.z, B0.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q0.w, B0.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.x, B1.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.y, B1.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.z, B1.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q1.w, B1.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.x, B2.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.y, B2.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.z, B2.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q2.w, B2.w, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.x, B3.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.y, B3.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.z, B3.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(q3.w, B3.w, acc, 0, 0, 0);
+    const int t[4] = {t0, t1, t2, t3};
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        const int sl = t[i] >> 8;
+        if (t[i] >= 0 && sl < nslot)
+        {
+            const int jcs = sl == 0 ? jc0 : (sl == 1 ? jc1 : jc2);
+            sums[jcs * CST + (t[i] & 0xFF)] = acc[i];
+        }
+    }
+}
+
+template <bool RICH, bool GAMMA1, bool MFMA>
+__global__ void __launch_bounds__(256, MFMA ? 4 : 7) render_bwd_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                           const uint32_t *__restrict__ point_list,
                                                           const float4 *__restrict__ rec, const float *__restrict__ final_T,
                                                           const uint32_t *__restrict__ n_contrib,
@@ -332,6 +387,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_kernel(RenderArgs a, const 
                                                           const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
     __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CST];
+    __shared__ __attribute__((aligned(16))) float tile_all[MFMA ? 4 : 1][MFMA ? MROWS * MRS : 4];
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -345,6 +401,7 @@ __global__ void __launch_bounds__(256, 7) render_bwd_kernel(RenderArgs a, const 
     const float g2 = 2.0f * a.gamma;
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
     float *cst = cst_all[wave];
+    float *mt = tile_all[MFMA ? wave : 0];
     // The 19 reduced sums of an entry are parked in the entry's own constants row: the row is dead once the entry has
     // been processed (each entry is visited once per batch; LDS executes a wave's accesses in order) except for the
     // triangle id in slot 19.
@@ -379,6 +436,48 @@ __global__ void __launch_bounds__(256, 7) render_bwd_kernel(RenderArgs a, const 
     const int wlast = __builtin_amdgcn_readlane(__float_as_int(wave_max63_nonneg((float)last)), 63);
     const int maxlast = (int)__int_as_float(wlast);
     if (maxlast <= 0) return;
+
+    // ---- MFMA path: constant operand (16 VGPRs) and scatter targets (see mfma_reduce_set) -----------------------------
+    float4 Bq0 = make_float4(0, 0, 0, 0), Bq1 = Bq0, Bq2 = Bq0, Bq3 = Bq0;
+    int tg0 = -1, tg1 = -1, tg2 = -1, tg3 = -1; // per D register: (slot << 8) | sum index, or -1 when the element is not one of the 19 sums
+    if (MFMA)
+    {
+        float *tmp = mt; // [pixel][8]: the per-pixel upstream gradients, pixel-major
+        tmp[lane * 8 + 0] = dpr; tmp[lane * 8 + 1] = dpg; tmp[lane * 8 + 2] = dpb;
+        tmp[lane * 8 + 3] = dnx; tmp[lane * 8 + 4] = dny; tmp[lane * 8 + 5] = dnz; tmp[lane * 8 + 6] = dd;
+        const int n = lane & 15, kq = lane >> 4;
+        const int src = (n >= 3 && n <= 8) ? n - 3 : 6;
+        auto bval = [=](int c) -> float {
+            const int p = 16 * kq + c;
+            const float qx = (float)(p & 7), qy = (float)(p >> 3);
+            const float t = tmp[p * 8 + src];
+            float val = 0.0f;
+            if (n == 0) val = 1.0f;
+            else if (n == 1) val = qx;
+            else if (n == 2) val = qy;
+            else if (n <= 9) val = t;       // dL/d(r g b nx ny nz), dL/ddepth
+            else if (n == 10) val = t * qx; // dL/ddepth * qx
+            else if (n == 11) val = t * qy;
+            return val;
+        };
+        Bq0 = make_float4(bval(0), bval(1), bval(2), bval(3));
+        Bq1 = make_float4(bval(4), bval(5), bval(6), bval(7));
+        Bq2 = make_float4(bval(8), bval(9), bval(10), bval(11));
+        Bq3 = make_float4(bval(12), bval(13), bval(14), bval(15));
+        auto target = [=](int i) -> int {
+            const int R = 4 * kq + i, sl = R / 5, vec = R % 5;
+            int idx = -1;
+            if (R < 15)
+            {
+                if (vec == 0 && n >= 3 && n <= 11) idx = 7 + n;                  // rgb 10..12, normal 13..15, depth moments 16..18
+                else if (vec >= 1 && vec <= 3 && n < 3) idx = 3 * (vec - 1) + n; // z_k moments 0..8
+                else if (vec == 4 && n == 0) idx = 9;                            // dL/dopacity
+            }
+            return idx < 0 ? -1 : ((sl << 8) | idx);
+        };
+        tg0 = target(0); tg1 = target(1); tg2 = target(2); tg3 = target(3);
+    }
+    int nslot = 0, jc0 = 0, jc1 = 0, jc2 = 0; // entries parked in the tile (wave-uniform)
 
     for (int base = ((maxlast - 1) >> 6) << 6; base >= 0; base -= 64)
     {
@@ -458,6 +557,21 @@ __global__ void __launch_bounds__(256, 7) render_bwd_kernel(RenderArgs a, const 
             const bool k2 = !k1 && a2 <= a1 && a2 <= a3;
             const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = (k1 || k2) ? 0.0f : z;
 
+            if (MFMA)
+            {
+                float *row = mt + (nslot * 5) * MRS + lane; // this pixel's column of the entry's five rows
+                row[0] = contrib;
+                row[MRS] = z1; row[2 * MRS] = z2; row[3 * MRS] = z3;
+                row[4 * MRS] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
+                if (nslot == 0) jc0 = jc; else if (nslot == 1) jc1 = jc; else jc2 = jc;
+                touched |= 1ull << jc;
+                if (++nslot == 3)
+                {
+                    mfma_reduce_set(mt, sums, lane, Bq0, Bq1, Bq2, Bq3, tg0, tg1, tg2, tg3, nslot, jc0, jc1, jc2);
+                    nslot = 0;
+                }
+                continue;
+            }
             float v[16];
             v[0] = z1; v[1] = z1 * fx; v[2] = z1 * fy;
             v[3] = z2; v[4] = z2 * fx; v[5] = z2 * fy;
@@ -486,6 +600,11 @@ __global__ void __launch_bounds__(256, 7) render_bwd_kernel(RenderArgs a, const 
 
         // Batch epilogue: the lane that owns a touched entry converts the 19 sums into the 16 gradient values.
         if (touched == 0) continue;
+        if (MFMA && nslot > 0) // entries still parked in the tile
+        {
+            mfma_reduce_set(mt, sums, lane, Bq0, Bq1, Bq2, Bq3, tg0, tg1, tg2, tg3, nslot, jc0, jc1, jc2);
+            nslot = 0;
+        }
         if ((touched >> lane) & 1)
         {
             const float4 *sq = (const float4 *)(sums + lane * CST);
@@ -541,6 +660,16 @@ __global__ void __launch_bounds__(256, 7) render_bwd_kernel(RenderArgs a, const 
 }
 } // namespace
 
+#define TS_DISPATCH_BWD(MFMA, ...)                                                                                    \
+    do                                                                                                                \
+    {                                                                                                                 \
+        const bool g1 = (a.gamma == 1.0f);                                                                            \
+        if (a.rich_info && g1) hipLaunchKernelGGL((render_bwd_kernel<true, true, MFMA>), grid, dim3(256), 0, s, __VA_ARGS__);   \
+        else if (a.rich_info) hipLaunchKernelGGL((render_bwd_kernel<true, false, MFMA>), grid, dim3(256), 0, s, __VA_ARGS__);   \
+        else if (g1) hipLaunchKernelGGL((render_bwd_kernel<false, true, MFMA>), grid, dim3(256), 0, s, __VA_ARGS__);            \
+        else hipLaunchKernelGGL((render_bwd_kernel<false, false, MFMA>), grid, dim3(256), 0, s, __VA_ARGS__);                   \
+    } while (0)
+
 #define TS_DISPATCH(KERNEL, ...)                                                                                      \
     do                                                                                                                \
     {                                                                                                                 \
@@ -567,8 +696,12 @@ void ts_launch_render_bwd(const RenderArgs &a, const GeometryStateView &g, const
 {
     const dim3 grid((unsigned)(a.grid_x * a.grid_y));
     if (grid.x == 0) return;
-    TS_DISPATCH(render_bwd_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature,
-                dL_dout_depth, dL_dout_normal, grad_rec);
+    if (!a.bwd_mfma) // default: cross-lane (permlane / DPP) reduction networks; TS2D_BWD=mfma selects the matrix-core variant
+        TS_DISPATCH_BWD(false, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature, dL_dout_depth,
+                        dL_dout_normal, grad_rec);
+    else
+        TS_DISPATCH_BWD(true, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature, dL_dout_depth,
+                        dL_dout_normal, grad_rec);
 }
 
 #ifdef TS2D_STATS

@@ -159,6 +159,7 @@ struct RenderArgs
     const float *background; // C floats, device
     bool rich_info;
     int ablate; // profiling only (env TS2D_ABLATE, builds with -DTS2D_ABLATION): 0 = full kernel; see render.hip
+    int bwd_mfma;  // experiment (env TS2D_BWD=mfma): render_bwd forms its per-entry sums with f32 MFMA instead of VALU reduction networks
     int refstruct; // measurement aid (env TS2D_MODE=refstruct): reference-structured blend kernels, see refstruct.hip
 };
 void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
