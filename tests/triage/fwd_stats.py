@@ -1,7 +1,7 @@
 """Profiling aid: culling / lane-occupancy statistics of render_fwd on the headline scene.  Needs a library built with
 -DTS2D_STATS (TS2D_EXTRA_FLAGS=-DTS2D_STATS python triangle-splatting_amd/build.py --force)."""
 import ctypes, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "triangle-splatting_amd"), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import synthetic, helpers

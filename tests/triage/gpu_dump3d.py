@@ -1,6 +1,6 @@
-"""Scratch (GPU box): dump HIP 3D outputs of one parity case for offline analysis."""
+"""Triage aid (test infrastructure: compares against the oracle, hence under tests/).  Scratch (GPU box): dump HIP 3D outputs of one parity case for offline analysis."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "triangle-splatting_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import synthetic, helpers

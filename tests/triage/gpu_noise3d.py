@@ -1,6 +1,6 @@
-"""Scratch (GPU box): fp32 noise of oracle vs HIP for the 3D variant, against the float64 autograd model."""
+"""Triage aid (test infrastructure: compares against the oracle, hence under tests/).  Scratch (GPU box): fp32 noise of oracle vs HIP for the 3D variant, against the float64 autograd model."""
 import sys, os
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "triangle-splatting_amd"), os.path.join(ROOT, "tests")]
 import numpy as np
 import synthetic, helpers, ref3d_f64

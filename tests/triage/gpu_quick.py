@@ -1,6 +1,6 @@
-"""Scratch triage script (GPU box): HIP path vs oracle on a few scenes, prints the diffs."""
+"""Triage aid (test infrastructure: compares against the oracle, hence under tests/).  Scratch triage script (GPU box): HIP path vs oracle on a few scenes, prints the diffs."""
 import sys, os, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "triangle-splatting_amd"), os.path.join(ROOT, "tests")]
 import numpy as np, torch
 import synthetic, helpers
