@@ -38,7 +38,7 @@ def _check_state3d(s, hf, of, use_feature=False):
     assert (nc_h != nc_o).mean() <= OUTLIER_FRAC
 
 
-GRAZING_COS = 0.03  # triangles seen within ~1.7 degrees of edge-on
+GRAZING_COS = 0.05  # triangles seen within ~2.9 degrees of edge-on
 TIE_GAP = 2e-5  # fp32 rounding level of the barycentrics (|a| ~ 1, a few ulp of the ~1e1 intermediate terms)
 
 
@@ -49,7 +49,7 @@ def _grazing_cos(st, i):
     return abs(c @ n) / (np.linalg.norm(c) * np.linalg.norm(n))
 
 
-def _check_geometry_grads(s, of, hip, ora, name):
+def _check_geometry_grads(s, of, hip, ora, name, scale=None):
     """rel-L2 < GRAD_TOL over all triangles, except the few whose fp32 gradient is ill-conditioned in the REFERENCE's
     own arithmetic, each of which must be explained by one of
       * an argmin near-tie: min(a1, a2, a3) is a tie at some pixel to within rounding, so which vertices receive that
@@ -60,14 +60,20 @@ def _check_geometry_grads(s, of, hip, ora, name):
         d(alpha)/d(ecc) into ~2 gamma ecc^(2 gamma - 1), so the ~1e-5 fp32 rounding of the 3D barycentrics moves the
         handful of edge pixels that carry the whole geometric gradient by per cents (the 2D variant's screen-space
         barycentrics are ~100x more exact, which is why test_parity_gpu.py needs no such clause);
-    and must stay within 5 % (20 % for a sharp window) of its own gradient norm unless it is a tie."""
+    and must stay within 5 % (20 % for a sharp window) of its own gradient norm unless it is a tie.
+    `scale` (per triangle) replaces the triangle's own norm as the yardstick: dL_dcenter2D is the view-space xy of the SUM of
+    the three vertex gradients (R3D backward.cu:211-213), which largely cancel, so its rounding error is that of the vertex
+    gradients, not of the (much smaller) sum."""
     sharp = float(s["gamma"]) >= 10.0
     P = hip.shape[0]
     st = of["state"]
     err = np.linalg.norm((hip.astype(np.float64) - ora).reshape(P, -1), axis=1)
     own = np.linalg.norm(ora.astype(np.float64).reshape(P, -1), axis=1)
     ref = np.linalg.norm(own)
-    suspects = np.nonzero(err > 0.1 * GRAD_TOL * ref)[0]
+    if scale is not None:
+        own = np.maximum(own, scale)
+    # a suspect matters globally (> 10 % of the error budget) AND misses the tolerance relative to its own gradient
+    suspects = np.nonzero((err > 0.1 * GRAD_TOL * ref) & (err > GRAD_TOL * own))[0]
     assert len(suspects) <= max(3, P // 500), (name, len(suspects))
     for i in suspects:
         tie = ref3d_f64.min_tie_gap(s, st, int(i)) < TIE_GAP
@@ -85,8 +91,9 @@ def _check_outputs(s, hf, of, ob, rich, use_feature=False):
             assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k
     for k in ["dL_dopacity", "dL_dfeature" if use_feature else "dL_dshs"]:
         assert helpers.rel_l2(hf[k], ob[k]) < GRAD_TOL, k
-    for k in ["dL_dvertex", "dL_dcenter2D"]:
-        _check_geometry_grads(s, of, hf[k], ob[k], k)
+    _check_geometry_grads(s, of, hf["dL_dvertex"], ob["dL_dvertex"], "dL_dvertex")
+    vnorm = np.linalg.norm(ob["dL_dvertex"].astype(np.float64).reshape(len(ob["dL_dvertex"]), -1), axis=1)
+    _check_geometry_grads(s, of, hf["dL_dcenter2D"], ob["dL_dcenter2D"], "dL_dcenter2D", scale=vnorm)
 
 
 CASES = [
