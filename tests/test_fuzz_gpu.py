@@ -1,0 +1,65 @@
+"""Seeded random-configuration parity sweep: small scenes with random image sizes (incl. 1-pixel-wide and non-multiples of
+8 / 16), triangle counts (incl. < 64), SH degrees / stored coefficient counts, feature mode with 1-3 channels, gamma,
+opacity extremes (exact 0 and 1), background, culling mode, and both rasterizer variants -- each against the oracle with
+the same bars as the structured parity tests."""
+import numpy as np
+import pytest
+
+import helpers
+import synthetic
+import test_parity3d_gpu as T3
+import test_parity_gpu as T2
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed):
+    rng = np.random.default_rng(seed)
+    variant = 2 if seed % 2 == 0 else 3
+    W = int(rng.choice([1, 7, 16, 33, 64, 100, 129, 255]))
+    H = int(rng.choice([1, 5, 16, 31, 64, 90, 130]))
+    P = int(rng.choice([1, 3, 40, 63, 65, 300, 1500, 4000]))
+    use_feature = bool(rng.random() < 0.35)
+    C = int(rng.integers(1, 4)) if use_feature else 3
+    maxdeg = int(rng.integers(0, 4))
+    D = int(rng.integers(0, maxdeg + 1))
+    edge = float(rng.choice([1.5, 6.0, 20.0, 60.0]))
+    s = synthetic.scene(P, W, H, D, seed=seed, edge_px=edge, max_degree=maxdeg)
+    s["gamma"] = float(rng.choice([0.5, 1.0, 1.0, 2.0, 8.0]))
+    op = s["opacity"].copy()
+    op[rng.random(P) < 0.1] = 0.0
+    op[rng.random(P) < 0.1] = 1.0
+    s["opacity"] = op
+    s["background_depth"] = float(rng.choice([0.0, 10.0, 5000.0]))
+    if use_feature:
+        s["feature"] = rng.random((P, C), dtype=np.float32)
+        s["background"] = rng.random(C, dtype=np.float32)
+        s["dL_dout_feature"] = rng.random((C, H, W), dtype=np.float32)
+    else:
+        s["background"] = rng.random(3, dtype=np.float32)
+    rich = bool(rng.random() < 0.7)
+    back = bool(rng.random() < 0.3)
+    return s, variant, rich, back, use_feature
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_configuration(seed):
+    s, variant, rich, back, use_feature = _case(seed)
+    of = helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant)
+    ob = helpers.oracle_backward(s, of, rich, use_feature=use_feature)
+    hf = helpers.hip_forward_backward(s, rich, back, use_feature=use_feature, variant=variant)
+    assert hf["num_rendered"] == of["num_rendered"]
+    assert np.array_equal(hf["radii"], of["radii"])
+    if of["num_rendered"] == 0:
+        bgimg = np.broadcast_to(s["background"][:, None, None], hf["out_feature"].shape)
+        assert np.allclose(hf["out_feature"], bgimg)
+        for k in ("dL_dvertex", "dL_dopacity"):
+            assert not hf[k].any()
+        return
+    if variant == 2:
+        if not use_feature:
+            T2._check_state(s, hf, of)
+        T2._check_outputs(hf, of, ob, rich, use_feature=use_feature)
+    else:
+        T3._check_state3d(s, hf, of, use_feature=use_feature)
+        T3._check_outputs(s, hf, of, ob, rich, use_feature=use_feature)

@@ -29,8 +29,12 @@ def _check_state3d(s, hf, of, use_feature=False):
     assert np.array_equal(helpers.hip_state(hf, s, "keys").reshape(-1), st.field("keys").view(np.int64).reshape(-1))
     vis = of["radii"] > 0
     rec = helpers.hip_state(hf, s, "records")
+    colour = st.field("rgb")
+    if use_feature:  # C <= 3 channels, the record pads with zeros
+        colour = np.zeros((len(s["feature"]), 3), np.float32)
+        colour[:, : s["feature"].shape[1]] = s["feature"]
     ora = np.concatenate([st.field("v1_view"), st.field("v2_view"), st.field("v3_view"), st.field("normal_view"),
-                          s["opacity"].reshape(-1, 1), s["feature"] if use_feature else st.field("rgb")], axis=1)
+                          s["opacity"].reshape(-1, 1), colour], axis=1)
     assert np.array_equal(rec[vis], ora[vis])  # contraction-free preprocess: bit-exact
     assert np.array_equal(helpers.hip_state(hf, s, "depth")[vis], st.field("depth")[vis])
     nc_h = helpers.hip_state(hf, s, "n_contrib").astype(np.int64)
