@@ -16,8 +16,13 @@
 //     reference's per-pixel difference form (the naively expanded closed form cancels ~1e4 : 1, and fitting N_k
 //     through sampled pixels blows up where a sample ray grazes the plane);
 //   * the conservative support test uses the sign of Den over the quadrant: a_k >= m  <=>  s * (N_k - m Den) >= 0.
-//   * the backward's 16 values are already the 64-byte gradient record (dL/dv1_view, dv2_view, dv3_view, dnormal_view,
-//     dopacity, drgb), so the batch epilogue only flushes.
+//   * backward: with q = hit point - v1, every per-pair gradient term of the reference is linear in (1, q) with per-pair
+//     scalar weights (zw1, zw2 = the arg-min barycentric's gradient split over a1 / a2, dip = dL_ddepth / Den), so the hot
+//     loop forms 20 weighted moments per lane (weights, weights * q, s2, dL_dopacity, rgb, normal), reduces them with the
+//     transpose-reduce networks, and once per batch the entry's owning lane turns the 20 sums into the 16 values of the
+//     64-byte gradient record with a handful of cross products (instead of five cross products per pixel and entry).
+//     Measuring q from v1 (not from the camera) keeps the sums free of the ~depth/edge cancellation an origin-based
+//     expansion would have.
 #include "ts2d_common.h"
 #include "ts2d_wave.h"
 
@@ -90,9 +95,9 @@ __device__ __forceinline__ Entry3 entry_setup3(V3 v1, V3 v2, V3 v3, V3 n, float 
     return e;
 }
 
-// LDS row layouts (floats).  Forward: 20 per entry; backward: 28 per entry, sums alias [0..15], id at [27].
+// LDS row layouts (floats).  Forward: 20 per entry; backward: 28 per entry, the 20 reduced sums alias [0..19], id at [27].
 //   [0..3] a1x a1y a1c a2x   [4..7] a2y a2c dx dy   [8..11] dc d0 op r   [12..15] g b nx ny   [16] nz
-//   backward only: [17..19] v1   [20..22] v2   [23..25] v3   [27] id
+//   backward only: [17] 1/n.n   [18..20] F1 = n x (v3 - v2) / n.n   [21..23] F2 = n x (v1 - v3) / n.n   [24..26] v1   [27] id
 constexpr int CS3F = 20, CS3B = 28;
 
 template <bool RICH, bool GAMMA1>
@@ -296,8 +301,8 @@ __global__ void __launch_bounds__(256) render3d_bwd_kernel(RenderArgs a, float t
             B = fmaf(dd, a.background_depth, B);
         }
     }
-    const int slot = slot_of_lane(lane);
-    const bool writer16 = (lane & 3) == 0;
+    const int slot = slot_of_lane(lane), slot4 = slot4_of_lane(lane);
+    const bool writer16 = (lane & 3) == 0, writer4 = (lane & 15) == 0;
 
     const int wlast = __builtin_amdgcn_readlane(__float_as_int(wave_max63_nonneg((float)last)), 63);
     const int maxlast = (int)__int_as_float(wlast);
@@ -326,9 +331,11 @@ __global__ void __launch_bounds__(256) render3d_bwd_kernel(RenderArgs a, float t
             q[1] = make_float4(e.a2y, e.a2c, e.dx, e.dy);
             q[2] = make_float4(e.dc, e.d0, r3.x, r3.y);
             q[3] = make_float4(r3.z, r3.w, en.x, en.y);
-            q[4] = make_float4(en.z, ev1.x, ev1.y, ev1.z);
-            q[5] = make_float4(ev2.x, ev2.y, ev2.z, ev3.x);
-            q[6] = make_float4(ev3.y, ev3.z, 0.0f, __uint_as_float(id));
+            const float inn_e = 1.0f / vdot(en, en);
+            const V3 F1 = vscale(inn_e, vcross(en, vsub(ev3, ev2))), F2 = vscale(inn_e, vcross(en, vsub(ev1, ev3)));
+            q[4] = make_float4(en.z, inn_e, F1.x, F1.y);
+            q[5] = make_float4(F1.z, F2.x, F2.y, F2.z);
+            q[6] = make_float4(ev1.x, ev1.y, ev1.z, __uint_as_float(id));
         }
         unsigned long long touched = 0;
         while (mask)
@@ -355,15 +362,15 @@ __global__ void __launch_bounds__(256) render3d_bwd_kernel(RenderArgs a, float t
 
             const float4 c3 = *(const float4 *)(cst + jc * CS3B + 12), c4 = *(const float4 *)(cst + jc * CS3B + 16);
             const float4 c5 = *(const float4 *)(cst + jc * CS3B + 20);
-            const float2 c6 = *(const float2 *)(cst + jc * CS3B + 24);
-            const V3 n = {c3.z, c3.w, c4.x}, v1 = {c4.y, c4.z, c4.w}, v2 = {c5.x, c5.y, c5.z}, v3 = {c5.w, c6.x, c6.y};
-            const float d0 = c2.y;
+            const float4 c6 = *(const float4 *)(cst + jc * CS3B + 24); // .w is the id, unused here
+            const V3 n = {c3.z, c3.w, c4.x}, F1 = {c4.z, c4.w, c5.x}, F2 = {c5.y, c5.z, c5.w}, v1 = {c6.x, c6.y, c6.z};
+            const float inn = c4.y, d0 = c2.y;
 
             const float al = hit ? alpha : 0.0f;
             const float oma = 1.0f - al;
             T = T * __builtin_amdgcn_rcpf(oma); // R3D backward.cu:354
             const float contrib = al * T;
-            const float depth = d0 * inv;
+            const float depth = hit ? d0 * inv : 0.0f;
             float X = fmaf(dpb, c3.y, fmaf(dpg, c3.x, dpr * c2.w)); // R3D backward.cu:368
             float dL_ddepth = 0.0f;
             if (RICH) // R3D backward.cu:373-382
@@ -381,36 +388,56 @@ __global__ void __launch_bounds__(256) render3d_bwd_kernel(RenderArgs a, float t
             const bool k2 = !k1 && a2 <= a1 && a2 <= a3;
             const bool k3 = !(k1 || k2);
             // dL/da = z e_k and a3 = 1 - a1 - a2:  sum_k dL/da_k da_k/dx = z (w1 da1/dx + w2 da2/dx)
-            const float w1 = (k1 ? 1.0f : 0.0f) - (k3 ? 1.0f : 0.0f), w2 = (k2 ? 1.0f : 0.0f) - (k3 ? 1.0f : 0.0f);
-            const float inn = __builtin_amdgcn_rcpf(vdot(n, n));
-            const float zw1 = z * w1 * inn, zw2 = z * w2 * inn;
-            const V3 p = vscale(depth, ray);
-            const V3 p1 = vsub(v1, p), p2 = vsub(v2, p), p3 = vsub(v3, p);
-            // da1/ddepth = n . cross(v3 - v2, p_ray) / n.n ; da2/ddepth = n . cross(v1 - v3, p_ray) / n.n  (:407,413)
-            const float da1_dd = vdot(n, vcross(vsub(v3, v2), ray)), da2_dd = vdot(n, vcross(vsub(v1, v3), ray));
-            dL_ddepth += zw1 * da1_dd + zw2 * da2_dd; // R3D backward.cu:421
-            const V3 c_n3 = vcross(n, p3), c_n2 = vcross(n, p2), c_1n = vcross(p1, n), c_23 = vcross(p2, p3), c_31 = vcross(p3, p1);
+            const float t1 = z * ((k1 ? 1.0f : 0.0f) - (k3 ? 1.0f : 0.0f)), t2 = z * ((k2 ? 1.0f : 0.0f) - (k3 ? 1.0f : 0.0f));
+            const float zw1 = t1 * inn, zw2 = t2 * inn;
+            // da1/ddepth = n . cross(v3 - v2, p_ray) / n.n = p_ray . F1, da2/ddepth = p_ray . F2   (:407,413,421)
+            dL_ddepth += t1 * vdot(ray, F1) + t2 * vdot(ray, F2);
             const float dip = hit ? dL_ddepth * inv : 0.0f; // dL_ddepth * inv_p_ray_dot_n (:422-423)
+            // q = hit point - v1 = -p_v1; p_v2 = (v2 - v1) - q, p_v3 = (v3 - v1) - q.  Every gradient term is linear in (1, q):
+            //   dL/dv1 = sum zw2 n x p_v3 + dip n                      = Z2 n x e3 - n x Q2 + Dp n            (:410,425)
+            //   dL/dv2 = -sum zw1 n x p_v3                             = -Z1 n x e3 + n x Q1                  (:404,426)
+            //   dL/dv3 = sum zw1 n x p_v2 + zw2 p_v1 x n               = Z1 n x e2 - n x Q1 + n x Q2          (:405,412,427)
+            //   dL/dn  = sum dn c + zw1 (p_v2 x p_v3 - 2 a1 n) + zw2 (p_v3 x p_v1 - 2 a2 n) + dip p_v1
+            //          = Nn + (Z1 - S2) n + (e3 - e2) x Q1 + Q2 x e3 - Qd                                      (:376,406,414,423,428)
+            // with e_k = v_k - v1, n = e2 x e3, Z = sum zw, Q = sum zw q, Dp = sum dip, Qd = sum dip q, S2 = sum 2 (zw1 a1 + zw2 a2).
+            const V3 q = {fmaf(depth, ray.x, -v1.x), fmaf(depth, ray.y, -v1.y), depth - v1.z};
+            const V3 qq = hit ? q : V3{0.0f, 0.0f, 0.0f};
             float v[16];
-            // dL/dv1_view = dL_da.y da2_dv1 + dL_da.z da3_dv1 + dL_ddepth ddepth_dv1, da2_dv1 = cross(n, p_v3)/n.n (:410,425)
-            v[0] = fmaf(zw2, c_n3.x, dip * n.x); v[1] = fmaf(zw2, c_n3.y, dip * n.y); v[2] = fmaf(zw2, c_n3.z, dip * n.z);
-            // dL/dv2_view: da1_dv2 = cross(p_v3, n)/n.n = -cross(n, p_v3)/n.n (:404,426)
-            v[3] = -zw1 * c_n3.x; v[4] = -zw1 * c_n3.y; v[5] = -zw1 * c_n3.z;
-            // dL/dv3_view: da1_dv3 = cross(n, p_v2)/n.n, da2_dv3 = cross(p_v1, n)/n.n (:405,412,427)
-            v[6] = fmaf(zw1, c_n2.x, zw2 * c_1n.x); v[7] = fmaf(zw1, c_n2.y, zw2 * c_1n.y); v[8] = fmaf(zw1, c_n2.z, zw2 * c_1n.z);
-            // dL/dnormal_view (:376,406,414,423,428): da_k/dn = (cross(..) - 2 a_k n)/n.n, ddepth/dn = (v1 - depth p_ray)/(p_ray.n)
-            const float s2 = 2.0f * (zw1 * a1 + zw2 * a2);
-            v[9] = fmaf(dnx, contrib, fmaf(zw1, c_23.x, fmaf(zw2, c_31.x, fmaf(dip, p1.x, -s2 * n.x))));
-            v[10] = fmaf(dny, contrib, fmaf(zw1, c_23.y, fmaf(zw2, c_31.y, fmaf(dip, p1.y, -s2 * n.y))));
-            v[11] = fmaf(dnz, contrib, fmaf(zw1, c_23.z, fmaf(zw2, c_31.z, fmaf(dip, p1.z, -s2 * n.z))));
-            v[12] = hit ? dL_dalpha * G : 0.0f; // R3D backward.cu:451
-            v[13] = dpr * contrib; v[14] = dpg * contrib; v[15] = dpb * contrib; // R3D backward.cu:365
-            if (!RICH) { /* dnx.. and dd are zero: same expressions */ }
+            v[0] = zw1; v[1] = zw2;
+            v[2] = zw1 * qq.x; v[3] = zw1 * qq.y; v[4] = zw1 * qq.z;
+            v[5] = zw2 * qq.x; v[6] = zw2 * qq.y; v[7] = zw2 * qq.z;
+            v[8] = dip; v[9] = dip * qq.x; v[10] = dip * qq.y; v[11] = dip * qq.z;
+            v[12] = 2.0f * (zw1 * a1 + zw2 * a2);
+            v[13] = hit ? dL_dalpha * G : 0.0f;      // R3D backward.cu:451
+            v[14] = dpr * contrib; v[15] = dpg * contrib; // R3D backward.cu:365
             const float r16 = reduce16(v, lane);
+            const float r4 = reduce4(dpb * contrib, dnx * contrib, dny * contrib, dnz * contrib);
             if (writer16) cst[jc * CS3B + slot] = r16; // the entry's row is dead except for the id in slot 27
+            if (writer4) cst[jc * CS3B + 16 + slot4] = r4;
             touched |= 1ull << jc;
         }
         if (touched == 0) continue;
+        if ((touched >> lane) & 1) // the owning lane turns the 20 sums into the 16 values of the gradient record
+        {
+            const float4 *sq = (const float4 *)(cst + lane * CS3B);
+            const float4 s0 = sq[0], s1 = sq[1], s2 = sq[2], s3 = sq[3], s4 = sq[4];
+            const float Z1 = s0.x, Z2 = s0.y, Dp = s2.x, S2 = s3.x;
+            const V3 Q1 = {s0.z, s0.w, s1.x}, Q2 = {s1.y, s1.z, s1.w}, Qd = {s2.y, s2.z, s2.w}, Nn = {s4.y, s4.z, s4.w};
+            const V3 e2 = vsub(ev2, ev1), e3 = vsub(ev3, ev1);
+            const V3 ne3 = vcross(en, e3), ne2 = vcross(en, e2), nQ1 = vcross(en, Q1), nQ2 = vcross(en, Q2);
+            const V3 gv1 = {Z2 * ne3.x - nQ2.x + Dp * en.x, Z2 * ne3.y - nQ2.y + Dp * en.y, Z2 * ne3.z - nQ2.z + Dp * en.z};
+            const V3 gv2 = {nQ1.x - Z1 * ne3.x, nQ1.y - Z1 * ne3.y, nQ1.z - Z1 * ne3.z};
+            const V3 gv3 = {Z1 * ne2.x - nQ1.x + nQ2.x, Z1 * ne2.y - nQ1.y + nQ2.y, Z1 * ne2.z - nQ1.z + nQ2.z};
+            const V3 eQ1 = vcross(vsub(e3, e2), Q1), Qe3 = vcross(Q2, e3);
+            const float zs = Z1 - S2;
+            const V3 gn = {Nn.x + zs * en.x + eQ1.x + Qe3.x - Qd.x, Nn.y + zs * en.y + eQ1.y + Qe3.y - Qd.y,
+                           Nn.z + zs * en.z + eQ1.z + Qe3.z - Qd.z};
+            float4 *gq = (float4 *)(cst + lane * CS3B); // grad-record order: gv1 gv2 gv3 gn dL/dopacity dL/drgb
+            gq[0] = make_float4(gv1.x, gv1.y, gv1.z, gv2.x);
+            gq[1] = make_float4(gv2.y, gv2.z, gv3.x, gv3.y);
+            gq[2] = make_float4(gv3.z, gn.x, gn.y, gn.z);
+            gq[3] = make_float4(s3.y /* dL/dopacity */, s3.z, s3.w, s4.x /* dL/drgb */);
+        }
         {
             const int sub = lane >> 4, col = lane & 15;
 #pragma unroll 1
