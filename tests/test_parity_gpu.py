@@ -237,3 +237,67 @@ def test_refstruct_mode_matches(monkeypatch):
     hf = helpers.hip_forward_backward(s, True)
     _check_state(s, hf, of)
     _check_outputs(hf, of, ob, True)
+
+
+def _robust_rel_l2(hip, ora, budget, exclude=None):
+    """rel-L2 over triangles after dropping `exclude` (bool mask) and the `budget` largest per-triangle errors."""
+    P = hip.shape[0]
+    err = np.linalg.norm((hip.astype(np.float64) - ora).reshape(P, -1), axis=1)
+    ref = np.linalg.norm(ora.astype(np.float64))
+    if exclude is not None:
+        err = np.where(exclude, 0.0, err)
+    if budget > 0:
+        err = np.sort(err)[: P - budget]
+    return np.sqrt((err ** 2).sum()) / ref
+
+
+@pytest.mark.parametrize("P,W,H,D,variant", [
+    (1_000_000, 1920, 1080, 3, 2),   # bench.py headline
+    (300_000, 800, 800, 3, 2),       # BASELINE.json configs[1]
+    (93_000, 1600, 1600, 0, 3),      # configs[3] (3D rasterizer, 800^2 x render_up_scale 2)
+])
+def test_full_size_against_oracle(P, W, H, D, variant):
+    """Full-size parity against the oracle itself (not only through properties).  The OpenMP oracle needs a many-core host
+    for this to stay within seconds (about 6 s for the headline on the GPU box); skipped on small hosts.
+
+    At 10^8 (pixel, triangle) pairs the DISCRETE decisions of the algorithm (arg-min barycentric, alpha >= 1/255,
+    T <= 1e-4) flip for a handful of pairs between any two fp32 evaluations (SURVEY.md 8c allows 1e-5 of pixels), and each
+    flip moves one pixel's worth of gradient between vertices.  Measured on the headline: dL_dvertex differs by 1.5e-3 over
+    all triangles but by 1.9e-5 once the 100 worst of 10^6 triangles are set aside.  So: images and the smooth gradients
+    (SH, opacity) must meet the bar outright; geometry gradients must meet a 10x TIGHTER bar (2D; the bar itself for 3D)
+    after an outlier budget of 2e-4 of the triangles.  For the 3D rasterizer, triangles seen within 2.9 degrees of edge-on are set aside as well:
+    there the reference's own fp32 ray/plane arithmetic is off by per cents (tests/triage notes)."""
+    import os
+    if (os.cpu_count() or 1) < 32:
+        pytest.skip("full-size oracle runs need a many-core host")
+    import test_parity3d_gpu as T3
+    s = synthetic.scene(P, W, H, D, seed=42)
+    of = helpers.oracle_forward(s, True, False, variant=variant)
+    ob = helpers.oracle_backward(s, of, True)
+    hf = helpers.hip_forward_backward(s, True, False, variant=variant)
+    assert hf["num_rendered"] == of["num_rendered"]
+    assert np.array_equal(hf["radii"], of["radii"])
+    for name in ("tiles_touched", "vals", "ranges"):
+        assert np.array_equal(helpers.hip_state(hf, s, name).astype(np.int64).reshape(-1),
+                              of["state"].field(name).astype(np.int64).reshape(-1)), name
+    nc_h = helpers.hip_state(hf, s, "n_contrib").astype(np.int64)
+    assert (nc_h != of["state"].field("n_contrib").astype(np.int64)).mean() <= OUTLIER_FRAC
+    for k in ("out_feature", "depth", "normal"):
+        assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k
+    grazing = None
+    if variant == 3:
+        st = of["state"]
+        c = (st.field("v1_view").astype(np.float64) + st.field("v2_view") + st.field("v3_view")) / 3.0
+        n = st.field("normal_view").astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            cosv = np.abs((c * n).sum(1)) / (np.linalg.norm(c, axis=1) * np.linalg.norm(n, axis=1))
+        grazing = np.nan_to_num(cosv, nan=1.0) < T3.GRAZING_COS
+        assert grazing.mean() < 0.1
+    budget = int(2e-4 * P) + 5
+    for k in ("contrib_sum", "contrib_max"):
+        assert _robust_rel_l2(hf[k], of[k], budget if variant == 3 else 0, grazing) < IMG_TOL, k
+    for k in ("dL_dshs", "dL_dopacity"):
+        assert _robust_rel_l2(hf[k], ob[k], budget if variant == 3 else 0, grazing) < GRAD_TOL, k
+    for k in ("dL_dvertex", "dL_dcenter2D"):
+        # 2D: 10x tighter than the bar once the flips are set aside; 3D: the bar itself (its fp32 barycentrics are ~100x noisier)
+        assert _robust_rel_l2(hf[k], ob[k], budget, grazing) < (GRAD_TOL if variant == 3 else 0.1 * GRAD_TOL), k
