@@ -96,3 +96,27 @@ def hip_state(res, s, name):
     g, b, im = res["buffers"]
     P = s["vertex"].shape[0]
     return _C.debug_read_state(name, P, res["num_rendered"], s["image_width"], s["image_height"], g, b, im).numpy()
+
+
+def grazing_mask(of, cos_limit):
+    """3D variant: triangles whose plane is seen within acos(cos_limit) of edge-on (from the oracle's view-space state).
+    There depth = v1.n / p_ray.n (R3D forward.cu:243-244) loses a factor 1 / cos of precision in ANY fp32 evaluation."""
+    st = of["state"]
+    c = (st.field("v1_view").astype(np.float64) + st.field("v2_view") + st.field("v3_view")) / 3.0
+    n = st.field("normal_view").astype(np.float64)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        cosv = np.abs((c * n).sum(1)) / (np.linalg.norm(c, axis=1) * np.linalg.norm(n, axis=1))
+    return np.nan_to_num(cosv, nan=1.0) < cos_limit
+
+
+def robust_rel_l2(hip, ora, budget, exclude=None, ref=None):
+    """rel-L2 over triangles after dropping `exclude` (bool mask) and the `budget` largest per-triangle errors; `ref`
+    overrides the norm the error is measured against."""
+    P = hip.shape[0]
+    err = np.linalg.norm((hip.astype(np.float64) - ora).reshape(P, -1), axis=1)
+    ref = np.linalg.norm(ora.astype(np.float64)) if ref is None else ref
+    if exclude is not None:
+        err = np.where(exclude, 0.0, err)
+    if budget > 0:
+        err = np.sort(err)[: P - budget]
+    return np.sqrt((err ** 2).sum()) / ref

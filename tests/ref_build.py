@@ -1,0 +1,55 @@
+"""Loader for the reference's own extensions built for gfx950 by oracle/build_ref.py (oracle/_ref/*.so; test infrastructure).
+Exposes thin wrappers with the calling convention of tests/helpers.py so that the same scenes can go through the oracle, the
+HIP product path and the REFERENCE's kernels."""
+from __future__ import annotations
+
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_cache = {}
+
+
+def load(name: str):
+    """name in {"_ref2d_C", "_ref3d_C", "_refknn_C"}; skips the calling test when the build is absent."""
+    if name not in _cache:
+        path = os.path.join(ROOT, "oracle", "_ref", name + ".so")
+        if not os.path.exists(path):
+            pytest.skip(f"{path} not built (python oracle/build_ref.py in the build container)")
+        import torch  # noqa: F401  (libtorch must be loaded before the extension)
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _cache[name] = mod
+    return _cache[name]
+
+
+def forward_backward(s, rich_info=True, back_culling=False, use_feature=False, variant=2, device="cuda"):
+    """One scene through the reference's rasterize_triangles / rasterize_triangles_backward (R2D/ext.cpp:6-8, R3D/ext.cpp)."""
+    import torch
+    ref = load("_ref2d_C" if variant == 2 else "_ref3d_C")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    empty = torch.empty(0, device=device)
+    shs = empty if use_feature else t(s["shs"])
+    feature = t(s["feature"]) if use_feature else empty
+    cam = (s["tanfovx"], s["tanfovy"], t(s["viewmatrix"]), t(s["projmatrix"]), t(s["campos"]), int(s["sh_degree"]), float(s["gamma"]),
+           float(s["scale_modifier"]), float(s["background_depth"]), t(s["background"]))
+    vertex, opacity = t(s["vertex"]), t(s["opacity"])
+    out = ref.rasterize_triangles(s["image_width"], s["image_height"], *cam, vertex, shs, feature, opacity, back_culling, rich_info, False)
+    n, img, radii, depth, normal, csum, cmax, gb, bb, ib = out
+    H, W = s["image_height"], s["image_width"]
+    g_depth = t(s["dL_dout_depth"]) if rich_info else torch.empty(0, device=device)
+    g_normal = t(s["dL_dout_normal"]) if rich_info else torch.empty(0, device=device)
+    bw = ref.rasterize_triangles_backward(*cam, vertex, shs, feature, opacity, n, radii, gb, bb, ib, t(s["dL_dout_feature"]), g_depth, g_normal,
+                                          rich_info, False)
+    torch.cuda.synchronize()
+    res = dict(num_rendered=int(n), out_feature=img.cpu().numpy(), radii=radii.cpu().numpy())
+    if rich_info:
+        res.update(depth=depth.cpu().numpy(), normal=normal.cpu().numpy(), contrib_sum=csum.cpu().numpy(), contrib_max=cmax.cpu().numpy())
+    dv, dc, dsh, df, dop = (x.cpu().numpy() for x in bw)
+    res.update(dL_dvertex=dv, dL_dcenter2D=dc, dL_dopacity=dop)
+    res["dL_dfeature" if use_feature else "dL_dshs"] = df if use_feature else dsh
+    return res

@@ -239,17 +239,7 @@ def test_refstruct_mode_matches(monkeypatch):
     _check_outputs(hf, of, ob, True)
 
 
-def _robust_rel_l2(hip, ora, budget, exclude=None, ref=None):
-    """rel-L2 over triangles after dropping `exclude` (bool mask) and the `budget` largest per-triangle errors; `ref`
-    overrides the norm the error is measured against."""
-    P = hip.shape[0]
-    err = np.linalg.norm((hip.astype(np.float64) - ora).reshape(P, -1), axis=1)
-    ref = np.linalg.norm(ora.astype(np.float64)) if ref is None else ref
-    if exclude is not None:
-        err = np.where(exclude, 0.0, err)
-    if budget > 0:
-        err = np.sort(err)[: P - budget]
-    return np.sqrt((err ** 2).sum()) / ref
+_robust_rel_l2 = helpers.robust_rel_l2
 
 
 @pytest.mark.parametrize("P,W,H,D,variant", [
@@ -287,12 +277,7 @@ def test_full_size_against_oracle(P, W, H, D, variant):
         assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k
     grazing = None
     if variant == 3:
-        st = of["state"]
-        c = (st.field("v1_view").astype(np.float64) + st.field("v2_view") + st.field("v3_view")) / 3.0
-        n = st.field("normal_view").astype(np.float64)
-        with np.errstate(invalid="ignore", divide="ignore"):
-            cosv = np.abs((c * n).sum(1)) / (np.linalg.norm(c, axis=1) * np.linalg.norm(n, axis=1))
-        grazing = np.nan_to_num(cosv, nan=1.0) < T3.GRAZING_COS
+        grazing = helpers.grazing_mask(of, T3.GRAZING_COS)
         assert grazing.mean() < 0.1
     budget = int(2e-4 * P) + 5
     for k in ("contrib_sum", "contrib_max"):
