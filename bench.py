@@ -233,6 +233,10 @@ def main():
             result["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(s, state["image"].detach().cpu().numpy(), 3 if args.rasterizer == "3D" else 2)
+            ref = reference_gpu_baseline(s, dev, args.rasterizer, state["image"].detach())
+            if ref is not None:
+                result["reference_gpu"] = ref
+                result["reference_gpu"]["speedup"] = round(result["value"] / ref["value"], 2)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
@@ -246,6 +250,47 @@ def hbm_traffic(kernel):
         return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+def reference_gpu_baseline(s, dev, rasterizer, hip_image):
+    """The REFERENCE's own rasterizer on this MI355X: oracle/_ref/_ref{2,3}d_C.so is the reference's extension compiled for
+    gfx950 from /root/reference by oracle/build_ref.py (baseline leg only, like cpu_baseline; None when it was not built).
+    Same scene, same upstream gradients, rasterize_triangles + rasterize_triangles_backward (R2D/ext.cpp:6-8) called
+    directly; 1 warm-up + 5 timed steps."""
+    import importlib.util
+    name = "_ref3d_C" if rasterizer == "3D" else "_ref2d_C"
+    path = os.path.join(ROOT, "oracle", "_ref", name + ".so")
+    if not os.path.exists(path):
+        return None
+    spec = importlib.util.spec_from_file_location(name, path)
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    W, H = s["image_width"], s["image_height"]
+    cam = (s["tanfovx"], s["tanfovy"], t(s["viewmatrix"]), t(s["projmatrix"]), t(s["campos"]), int(s["sh_degree"]), 1.0, 1.0,
+           float(s["background_depth"]), t(s["background"]))
+    vertex, shs, opacity, empty = t(s["vertex"]), t(s["shs"]), t(s["opacity"]), torch.empty(0, device=dev)
+    g = (t(s["dL_dout_feature"]), t(s["dL_dout_depth"]), t(s["dL_dout_normal"]))
+
+    def step():
+        out = ref.rasterize_triangles(W, H, *cam, vertex, shs, empty, opacity, False, True, False)
+        n, img, radii, depth, normal, csum, cmax, gb, bb, ib = out
+        ref.rasterize_triangles_backward(*cam, vertex, shs, empty, opacity, n, radii, gb, bb, ib, *g, True, False)
+        return img
+
+    img = step()
+    torch.cuda.synchronize()
+    steps = 5
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    rel = float((img - hip_image).norm() / img.norm())
+    return {"value": round(W * H / (ms * 1e-3) / 1e6, 3), "unit": "Mpix/s", "ms_per_step": round(ms, 3), "kind": "reference",
+            "sample": f"the reference's {rasterizer} extension built for gfx950 (oracle/build_ref.py), same scene, {steps} timed steps of "
+                      "rasterize_triangles + rasterize_triangles_backward",
+            "image_rel_l2_hip_vs_reference": rel}
 
 
 def cpu_baseline(s, hip_image, variant=2):

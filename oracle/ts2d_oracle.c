@@ -11,13 +11,20 @@
  * follows.  All per-pair / per-triangle arithmetic is fp32 in the reference's
  * expression order; build with -ffp-contract=off so no FMA is formed.
  *
- * PARITY PINNING STATUS: "parity unpinned" for the rasterizer as a whole.
- *   - The reference has no tests, golden vectors or fixtures for this path
- *      and its implementation is CUDA (.cu + CUB), which
- *     cannot be compiled or run in this image (no nvcc, no GPU); building it
- *     would need stand-in CUDA/CUB/torch headers, which is not allowed.
- *   - Pinned sub-parts: the SH colour polynomial is checked against the
- *     reference's own Python `eval_sh` (src/diff_recon/utils/sh_utils.py:41-100)
+ * PARITY PINNING STATUS: pinned against the reference's own kernels.
+ *   - The reference ships no tests, golden vectors or fixtures for this path
+ *     (SURVEY.md section 4), and it is CUDA, so nothing can be pinned on a CPU.
+ *     But the image carries the toolchain that installs CUDA extensions on ROCm
+ *     (hipify-perl, hipcc, hipCUB / rocThrust, PyTorch): oracle/build_ref.py
+ *     compiles the reference's three extensions for gfx950 from the sources
+ *     where they lie into oracle/_ref/*.so (no stand-in headers, nothing
+ *     copied; the recipe's header lists every deviation), and
+ *     tests/test_reference_gpu.py runs the reference's kernels on the MI355X
+ *     against THIS oracle (2D and 3D variants, seven configurations each:
+ *     integer state equal, images ~1e-5, gradients ~1e-5..1e-4) and against the
+ *     HIP product path directly, up to the headline size.
+ *   - Pinned on the CPU as well: the SH colour polynomial against the
+ *     reference's Python `eval_sh` (src/diff_recon/utils/sh_utils.py:41-100)
  *     and the camera/matrix convention against src/diff_recon/utils/camera.py
  *     through committed fixtures (tests/golden/, generator script alongside).
  *   - The backward is additionally cross-checked against float64 torch autograd

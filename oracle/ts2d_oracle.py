@@ -6,7 +6,7 @@ cpu_baseline leg; the product package never imports this module.
 The functions mirror the reference's pybind entry points `rasterize_triangles` /
 `rasterize_triangles_backward` (R2D/ext.cpp:6-8, R2D/src/extension_interface.h:7-62) with numpy
 arrays in place of torch tensors.  Parity status of the oracle itself: see the header of
-ts2d_oracle.c ("parity unpinned" except the SH polynomial and the camera convention).
+ts2d_oracle.c (pinned against the reference's own kernels built for gfx950, oracle/build_ref.py + tests/test_reference_gpu.py).
 """
 from __future__ import annotations
 

@@ -4,8 +4,9 @@ Both functions of submodules/simple-knn are exact searches (simple_knn.cu:153-23
 the oracle is the definition itself, evaluated with scipy's exact k-d tree in float64:
     mean_dist3(points)[i]      = mean of the 3 smallest |p_i - p_j|^2, j != i          (simple_knn.cu:153-187)
     nearest_other(points, g)[i] = argmin_j |p_i - p_j|^2 over j // g != i // g           (simple_knn.cu:189-235)
-Parity status: the reference (CUDA + CUB + thrust) cannot be built in this image and ships no expected outputs
-(main.cu:50-75 only prints), so nothing pins this beyond the mathematics: "parity unpinned".
+Parity status: the reference ships no expected outputs (main.cu:50-75 only prints); its extension built for gfx950
+(oracle/build_ref.py -> oracle/_ref/_refknn_C.so) is compared with the product on the GPU (tests/test_reference_gpu.py:
+distances to 2e-6, indices exactly), which pins the tie rule that this float64 oracle cannot.
 Only tests/ may import this module.
 """
 from __future__ import annotations

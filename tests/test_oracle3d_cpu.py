@@ -1,8 +1,8 @@
 """CPU tests of the oracle's 3D variant (rasterizer_type "3D"; oracle/ts2d_oracle.c, R3D citations there).
 
-Parity status: like the 2D path, the reference's 3D CUDA extension cannot be built or run in this image and its
-repository holds no golden vectors for it, so the 3D restatement is pinned only through (a) the shared SH / camera
-fixtures of test_oracle_cpu.py and (b) the independent float64 autograd model below ("parity unpinned" otherwise)."""
+Parity status: like the 2D path, the 3D restatement is pinned on the GPU against the reference's own 3D extension built
+for gfx950 (tests/test_reference_gpu.py); on the CPU through (a) the shared SH / camera fixtures of test_oracle_cpu.py and
+(b) the independent float64 autograd model below."""
 import numpy as np
 
 import helpers

@@ -1,10 +1,10 @@
 """CPU tests of the oracle (no GPU): golden fixtures generated from the reference's own Python, hand-checked
 integer semantics, and an independent float64 autograd restatement of the forward model for the gradients.
 
-Pinning status (see oracle/ts2d_oracle.c header): the reference ships no tests/golden vectors for the rasterizer and
-its CUDA cannot be built here, so the rasterizer as a whole is "parity unpinned"; what CAN be pinned against the
-reference's own code is pinned here: the SH colour polynomial (sh_utils.eval_sh) and the camera/matrix convention
-(camera.Camera).
+Pinning status (see oracle/ts2d_oracle.c header): the reference ships no tests/golden vectors for the rasterizer; the
+rasterizer as a whole is pinned on the GPU against the reference's own kernels built for gfx950
+(tests/test_reference_gpu.py).  What can be pinned WITHOUT a GPU is pinned here: the SH colour polynomial
+(sh_utils.eval_sh) and the camera/matrix convention (camera.Camera).
 """
 import math
 import os
