@@ -17,7 +17,7 @@
  *     But the image carries the toolchain that installs CUDA extensions on ROCm
  *     (hipify-perl, hipcc, hipCUB / rocThrust, PyTorch): oracle/build_ref.py
  *     compiles the reference's three extensions for gfx950 from the sources
- *     where they lie into oracle/_ref/*.so (no stand-in headers, nothing
+ *     where they lie into oracle/_ref/ (shared objects; no stand-in headers, nothing
  *     copied; the recipe's header lists every deviation), and
  *     tests/test_reference_gpu.py runs the reference's kernels on the MI355X
  *     against THIS oracle (2D and 3D variants, seven configurations each:
