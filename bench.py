@@ -74,8 +74,6 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--mode", default="product", choices=["product", "refstruct"],
-                    help="refstruct = reference-structured blend kernels (measurement aid, BASELINE.md section 3)")
     ap.add_argument("--rasterizer", default="2D", choices=["2D", "3D"],
                     help="2D = the headline path (BASELINE.json); 3D = the ray/plane variant (SURVEY.md 8f rank 1), not the headline")
     ap.add_argument("--dense-exchange", action="store_true",
@@ -83,8 +81,6 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
 
-    if args.mode == "refstruct":
-        os.environ["TS2D_MODE"] = "refstruct"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -207,7 +203,7 @@ def main():
         "value": round(mpix_s, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"mode": args.mode, "rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
+        "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
                    "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N,
                    "parallelism": f"image-parallel x{world}" + ((", RCCL all-reduce of 12 floats/triangle + all-gather of factored SH grads (3 floats/triangle/view)" if factored
                                        else ", RCCL all-reduce of dense per-triangle grads (60 floats/triangle)") if world > 1 else ""),

@@ -36,7 +36,6 @@ SOURCES = {
     "binning.hip": [],
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
     "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
-    "refstruct.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],  # measurement aid (TS2D_MODE=refstruct)
     "api.hip": [],
 }
 HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),

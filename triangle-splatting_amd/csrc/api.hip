@@ -152,8 +152,6 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.ablate = ab ? atoi(ab) : 0;
     const char *bw = getenv("TS2D_BWD");
     r.bwd_mfma = (bw && strcmp(bw, "mfma") == 0) ? 1 : 0;
-    const char *mode = getenv("TS2D_MODE");
-    r.refstruct = (mode && strcmp(mode, "refstruct") == 0) ? 1 : 0;
     return r;
 }
 } // namespace
@@ -274,8 +272,6 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
         if (flags & TS2D_FLAG_3D)
             ts_launch_render3d_fwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
                                    out->contrib_sum, out->contrib_max, s);
-        else if (r.refstruct)
-            ts_launch_refstruct_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
         else
             ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
     }
@@ -323,8 +319,6 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
         if (flags & TS2D_FLAG_3D)
             ts_launch_render3d_bwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
                                    loss->dL_dout_normal, grad_rec, s);
-        else if (r.refstruct)
-            ts_launch_refstruct_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
         else
             ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
     }

@@ -160,7 +160,6 @@ struct RenderArgs
     bool rich_info;
     int ablate; // profiling only (env TS2D_ABLATE, builds with -DTS2D_ABLATION): 0 = full kernel; see render.hip
     int bwd_mfma;  // experiment (env TS2D_BWD=mfma): render_bwd forms its per-entry sums with f32 MFMA instead of VALU reduction networks
-    int refstruct; // measurement aid (env TS2D_MODE=refstruct): reference-structured blend kernels, see refstruct.hip
 };
 void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                           const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
@@ -168,12 +167,6 @@ void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const
 void ts_launch_render_bwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                           const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
                           const float *dL_dout_normal, float *grad_rec, hipStream_t s);
-void ts_launch_refstruct_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
-                             const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
-                             float *contrib_sum, float *contrib_max, hipStream_t s);
-void ts_launch_refstruct_bwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
-                             const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
-                             const float *dL_dout_normal, float *grad_rec, hipStream_t s);
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                               float *dL_dfeature, float *dL_dopacity, hipStream_t s);
