@@ -110,7 +110,8 @@ def build(force: bool = False):
     if not available():
         raise RuntimeError("/root/reference or hipify-perl is not present: the reference build exists only as the prebuilt oracle/_ref/*.so")
     os.makedirs(OUT, exist_ok=True)
-    return [build_one(n, force) for n in EXTENSIONS]
+    with ThreadPoolExecutor(max_workers=len(EXTENSIONS)) as ex:  # hipcc on torch headers is slow: overlap the three extensions
+        return list(ex.map(lambda n: build_one(n, force), EXTENSIONS))
 
 
 if __name__ == "__main__":
