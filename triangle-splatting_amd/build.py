@@ -34,8 +34,8 @@ SOURCES = {
     "knn.hip": [],
     "model_update.hip": [],
     "binning.hip": [],
-    "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
-    "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"],
+    "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
+    "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "api.hip": [],
 }
 HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
