@@ -66,7 +66,12 @@ __device__ __forceinline__ void swap16(float &a, float &b) // odd rows of a <-> 
 // the 16 values; the four lanes of a quad hold the same value and the 16 quads hold the 16 different values.
 // Which value a lane ends up with is discovered once per wave by reducing indicator inputs (slot_of_lane()).
 struct OpAdd { __device__ __forceinline__ float operator()(float a, float b) const { return a + b; } };
-struct OpMax { __device__ __forceinline__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+// Maximum of NON-NEGATIVE floats on their bit patterns: for x, y >= 0 the integer order equals the float order, and
+// v_max_i32 needs none of the NaN-quieting (v_max_f32 x, x) that IEEE-mode fmaxf drags in after every cross-lane move.
+struct OpMax
+{
+    __device__ __forceinline__ float operator()(float a, float b) const { return __int_as_float(max(__float_as_int(a), __float_as_int(b))); }
+};
 
 template <typename Op>
 __device__ __forceinline__ float reduce16(float (&v)[16], int lane, Op op)
