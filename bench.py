@@ -223,7 +223,7 @@ def main():
             result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom),
                                   "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(dom_avg, 4),
-                                  "launches_timed": dom_n,
+                                  "launches_timed": dom_n, "valu": valu_util(dom),
                                   "note": "blend kernels are VALU-bound (PMC), not HBM-bound; see DESIGN.md section 4"}
         else:
             result["roofline"] = None
@@ -236,6 +236,17 @@ def main():
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def valu_util(kernel):
+    """VALU utilisation of `kernel` from the committed SQ-counter pass (profiles/valu_util.json, tools/collect_valu_util.sh):
+    the blend kernels are bound by VALU issue, so this -- not the HBM fraction -- is the roofline they sit on."""
+    try:
+        v = json.load(open(os.path.join(ROOT, "profiles", "valu_util.json"))).get(kernel)
+        return None if v is None else {"busy_frac": v["valu_busy_frac"], "cycles_per_inst": v["cycles_per_valu_inst"],
+                                       "insts_per_launch": v["valu_insts_per_launch"]}
+    except Exception:
+        return None
 
 
 def hbm_traffic(kernel):
