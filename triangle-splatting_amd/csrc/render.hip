@@ -9,18 +9,23 @@
 // shared-memory batches, two __syncthreads per batch, per-(pixel,triangle) global atomics):
 //
 //   * one wave64 per 8x8 pixel quadrant; the four quadrant waves of a tile form one 256-thread workgroup so
-//     their record gathers share the CU's L1, but they never synchronise (no LDS, no barrier) and each
-//     terminates as soon as its own 64 pixels are saturated;
+//     their record gathers share the CU's L1, but they never synchronise (all LDS is wave-private, no barrier)
+//     and each terminates as soon as its own 64 pixels are saturated;
 //   * a batch = 64 list entries, one per lane: each lane gathers its entry's 64-byte record with four dwordx4
 //     loads, does the per-(entry,quadrant) setup once (edge functions as affine forms of the in-quadrant pixel
-//     offset, conservative support box) and the wave ballots the entries whose support box meets the quadrant;
-//   * the wave then walks the set bits of that ballot (s_ff1 / s_flbit); per-entry constants reach all lanes
-//     through v_readlane (SGPR broadcast), and the per-pixel test is 4 FMAs + min3 + 2 compares;
-//   * backward: the 16 per-triangle gradient terms of the 64 pixels are reduced inside the wave by a
-//     transpose-reduce network (v_permlane32_swap / v_permlane16_swap / DPP, 35 VALU ops instead of 16 x 6 for
-//     independent butterflies) that leaves each of the 16 sums in a distinct lane quad, so one 16-lane
-//     global_atomic_add_f32 on the triangle's 64-byte gradient record replaces the reference's 16 x 64
-//     atomics per (tile quadrant, triangle).
+//     offset; conservative support factor from alpha >= 1/255; bounding-box + separating-axis test against the
+//     8x8 sample box) and the wave ballots the entries that can touch the quadrant (99.7 % of them then do);
+//   * the wave then walks the set bits of that ballot (s_ff1 / s_flbit); per-entry constants reach all lanes as
+//     LDS broadcasts (ds_read_b128 at a wave-uniform address), and the per-pixel test is 4 FMAs + min3 + 2 compares;
+//   * forward: contrib_sum / contrib_max contributions are parked in LDS and reduced 8 entries at a time by two
+//     transpose-reduce passes, so 8 entries cost one 8-lane atomic add and one 8-lane atomic max;
+//   * backward: one scalar back-to-front composite per pixel instead of seven; every gradient term is a zeroth or
+//     first pixel moment of three per-pair scalars, so the loop forms 19 products per lane, reduces them inside the
+//     wave with transpose-reduce networks (v_permlane32_swap / v_permlane16_swap / DPP) that leave each sum in a
+//     distinct lane quad, parks them in the entry's own (by then dead) LDS row, and once per batch the lane that
+//     owns an entry turns its 19 sums into the 16 gradient values, flushed as one 16-lane global_atomic_add_f32
+//     per 64-byte gradient record -- instead of the reference's 16 x 64 atomics per (tile quadrant, triangle).
+//     An f32-MFMA formulation of the same sums exists (TS2D_BWD=mfma) and is ~10 % slower, see below.
 //
 // Skipping entries by the support box cannot change results: an entry is only skipped for a quadrant when no
 // pixel of the quadrant can pass the reference's own tests (0 <= ecc <= 10 and alpha >= 1/255), and
