@@ -119,4 +119,5 @@ def robust_rel_l2(hip, ora, budget, exclude=None, ref=None):
         err = np.where(exclude, 0.0, err)
     if budget > 0:
         err = np.sort(err)[: P - budget]
-    return np.sqrt((err ** 2).sum()) / ref
+    d = np.sqrt((err ** 2).sum())
+    return d / ref if ref > 0 else d

@@ -39,7 +39,8 @@ def _check_state3d(s, hf, of, use_feature=False):
     assert np.array_equal(helpers.hip_state(hf, s, "depth")[vis], st.field("depth")[vis])
     nc_h = helpers.hip_state(hf, s, "n_contrib").astype(np.int64)
     nc_o = st.field("n_contrib").astype(np.int64)
-    assert (nc_h != nc_o).mean() <= OUTLIER_FRAC
+    # termination (T <= 1e-4) and the alpha threshold are fp32-rounding-sensitive per pixel: a budget, at least 2 pixels
+    assert (nc_h != nc_o).sum() <= max(2, OUTLIER_FRAC * nc_h.size)
 
 
 GRAZING_COS = 0.05  # triangles seen within ~2.9 degrees of edge-on

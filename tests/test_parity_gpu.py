@@ -49,7 +49,8 @@ def _check_state(s, hf, of):
     assert np.array_equal(helpers.hip_state(hf, s, "rgb")[vis], st.field("rgb")[vis])
     nc_h = helpers.hip_state(hf, s, "n_contrib").astype(np.int64)
     nc_o = st.field("n_contrib").astype(np.int64)
-    assert (nc_h != nc_o).mean() <= OUTLIER_FRAC
+    # termination (T <= 1e-4) and the alpha threshold are fp32-rounding-sensitive per pixel: a budget, at least 2 pixels
+    assert (nc_h != nc_o).sum() <= max(2, OUTLIER_FRAC * nc_h.size)
 
 
 def _check_outputs(hf, of, ob, rich, use_feature=False):
