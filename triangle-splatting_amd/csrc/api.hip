@@ -148,10 +148,13 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.gamma = geom->gamma; r.background_depth = geom->background_depth;
     r.background = geom->background;
     r.rich_info = flags & TS2D_FLAG_RICH_INFO;
-    const char *ab = getenv("TS2D_ABLATE");
-    r.ablate = ab ? atoi(ab) : 0;
-    const char *bw = getenv("TS2D_BWD");
-    r.bwd_mfma = (bw && strcmp(bw, "mfma") == 0) ? 1 : 0;
+    // measurement / triage switches, read ONCE per process (none of them is needed by the product path)
+    static const int s_ablate = [] { const char *e = getenv("TS2D_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int s_mfma = [] { const char *e = getenv("TS2D_BWD"); return (e && strcmp(e, "mfma") == 0) ? 1 : 0; }();
+    static const int s_legacy = [] { const char *e = getenv("TS2D_BLEND"); return (e && strcmp(e, "wave") == 0) ? 1 : 0; }();
+    r.ablate = s_ablate;
+    r.bwd_mfma = s_mfma;
+    r.legacy_blend = s_legacy;
     return r;
 }
 } // namespace
@@ -272,8 +275,10 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
         if (flags & TS2D_FLAG_3D)
             ts_launch_render3d_fwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
                                    out->contrib_sum, out->contrib_max, s);
-        else
+        else if (r.legacy_blend)
             ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+        else
+            ts_launch_render_fwd_group(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
     }
     TS_CHECK(flags, s, "render_fwd");
     return TS2D_OK;
@@ -319,8 +324,10 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
         if (flags & TS2D_FLAG_3D)
             ts_launch_render3d_bwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
                                    loss->dL_dout_normal, grad_rec, s);
-        else
+        else if (r.legacy_blend || r.bwd_mfma)
             ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
+        else
+            ts_launch_render_bwd_group(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
     }
     TS_CHECK(flags, s, "render_bwd");
     {

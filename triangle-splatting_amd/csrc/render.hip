@@ -657,6 +657,9 @@ __global__ void __launch_bounds__(256, MFMA ? 4 : 7) render_bwd_kernel(RenderArg
                 if ((touched >> e) & 1)
                 {
                     const uint32_t eid = __float_as_uint(cst[e * CST + 19]);
+#ifdef TS2D_ABLATION
+                    if (a.ablate == 4) continue; // profiling: no gradient-record atomics
+#endif
                     if (RICH || col < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + col, sums[e * CST + col]);
                 }
             }

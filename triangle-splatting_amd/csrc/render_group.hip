@@ -1,0 +1,633 @@
+// render_group.hip -- per-pixel alpha blend (forward) and its back-to-front replay (backward), lane-group edition.
+//
+// Behaviour follows FORWARD::renderCUDA (R2D/src/forward.cu:198-355) and BACKWARD::renderCUDA
+// (R2D/src/backward.cu:265-493); SURVEY.md Appendix B lists the quirks that are kept (integer pixel centres, n_contrib
+// counts examined entries, stop AFTER the triangle that drives T <= 1e-4, dL_dopacity not gated by the 0.99 clamp,
+// arg-min tie order a1, a2, a3, division by ecc + 1e-8).
+//
+// Why this structure (measured on MI355X, profiles/r02_notes.md):
+//   * a blended (triangle, 8x8 quadrant) pair touches 18 of the 64 pixels on average, so one triangle per wave
+//     iteration leaves 72 % of the lanes idle, and gfx950 does not skip an all-idle 32-lane pass;
+//   * on gfx950 only fma/add/mul (f32) and add/and (u32) issue at the full 32-lanes-per-clock rate; v_cmp, v_cndmask,
+//     v_min/max, every DPP form and the integer shift/mad forms are half rate, transcendentals and v_permlane*_swap
+//     quarter rate -- the blend loops are bound by exactly those, not by FMAs.
+// So: one wave64 still owns one 8x8 pixel quadrant of a 16x16 tile, but its lanes form FOUR 16-lane groups, one per 4x4
+// pixel block, and every group walks ITS OWN culled list of the batch's triangles: four different triangles are blended
+// per wave step (lane occupancy 28 % -> ~45 %), the per-step body is branch-free, and all cross-lane reductions stay
+// inside a 16-lane DPP row (no v_permlane*_swap).
+//
+//   batch   = 64 list entries, one per lane: the lane gathers the 64-byte render record, computes the conservative
+//             support of the triangle (edge functions as affine forms of the in-quadrant pixel offset, used for CULLING
+//             only) against the four 4x4 blocks, and the wave ballots one 64-bit mask per block;
+//   lists   = each block's surviving entries, compacted in visiting order into a 64-byte LDS list (v_mbcnt rank);
+//   step    = every lane reads ITS group's next entry index, then that entry's constants from the wave-private LDS
+//             table (4 distinct rows per ds_read_b128 cost the same as one broadcast row, tools/valu_bench2.hip); a group
+//             whose list is exhausted reads the dummy row -1, which no pixel can hit;
+//   pixels  = barycentrics are evaluated exactly as the reference does, cross(v_j - p, v_k - p) / area2 from
+//             pixel-relative vertex offsets (v - tile origin and (v - origin) - offset are exact in fp32, so the offsets
+//             are bit-identical to the reference's).  Round 1 used affine forms of the pixel offset instead: 4 FMAs
+//             cheaper, but ~10x noisier on sub-pixel slivers, where the 1/area2 amplification turns 1e-6 into 1e-3
+//             (profiles/r02_noise_floor_1M_before.json) -- the gradients of those few triangles dominate the norm.
+#include "ts2d_common.h"
+#include "ts2d_wave.h"
+
+#ifndef TSG_PROBE
+#define TSG_PROBE 0 // profiling builds: 1 = no contribution atomics, 2 = no contribution statistics at all (results wrong)
+#endif
+namespace
+{
+constexpr int ROW = 20; // floats per entry row of the constants table:
+//   [0..3] u1x u1y u2x u2y   [4..7] u3x u3y 1/area2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [17] id
+//   [18] [19] forward: the wave's running contrib_sum / contrib_max of the entry
+// (u_k = screen vertex k relative to the quadrant origin); row -1 is a dummy that fails every pixel's ecc test.
+
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int lane_rank(unsigned long long m) // set bits of m below this lane
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+struct BlockCull
+{
+    float u1x, u1y, u2x, u2y, u3x, u3y, ia;
+    bool ov[4]; // the triangle's support (alpha >= 1/255 and ecc <= 10) can reach block g = (by >> 2) * 2 + (bx >> 2)
+};
+
+// Conservative culling of one triangle against the four 4x4 sample blocks of the quadrant whose origin is (OX, OY).
+// The affine forms a_k(q) = A_k qx + B_k qy + C_k are used ONLY here; their rounding error (up to ~(|C| + 7|A| + 7|B|) ulp
+// for sub-pixel slivers) is added to the acceptance margin so that no pixel the exact test would blend is ever culled.
+template <bool GAMMA1>
+__device__ __forceinline__ BlockCull block_cull(float v1x, float v1y, float v2x, float v2y, float v3x, float v3y, float op, float g2,
+                                                float OX, float OY)
+{
+    BlockCull s;
+    // area2 exactly as preprocess evaluates (and the reference stores) it: cross(v2 - v1, v3 - v1) without contraction
+    const float area2 = __fsub_rn(__fmul_rn(v2x - v1x, v3y - v1y), __fmul_rn(v2y - v1y, v3x - v1x)); // forward.cu:137
+    s.ia = 1.0f / area2;
+    s.u1x = v1x - OX; s.u1y = v1y - OY; s.u2x = v2x - OX; s.u2y = v2y - OY; s.u3x = v3x - OX; s.u3y = v3y - OY;
+    const float C1 = (s.u2x * s.u3y - s.u2y * s.u3x) * s.ia, A1 = (v2y - v3y) * s.ia, B1 = (v3x - v2x) * s.ia;
+    const float C2 = (s.u3x * s.u1y - s.u3y * s.u1x) * s.ia, A2 = (v3y - v1y) * s.ia, B2 = (v1x - v3x) * s.ia;
+    const float A3 = -A1 - A2, B3 = -B1 - B2, C3 = 1.0f - C1 - C2;
+    // alpha >= 1/255 needs ecc^(2 gamma) <= 2 ln(255 op); ecc <= E is the triangle scaled by E about its centroid
+    const float t = 255.0f * op;
+    float E = -1.0f;
+    if (t >= 1.0f)
+    {
+        const float L = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(t);
+        if (GAMMA1) E = __builtin_amdgcn_sqrtf(L);
+        else E = (g2 < 1e-6f) ? 10.0f : pow_nonneg(L, 1.0f / g2);
+        E = fminf(E * 1.0005f + 0.002f, 10.01f);
+    }
+    const float cx = (s.u1x + s.u2x + s.u3x) * (1.0f / 3.0f), cy = (s.u1y + s.u2y + s.u3y) * (1.0f / 3.0f);
+    const float e1x = E * (s.u1x - cx), e2x = E * (s.u2x - cx), e3x = E * (s.u3x - cx);
+    const float e1y = E * (s.u1y - cy), e2y = E * (s.u2y - cy), e3y = E * (s.u3y - cy);
+    const float pad = 0.05f;
+    const float bminx = cx + fminf(fminf(e1x, e2x), e3x) - pad, bmaxx = cx + fmaxf(fmaxf(e1x, e2x), e3x) + pad;
+    const float bminy = cy + fminf(fminf(e1y, e2y), e3y) - pad, bmaxy = cy + fmaxf(fmaxf(e1y, e2y), e3y) + pad;
+    const bool live = E > 0.0f;
+    const bool x0 = live && bminx <= 3.0f && bmaxx >= 0.0f, x1 = live && bminx <= 7.0f && bmaxx >= 4.0f;
+    const bool y0 = bminy <= 3.0f && bmaxy >= 0.0f, y1 = bminy <= 7.0f && bmaxy >= 4.0f;
+    // separating axes = the three edge normals: ecc <= E  <=>  min_k a_k >= (1 - E) / 3, and the maximum of a_k over the
+    // 4x4 sample box at (bx, by) is C_k + A_k bx + B_k by + max(0, 3 A_k) + max(0, 3 B_k)
+    const float m = (1.0f - E) * (1.0f / 3.0f);
+    const float k1 = C1 + fmaxf(0.0f, 3.0f * A1) + fmaxf(0.0f, 3.0f * B1) - m + 1e-6f * (fabsf(C1) + 7.0f * (fabsf(A1) + fabsf(B1)));
+    const float k2 = C2 + fmaxf(0.0f, 3.0f * A2) + fmaxf(0.0f, 3.0f * B2) - m + 1e-6f * (fabsf(C2) + 7.0f * (fabsf(A2) + fabsf(B2)));
+    const float k3 = C3 + fmaxf(0.0f, 3.0f * A3) + fmaxf(0.0f, 3.0f * B3) - m + 1e-6f * (fabsf(C3) + 7.0f * (fabsf(A3) + fabsf(B3)));
+    const float ax1 = 4.0f * A1, ax2 = 4.0f * A2, ax3 = 4.0f * A3, by1 = 4.0f * B1, by2 = 4.0f * B2, by3 = 4.0f * B3;
+    s.ov[0] = x0 && y0 && k1 >= 0.0f && k2 >= 0.0f && k3 >= 0.0f;
+    s.ov[1] = x1 && y0 && k1 + ax1 >= 0.0f && k2 + ax2 >= 0.0f && k3 + ax3 >= 0.0f;
+    s.ov[2] = x0 && y1 && k1 + by1 >= 0.0f && k2 + by2 >= 0.0f && k3 + by3 >= 0.0f;
+    s.ov[3] = x1 && y1 && k1 + ax1 + by1 >= 0.0f && k2 + ax2 + by2 >= 0.0f && k3 + ax3 + by3 >= 0.0f;
+    return s;
+}
+
+__device__ __forceinline__ void publish_row(float *row, const BlockCull &s, uint32_t id, const float4 &r1, const float4 &r2, const float4 &r3)
+{
+    float4 *q = (float4 *)row;
+    q[0] = make_float4(s.u1x, s.u1y, s.u2x, s.u2y);
+    q[1] = make_float4(s.u3x, s.u3y, s.ia, r1.z);
+    q[2] = make_float4(r1.w, r2.x, r2.y, r2.z);
+    q[3] = make_float4(r2.w, r3.x, r3.y, r3.z);
+    q[4] = make_float4(r3.w, __uint_as_float(id), 0.0f, 0.0f); // [18] [19]: this wave's contrib_sum / contrib_max of the entry
+}
+
+// Row -1: a unit triangle a thousand pixels away with opacity 0 -> every pixel of the quadrant sees ecc ~ 3000 and alpha 0.
+__device__ __forceinline__ void write_dummy_row(float *cst, int lane)
+{
+    if (lane < ROW)
+    {
+        float v = 0.0f;
+        if (lane == 0 || lane == 1 || lane == 3 || lane == 4) v = 1000.0f;
+        if (lane == 2 || lane == 5) v = 1001.0f;
+        if (lane == 6) v = 1.0f;
+        cst[lane - ROW] = v;
+    }
+}
+
+// The reference's per-pixel barycentrics (forward.cu:299-305, backward.cu:383-391): p_vk = v_k - pixel, a1 = cross(p_v2, p_v3) / area2,
+// a2 = cross(p_v3, p_v1) / area2, a3 = 1 - a1 - a2, ecc = 1 - 3 min(a).  Division by area2 becomes a multiplication by its
+// correctly rounded reciprocal (<= 1 ulp apart).
+struct Bary { float p1x, p1y, p2x, p2y, p3x, p3y, a1, a2, a3, mn, ecc; };
+__device__ __forceinline__ Bary barycentrics(const float4 &q0, const float4 &q1, float fx, float fy)
+{
+    Bary b;
+    b.p1x = q0.x - fx; b.p1y = q0.y - fy; b.p2x = q0.z - fx; b.p2y = q0.w - fy; b.p3x = q1.x - fx; b.p3y = q1.y - fy;
+    b.a1 = (b.p2x * b.p3y - b.p2y * b.p3x) * q1.z;
+    b.a2 = (b.p3x * b.p1y - b.p3y * b.p1x) * q1.z;
+    b.a3 = 1.0f - b.a1 - b.a2;
+    b.mn = fminf(fminf(b.a1, b.a2), b.a3);
+    b.ecc = fmaf(-3.0f, b.mn, 1.0f);
+    return b;
+}
+// 0 <= ecc <= 10 (forward.cu:307) as ONE unsigned compare: negative floats and NaN have larger bit patterns than 10.0f
+__device__ __forceinline__ bool ecc_in_range(float ecc) { return __float_as_uint(ecc) <= 0x41200000u; }
+
+// ---- 16-lane (DPP row) transpose-reduce: N values per lane -> each lane keeps the row-wide reduction of ONE value ----
+// Level 1 pairs lanes l, l ^ 8 (row_ror:8), level 2 lanes inside a group of 8 (row_half_mirror), level 3 l, l ^ 2, then l, l ^ 1.
+struct RowSel
+{
+    bool b3, b2, b1;
+    __device__ __forceinline__ explicit RowSel(int lane) : b3(lane & 8), b2(lane & 4), b1(lane & 2) {}
+};
+template <typename Op>
+__device__ __forceinline__ float pair_ror8(float x, float y, bool b, Op op)
+{
+    const float own = b ? y : x, oth = b ? x : y;
+    return op(own, dpp<DPP_ROR8>(oth));
+}
+template <typename Op>
+__device__ __forceinline__ float pair_hmir(float x, float y, bool b, Op op)
+{
+    const float own = b ? y : x, oth = b ? x : y;
+    return op(own, dpp<DPP_HALF_MIRROR>(oth));
+}
+template <typename Op>
+__device__ __forceinline__ float pair_xor2(float x, float y, bool b, Op op)
+{
+    const float own = b ? y : x, oth = b ? x : y;
+    return op(own, dpp<DPP_XOR2>(oth));
+}
+// 8 values: the result of value (b3 + 2 b2 + 4 b1) lands in lanes l and l ^ 1
+template <typename Op>
+__device__ __forceinline__ float row_reduce8(const float (&c)[8], const RowSel &r, Op op)
+{
+    const float s0 = pair_ror8(c[0], c[1], r.b3, op), s1 = pair_ror8(c[2], c[3], r.b3, op);
+    const float s2 = pair_ror8(c[4], c[5], r.b3, op), s3 = pair_ror8(c[6], c[7], r.b3, op);
+    const float t0 = pair_hmir(s0, s1, r.b2, op), t1 = pair_hmir(s2, s3, r.b2, op);
+    const float v = pair_xor2(t0, t1, r.b1, op);
+    return op(v, dpp<DPP_XOR1>(v));
+}
+__device__ __forceinline__ uint32_t row_select8(const uint32_t (&c)[8], const RowSel &r)
+{
+    const uint32_t s0 = r.b3 ? c[1] : c[0], s1 = r.b3 ? c[3] : c[2], s2 = r.b3 ? c[5] : c[4], s3 = r.b3 ? c[7] : c[6];
+    const uint32_t t0 = r.b2 ? s1 : s0, t1 = r.b2 ? s3 : s2;
+    return r.b1 ? t1 : t0;
+}
+
+#ifdef TS2D_STATS
+// Profiling builds only (-DTS2D_STATS), read with ts2d_stats_read_group():
+// [0] list entries visited (per quadrant wave)  [1] (entry, block) pairs surviving the cull  [2] wave steps  [3] windows
+// [4] (pixel, entry) pairs blended  [5] quadrant waves  [6] batches with work  [7] (entry, quadrant) pairs surviving
+__device__ unsigned long long g_stats_group[8];
+#define TSG_STAT(i, v) stat_acc[i] += (unsigned long long)(v)
+#else
+#define TSG_STAT(i, v)
+#endif
+
+template <bool RICH, bool GAMMA1>
+__global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+                                                                const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
+                                                                float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                                float *__restrict__ out_feature, float *__restrict__ out_depth,
+                                                                float *__restrict__ out_normal, float *__restrict__ contrib_sum,
+                                                                float *__restrict__ contrib_max)
+{
+    __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
+    __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+
+    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
+    const int lx = ((grp & 1) << 2) + (sub & 3), ly = ((grp >> 1) << 2) + (sub >> 2);
+    const int px = X0 + lx, py = Y0 + ly;
+    const bool inside = px < a.W && py < a.H;
+    const float fx = (float)lx, fy = (float)ly, OX = (float)X0, OY = (float)Y0;
+    const uint2 range = ranges[tile];
+    const int len = (int)(range.y - range.x);
+    const float g2 = 2.0f * a.gamma;
+    const float bg0 = a.background[0], bg1 = a.C > 1 ? a.background[1] : 0.0f, bg2 = a.C > 2 ? a.background[2] : 0.0f;
+    float *cst = cst_all[wave] + ROW;
+    signed char *list = list_all[wave];
+    write_dummy_row(cst, lane);
+    const RowSel rsel(lane);
+    const int my_slot = (lane >> 3 & 1) + ((lane >> 2 & 1) << 1) + ((lane >> 1 & 1) << 2); // which of a window's 8 steps this lane reports
+
+    float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, anx = 0.0f, any_ = 0.0f, anz = 0.0f, ad = 0.0f;
+    bool done = !inside;
+    uint32_t last = (uint32_t)len; // a pixel that never saturates examines the whole list (forward.cu:296-297)
+
+#ifdef TS2D_STATS
+    unsigned long long stat_acc[8] = {0, 0, 0, 0, 0, 1, 0, 0};
+#endif
+    for (int base = 0; base < len; base += 64)
+    {
+        const unsigned long long alive = ballot(!done);
+        if (alive == 0) break;
+        const int k = base + lane;
+        const bool valid = k < len;
+        uint32_t id = 0;
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+        if (valid)
+        {
+            id = point_list[range.x + k];
+            const float4 *rp = rec + 4 * (size_t)id;
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+            if (RICH) r3 = rp[3];
+        }
+        const BlockCull s = block_cull<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
+        // one entry mask per block; a block whose 16 pixels are all saturated takes no more entries
+        unsigned long long M[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) M[g] = ((alive >> (16 * g)) & 0xFFFFull) ? ballot(valid && s.ov[g]) : 0ull;
+        const unsigned long long any = M[0] | M[1] | M[2] | M[3];
+        TSG_STAT(0, __popcll(ballot(valid)));
+        if (any == 0) continue;
+        TSG_STAT(1, __popcll(M[0]) + __popcll(M[1]) + __popcll(M[2]) + __popcll(M[3]));
+        TSG_STAT(6, 1);
+        TSG_STAT(7, __popcll(any));
+        if ((any >> lane) & 1) publish_row(cst + lane * ROW, s, id, r1, r2, r3);
+        ((uint32_t *)list)[lane] = 0xFFFFFFFFu; // four lists x 64 entries of -1
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            if ((M[g] >> lane) & 1) list[g * 64 + lane_rank(M[g])] = (signed char)lane;
+        const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
+        const signed char *mylist = list + grp * 64;
+        TSG_STAT(2, steps);
+        TSG_STAT(3, (steps + 7) / 8);
+
+        for (int t0 = 0; t0 < steps; t0 += 8)
+        {
+            float c[8];
+            uint32_t cjc[8];
+            const uint2 packed = *(const uint2 *)(mylist + t0); // this group's next 8 entry indices
+#pragma unroll
+            for (int st = 0; st < 8; st++)
+            {
+                c[st] = 0.0f;
+                cjc[st] = 0u;
+                if (t0 + st < steps)
+                {
+                    const int jc = (int)(signed char)(((st < 4 ? packed.x : packed.y) >> (8 * (st & 3))) & 0xFFu);
+                    const float *row = cst + jc * ROW;
+                    const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
+                    const Bary b = barycentrics(q0, q1, fx, fy);
+                    const float4 q2 = *(const float4 *)(row + 8);
+                    float4 q3 = make_float4(0, 0, 0, 0);
+                    float vd3 = 0.0f;
+                    if (RICH)
+                    {
+                        q3 = *(const float4 *)(row + 12);
+                        vd3 = row[16];
+                        cjc[st] = (uint32_t)jc;
+                    }
+                    const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
+                    const float alpha = fminf(0.99f, q1.w * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:311-312
+                    const bool hit = !done && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f;                     // forward.cu:307,313
+                    // branch-free blend: a lane that does not hit runs with alpha = 0 (x + c*0 == x, T*1 == T bit for bit)
+                    const float al = hit ? alpha : 0.0f;
+                    TSG_STAT(4, __popcll(ballot(hit)));
+                    const float contrib = al * T;
+                    ar = fmaf(q2.x, contrib, ar);
+                    ag = fmaf(q2.y, contrib, ag);
+                    ab = fmaf(q2.z, contrib, ab);
+                    if (RICH)
+                    {
+                        anx = fmaf(q2.w, contrib, anx);
+                        any_ = fmaf(q3.x, contrib, any_);
+                        anz = fmaf(q3.y, contrib, anz);
+                        const float d = q3.z * b.a1 + q3.w * b.a2 + vd3 * b.a3; // forward.cu:328
+                        ad = fmaf(d, contrib, ad);
+                        c[st] = contrib;
+                    }
+                    T *= (1.0f - al);
+                    const bool sat = hit && T <= 0.0001f; // forward.cu:333
+                    last = sat ? (uint32_t)(base + jc + 1) : last;
+                    done = done || sat;
+                }
+            }
+#if TSG_PROBE != 2
+            if (RICH)
+            {
+                // contrib_sum / contrib_max (forward.cu:323-324; the reference issues two global atomics per (pixel, triangle)):
+                // the window's 8 x 64 contributions are reduced inside each 16-lane group, lane pairs (l, l ^ 1) end up with
+                // (sum, max, entry) of step `b3 + 2 b2 + 4 b1` of their group, and the even lanes fold them into the entry's
+                // row of the wave's table -- one group after the other, because two groups may hold the same entry.
+                const float sm = row_reduce8(c, rsel, OpAdd());
+                const float mx = row_reduce8(c, rsel, OpMax());
+                const int ejc = (int)row_select8(cjc, rsel);
+                float *acc = cst + ejc * ROW + 18;
+                const bool writer = (lane & 1) == 0 && sm > 0.0f;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    if (writer && grp == g)
+                    {
+                        float2 o = *(float2 *)acc;
+                        o.x += sm;
+                        o.y = __int_as_float(max(__float_as_int(o.y), __float_as_int(mx))); // both >= 0: int order == float order
+                        *(float2 *)acc = o;
+                    }
+            }
+#endif
+        }
+#if TSG_PROBE == 0
+        if (RICH && ((any >> lane) & 1))
+        {
+            const float2 o = *(const float2 *)(cst + lane * ROW + 18);
+            if (o.x > 0.0f)
+            {
+                unsafeAtomicAdd(contrib_sum + id, o.x);
+                atomicMax((int *)contrib_max + id, __float_as_int(o.y));
+            }
+        }
+#endif
+    }
+
+#ifdef TS2D_STATS
+    if (lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&g_stats_group[i], stat_acc[i]);
+#endif
+    if (inside)
+    {
+        const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_feature[pix] = ar + T * bg0; // forward.cu:345
+        if (a.C > 1) out_feature[HW + pix] = ag + T * bg1;
+        if (a.C > 2) out_feature[2 * HW + pix] = ab + T * bg2;
+        if (RICH)
+        {
+            out_depth[pix] = ad + T * a.background_depth; // forward.cu:349
+            out_normal[pix] = anx;
+            out_normal[HW + pix] = any_;
+            out_normal[2 * HW + pix] = anz;
+        }
+    }
+}
+
+// 16 values: the row-wide sum of the value fed at position (b3 + 2 b2 + 4 b1 + 8 b0) lands in the lane -- callers feed
+// gradient-record column c at position bitrev4(c), so that lane (l & 15) of a group ends up with column (l & 15).
+__device__ __forceinline__ float row_reduce16(const float (&v)[16], const RowSel &r, bool b0)
+{
+    OpAdd op;
+    float s[8], t[4];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = pair_ror8(v[2 * i], v[2 * i + 1], r.b3, op);
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = pair_hmir(s[2 * i], s[2 * i + 1], r.b2, op);
+    const float x = pair_xor2(t[0], t[1], r.b1, op), y = pair_xor2(t[2], t[3], r.b1, op);
+    const float own = b0 ? y : x, oth = b0 ? x : y;
+    return own + dpp<DPP_XOR1>(oth);
+}
+constexpr int bitrev4(int c) { return ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3); }
+
+// Backward.  Per (pixel, triangle) pair the reference adds 16 values into per-triangle arrays (backward.cu:412-490); here the
+// pair's 16 values are formed per lane exactly in the reference's per-pixel form (no moment / epilogue algebra):
+//   dL/dv_j (screen space) = perp(t_j) / area2 with  t_1 = e_3 p_v2 - e_2 p_v3,  t_2 = e_1 p_v3 - e_3 p_v1,  t_3 = e_2 p_v1 - e_1 p_v2,
+//   e_k = dL/da_k - sum_m dL/da_m a_m     (backward.cu:464-479 regrouped: v2_v3 = p_v3 - p_v2 etc.; perp(x, y) = (y, -x)),
+// the division by area2 is applied once per entry when the sums are flushed.  The reference's seven back-to-front
+// composites per pixel collapse to one scalar B = sum_c dL_dpix_c * accum_c (same mathematics, see render.hip).
+// Each group reduces its 16 values over its 16 lanes (DPP row transpose-reduce) and adds them into the entry's row of a
+// wave-private LDS table (one group after the other: two groups may be working on the same entry); once per batch the rows
+// leave as coalesced 64-byte atomic adds, one gradient record per 16 lanes.
+template <bool RICH, bool GAMMA1>
+__global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+                                                                   const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
+                                                                   const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                                   const float *__restrict__ dL_dout_feature,
+                                                                   const float *__restrict__ dL_dout_depth,
+                                                                   const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
+{
+    __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
+    __shared__ __attribute__((aligned(16))) float sums_all[4][64 * 16];
+    __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+
+    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
+    const int lx = ((grp & 1) << 2) + (sub & 3), ly = ((grp >> 1) << 2) + (sub >> 2);
+    const int px = X0 + lx, py = Y0 + ly;
+    const bool inside = px < a.W && py < a.H;
+    const float fx = (float)lx, fy = (float)ly, OX = (float)X0, OY = (float)Y0;
+    const uint2 range = ranges[tile];
+    const float g2 = 2.0f * a.gamma;
+    const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
+    float *cst = cst_all[wave] + ROW;
+    float *sums = sums_all[wave];
+    signed char *list = list_all[wave];
+    write_dummy_row(cst, lane);
+    const RowSel rsel(lane);
+    const bool b0 = lane & 1;
+
+    float T = inside ? final_T[pix] : 0.0f;            // backward.cu:318
+    const int last = inside ? (int)n_contrib[pix] : 0; // backward.cu:320
+    float dpr = 0.0f, dpg = 0.0f, dpb = 0.0f, dnx = 0.0f, dny = 0.0f, dnz = 0.0f, dd = 0.0f, B = 0.0f;
+    if (inside) // backward.cu:331-343
+    {
+        dpr = dL_dout_feature[pix];
+        B = dpr * a.background[0];
+        if (a.C > 1) { dpg = dL_dout_feature[HW + pix]; B = fmaf(dpg, a.background[1], B); }
+        if (a.C > 2) { dpb = dL_dout_feature[2 * HW + pix]; B = fmaf(dpb, a.background[2], B); }
+        if (RICH)
+        {
+            dnx = dL_dout_normal[pix]; dny = dL_dout_normal[HW + pix]; dnz = dL_dout_normal[2 * HW + pix];
+            dd = dL_dout_depth[pix];
+            B = fmaf(dd, a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
+        }
+    }
+    // entries at list positions >= the largest n_contrib of a block are skipped by all of its pixels (backward.cu:377-379)
+    float lm = (float)last;
+    lm = fmaxf(lm, dpp<DPP_XOR1>(lm));
+    lm = fmaxf(lm, dpp<DPP_XOR2>(lm));
+    lm = fmaxf(lm, dpp<DPP_HALF_MIRROR>(lm));
+    lm = fmaxf(lm, dpp<DPP_MIRROR>(lm));
+    int glast[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) glast[g] = (int)__builtin_amdgcn_readlane((int)lm, 16 * g);
+    const int maxlast = max(max(glast[0], glast[1]), max(glast[2], glast[3]));
+    if (maxlast <= 0) return;
+
+    for (int base = ((maxlast - 1) >> 6) << 6; base >= 0; base -= 64)
+    {
+        const int k = base + lane;
+        const bool valid = k < maxlast;
+        uint32_t id = 0;
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+        if (valid)
+        {
+            id = point_list[range.x + k];
+            const float4 *rp = rec + 4 * (size_t)id;
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+            if (RICH) r3 = rp[3];
+        }
+        const BlockCull s = block_cull<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
+        unsigned long long M[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            const int n = glast[g] - base; // entries [0, n) of this batch can still matter to block g
+            const unsigned long long keep = n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
+            M[g] = ballot(valid && s.ov[g]) & keep;
+        }
+        const unsigned long long any = M[0] | M[1] | M[2] | M[3];
+        if (any == 0) continue;
+        if ((any >> lane) & 1)
+        {
+            publish_row(cst + lane * ROW, s, id, r1, r2, r3);
+            float4 *z = (float4 *)(sums + lane * 16);
+            z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
+        }
+        ((uint32_t *)list)[lane] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int g = 0; g < 4; g++) // back to front: the entry with the highest list position first
+            if ((M[g] >> lane) & 1) list[g * 64 + (__popcll(M[g]) - 1 - lane_rank(M[g]))] = (signed char)lane;
+        const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
+        const signed char *mylist = list + grp * 64;
+
+        for (int t0 = 0; t0 < steps; t0 += 4)
+        {
+            const uint32_t packed = *(const uint32_t *)(mylist + t0); // this group's next 4 entry indices
+#pragma unroll
+            for (int st = 0; st < 4; st++)
+            {
+                if (t0 + st >= steps) break;
+                const int jc = (int)(signed char)((packed >> (8 * st)) & 0xFFu);
+                const float *row = cst + jc * ROW;
+                const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
+                const Bary b = barycentrics(q0, q1, fx, fy);
+                const float4 q2 = *(const float4 *)(row + 8);
+                float4 q3 = make_float4(0, 0, 0, 0);
+                float vd3 = 0.0f;
+                if (RICH)
+                {
+                    q3 = *(const float4 *)(row + 12);
+                    vd3 = row[16];
+                }
+                const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
+                const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f); // exp(-0.5 pw)
+                const float opG = q1.w * G;
+                const float alpha = fminf(0.99f, opG);
+                const bool hit = (base + jc < last) && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f; // backward.cu:378,393,400
+                // branch-free from here on: a lane that does not hit runs with alpha = 0, so T and B stay bit-unchanged and every
+                // value it feeds into the reduction is an exact 0
+                const float al = hit ? alpha : 0.0f;
+                const float oma = 1.0f - al;
+                T = T * __builtin_amdgcn_rcpf(oma); // backward.cu:403
+                const float contrib = al * T;
+                float X = fmaf(dpb, q2.z, fmaf(dpg, q2.y, dpr * q2.x)); // backward.cu:415
+                float w = 0.0f;
+                if (RICH) // backward.cu:419-437
+                {
+                    X = fmaf(dnz, q3.y, fmaf(dny, q3.x, fmaf(dnx, q2.w, X)));
+                    const float depth = fmaf(vd3, b.a3, fmaf(q3.w, b.a2, q3.z * b.a1));
+                    X = fmaf(dd, depth, X);
+                    w = dd * contrib; // dL_ddepth
+                }
+                const float dL_dcontrib = X - B;
+                B = fmaf(al, X, oma * B);
+                const float dL_dalpha = dL_dcontrib * T;
+                // backward.cu:443-447: dL_decc = dL_dpower * 2 gamma * power / (ecc + 1e-8) with power = -0.5 pw and
+                // dL_dpower = dL_dalpha * alpha unless the 0.99 clamp was active; z = -3 dL_decc goes to the arg-min barycentric
+                const float zr = 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(b.ecc + 1e-8f);
+                const float z = (hit && opG < 0.99f) ? zr : 0.0f; // the select sits last: a lane that does not hit may hold inf / NaN in pw
+                const bool k1 = b.a1 == b.mn;        // backward.cu:449-461: a1 <= a2 && a1 <= a3, then a2 <= a1 && a2 <= a3, else a3
+                const bool k2 = !k1 && b.a2 == b.mn;
+                const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = z - z1 - z2;
+                const float da1 = fmaf(w, q3.z, z1), da2 = fmaf(w, q3.w, z2), da3 = fmaf(w, vd3, z3); // backward.cu:433,462
+                const float sdot = fmaf(da3, b.a3, fmaf(da2, b.a2, da1 * b.a1));
+                const float e1 = da1 - sdot, e2 = da2 - sdot, e3 = da3 - sdot;
+                float v[16];
+                v[bitrev4(0)] = e3 * b.p2y - e2 * b.p3y;  // perp(t_1).x =  t_1.y
+                v[bitrev4(1)] = e2 * b.p3x - e3 * b.p2x;  // perp(t_1).y = -t_1.x
+                v[bitrev4(2)] = e1 * b.p3y - e3 * b.p1y;
+                v[bitrev4(3)] = e3 * b.p1x - e1 * b.p3x;
+                v[bitrev4(4)] = e2 * b.p1y - e1 * b.p2y;
+                v[bitrev4(5)] = e1 * b.p2x - e2 * b.p1x;
+                v[bitrev4(6)] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
+                v[bitrev4(7)] = dpr * contrib; v[bitrev4(8)] = dpg * contrib; v[bitrev4(9)] = dpb * contrib; // backward.cu:412
+                v[bitrev4(10)] = dnx * contrib; v[bitrev4(11)] = dny * contrib; v[bitrev4(12)] = dnz * contrib; // backward.cu:421-423
+                v[bitrev4(13)] = w * b.a1; v[bitrev4(14)] = w * b.a2; v[bitrev4(15)] = w * b.a3;             // backward.cu:429-431
+                const float red = row_reduce16(v, rsel, b0); // lane (l & 15) now holds column (l & 15) of its group's entry
+                float *acc = sums + jc * 16 + sub;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                    if (grp == g && jc >= 0) *acc += red;
+            }
+        }
+
+        // Batch flush: 16 consecutive lanes add the 16 floats (one 64-byte line) of one triangle's gradient record, four
+        // entries per instruction; the vertex columns get their 1 / area2 here.
+        {
+#pragma unroll 1
+            for (int e0 = 0; e0 < 64; e0 += 4)
+            {
+                if (((any >> e0) & 0xFull) == 0) continue;
+                const int e = e0 + grp;
+                if ((any >> e) & 1)
+                {
+                    const uint32_t eid = __float_as_uint(cst[e * ROW + 17]);
+                    float val = sums[e * 16 + sub];
+                    if (sub < 6) val *= cst[e * ROW + 6];
+                    if (RICH || sub < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, val);
+                }
+            }
+        }
+    }
+}
+} // namespace
+
+#define TS_DISPATCH_G(KERNEL, ...)                                                                                    \
+    do                                                                                                                \
+    {                                                                                                                 \
+        const bool g1 = (a.gamma == 1.0f);                                                                            \
+        if (a.rich_info && g1) hipLaunchKernelGGL((KERNEL<true, true>), grid, dim3(256), 0, s, __VA_ARGS__);          \
+        else if (a.rich_info) hipLaunchKernelGGL((KERNEL<true, false>), grid, dim3(256), 0, s, __VA_ARGS__);          \
+        else if (g1) hipLaunchKernelGGL((KERNEL<false, true>), grid, dim3(256), 0, s, __VA_ARGS__);                   \
+        else hipLaunchKernelGGL((KERNEL<false, false>), grid, dim3(256), 0, s, __VA_ARGS__);                          \
+    } while (0)
+
+void ts_launch_render_fwd_group(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
+                                float *out_feature, float *out_depth, float *out_normal, float *contrib_sum, float *contrib_max,
+                                hipStream_t s)
+{
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    if (grid.x == 0) return;
+    TS_DISPATCH_G(render_fwd_group_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, out_feature, out_depth, out_normal,
+                  contrib_sum, contrib_max);
+}
+
+#ifdef TS2D_STATS
+extern "C" int ts2d_stats_read_group(unsigned long long *out, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats_group), sizeof(unsigned long long) * 8);
+    if (e == hipSuccess && reset)
+    {
+        unsigned long long z[8] = {0};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats_group), z, sizeof(z));
+    }
+    return e == hipSuccess ? 0 : 2;
+}
+#endif
+
+void ts_launch_render_bwd_group(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
+                                const float *dL_dout_feature, const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec,
+                                hipStream_t s)
+{
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    if (grid.x == 0) return;
+    TS_DISPATCH_G(render_bwd_group_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature, dL_dout_depth,
+                  dL_dout_normal, grad_rec);
+}

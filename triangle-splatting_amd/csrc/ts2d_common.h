@@ -159,6 +159,7 @@ struct RenderArgs
     const float *background; // C floats, device
     bool rich_info;
     int ablate; // profiling only (env TS2D_ABLATE, builds with -DTS2D_ABLATION): 0 = full kernel; see render.hip
+    int legacy_blend; // measurement only (env TS2D_BLEND=wave, read once): round-1 one-triangle-per-wave blend kernels
     int bwd_mfma;  // experiment (env TS2D_BWD=mfma): render_bwd forms its per-entry sums with f32 MFMA instead of VALU reduction networks
 };
 void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
@@ -167,6 +168,13 @@ void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const
 void ts_launch_render_bwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                           const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
                           const float *dL_dout_normal, float *grad_rec, hipStream_t s);
+// lane-group blend kernels (render_group.hip): four 4x4 pixel blocks per wave, one triangle per block and step
+void ts_launch_render_fwd_group(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
+                                const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
+                                float *contrib_sum, float *contrib_max, hipStream_t s);
+void ts_launch_render_bwd_group(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
+                                const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
+                                const float *dL_dout_normal, float *grad_rec, hipStream_t s);
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                               float *dL_dfeature, float *dL_dopacity, hipStream_t s);
