@@ -42,6 +42,15 @@ constexpr int ROW = 20; // floats per entry row of the constants table:
 // (u_k = screen vertex k relative to the quadrant origin); row -1 is a dummy that fails every pixel's ecc test.
 
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Orders this wave's LDS accesses ACROSS LANES at this point of the program: the per-thread language model lets the
+// compiler merge or reorder the accesses of different lanes (it did: three groups' read-add-write sequences became three
+// reads and one common write); a wavefront-scope fence + wave_barrier pins them (no instruction is emitted: LDS executes a
+// wave's accesses in order).
+__device__ __forceinline__ void wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
 __device__ __forceinline__ int lane_rank(unsigned long long m) // set bits of m below this lane
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -63,7 +72,7 @@ __device__ __forceinline__ BlockCull block_cull(float v1x, float v1y, float v2x,
     BlockCull s;
     // area2 exactly as preprocess evaluates (and the reference stores) it: cross(v2 - v1, v3 - v1) without contraction
     const float area2 = __fsub_rn(__fmul_rn(v2x - v1x, v3y - v1y), __fmul_rn(v2y - v1y, v3x - v1x)); // forward.cu:137
-    s.ia = 1.0f / area2;
+    s.ia = __builtin_amdgcn_rcpf(area2); // the reference divides by area2 per pixel; a 1-ulp reciprocal moves a_k by <= 2 ulp
     s.u1x = v1x - OX; s.u1y = v1y - OY; s.u2x = v2x - OX; s.u2y = v2y - OY; s.u3x = v3x - OX; s.u3y = v3y - OY;
     const float C1 = (s.u2x * s.u3y - s.u2y * s.u3x) * s.ia, A1 = (v2y - v3y) * s.ia, B1 = (v3x - v2x) * s.ia;
     const float C2 = (s.u3x * s.u1y - s.u3y * s.u1x) * s.ia, A2 = (v3y - v1y) * s.ia, B2 = (v1x - v3x) * s.ia;
@@ -331,6 +340,7 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
                 const bool writer = (lane & 1) == 0 && sm > 0.0f;
 #pragma unroll
                 for (int g = 0; g < 4; g++)
+                {
                     if (writer && grp == g)
                     {
                         float2 o = *(float2 *)acc;
@@ -338,6 +348,8 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
                         o.y = __int_as_float(max(__float_as_int(o.y), __float_as_int(mx))); // both >= 0: int order == float order
                         *(float2 *)acc = o;
                     }
+                    wave_lds_order();
+                }
             }
 #endif
         }
@@ -378,17 +390,40 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
 
 // 16 values: the row-wide sum of the value fed at position (b3 + 2 b2 + 4 b1 + 8 b0) lands in the lane -- callers feed
 // gradient-record column c at position bitrev4(c), so that lane (l & 15) of a group ends up with column (l & 15).
-__device__ __forceinline__ float row_reduce16(const float (&v)[16], const RowSel &r, bool b0)
+// Levels 1 and 2 pair lanes of different DPP banks (l ^ 8 via row_ror:8, then the two banks of each 8 via row_half_mirror), so
+// the "which half keeps which value" select is the instruction's own bank write mask: two v_add_f32_dpp per pair instead of
+// two v_cndmask + one (all half rate on gfx950).  Levels 3 and 4 pair lanes inside a quad and need one v_cndmask each.
+// Written as ONE asm statement because hipcc's DPP combiner does not form partially masked adds; wait states (a VALU
+// result needs 2 states before a DPP op reads it) are satisfied by the instruction order plus the three s_nop.
+__device__ __forceinline__ float row_reduce16(float (&v)[16], unsigned long long mask_b1, unsigned long long mask_b0)
 {
-    OpAdd op;
-    float s[8], t[4];
-#pragma unroll
-    for (int i = 0; i < 8; i++) s[i] = pair_ror8(v[2 * i], v[2 * i + 1], r.b3, op);
-#pragma unroll
-    for (int i = 0; i < 4; i++) t[i] = pair_hmir(s[2 * i], s[2 * i + 1], r.b2, op);
-    const float x = pair_xor2(t[0], t[1], r.b1, op), y = pair_xor2(t[2], t[3], r.b1, op);
-    const float own = b0 ? y : x, oth = b0 ? x : y;
-    return own + dpp<DPP_XOR1>(oth);
+#define TSG_L1(X, Y)                                                                    \
+    "v_add_f32_dpp " Y ", " Y ", " Y " row_ror:8 row_mask:0xf bank_mask:0xc\n"         \
+    "v_add_f32_dpp " Y ", " X ", " X " row_ror:8 row_mask:0xf bank_mask:0x3\n"
+#define TSG_L2(X, Y)                                                                    \
+    "v_add_f32_dpp " Y ", " Y ", " Y " row_half_mirror row_mask:0xf bank_mask:0xa\n"   \
+    "v_add_f32_dpp " Y ", " X ", " X " row_half_mirror row_mask:0xf bank_mask:0x5\n"
+#define TSG_L3(X, Y, QP, M)                                                             \
+    "v_add_f32_dpp " X ", " X ", " X " quad_perm:" QP " row_mask:0xf bank_mask:0xf\n"  \
+    "v_add_f32_dpp " Y ", " Y ", " Y " quad_perm:" QP " row_mask:0xf bank_mask:0xf\n"  \
+    "v_cndmask_b32_e64 " Y ", " X ", " Y ", " M "\n"
+    asm volatile("s_nop 1\n"
+                 TSG_L1("%0", "%1") TSG_L1("%2", "%3") TSG_L1("%4", "%5") TSG_L1("%6", "%7")
+                 TSG_L1("%8", "%9") TSG_L1("%10", "%11") TSG_L1("%12", "%13") TSG_L1("%14", "%15")
+                 TSG_L2("%1", "%3") TSG_L2("%5", "%7") TSG_L2("%9", "%11") TSG_L2("%13", "%15")
+                 TSG_L3("%3", "%7", "[2,3,0,1]", "%16") TSG_L3("%11", "%15", "[2,3,0,1]", "%16")
+                 "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 0\n"
+                 "v_add_f32_dpp %15, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_e64 %15, %7, %15, %17\n"
+                 "s_nop 1\n"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                 : "s"(mask_b1), "s"(mask_b0));
+#undef TSG_L1
+#undef TSG_L2
+#undef TSG_L3
+    return v[15];
 }
 constexpr int bitrev4(int c) { return ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3); }
 
@@ -410,7 +445,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, 
                                                                    const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
     __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
-    __shared__ __attribute__((aligned(16))) float sums_all[4][64 * 16];
+    __shared__ __attribute__((aligned(16))) float sums_all[4][65 * 16]; // row -1 absorbs the adds of idle groups
     __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
@@ -426,11 +461,9 @@ __global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, 
     const float g2 = 2.0f * a.gamma;
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
     float *cst = cst_all[wave] + ROW;
-    float *sums = sums_all[wave];
+    float *sums = sums_all[wave] + 16;
     signed char *list = list_all[wave];
     write_dummy_row(cst, lane);
-    const RowSel rsel(lane);
-    const bool b0 = lane & 1;
 
     float T = inside ? final_T[pix] : 0.0f;            // backward.cu:318
     const int last = inside ? (int)n_contrib[pix] : 0; // backward.cu:320
@@ -497,15 +530,22 @@ __global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, 
         const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
         const signed char *mylist = list + grp * 64;
 
-        for (int t0 = 0; t0 < steps; t0 += 4)
+        // steps at which two groups work on the SAME entry (their sums must then be added to its row one after the other)
+        unsigned long long conflict;
         {
-            const uint32_t packed = *(const uint32_t *)(mylist + t0); // this group's next 4 entry indices
-#pragma unroll
-            for (int st = 0; st < 4; st++)
+            const int l0 = list[lane], l1 = list[64 + lane], l2 = list[128 + lane], l3 = list[192 + lane];
+            conflict = ballot((l0 >= 0 && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 >= 0 && (l1 == l2 || l1 == l3)) || (l2 >= 0 && l2 == l3));
+        }
+        const int lrel = last - base; // entries [0, lrel) of this batch are in front of the pixel's last contributor
+        for (int t0 = 0; t0 < steps; t0++)
+        {
             {
-                if (t0 + st >= steps) break;
-                const int jc = (int)(signed char)((packed >> (8 * st)) & 0xFFu);
+                constexpr int st = 0;
+                const int jc = mylist[t0]; // this group's next entry; past the end of its list: -1 = the dummy row
                 const float *row = cst + jc * ROW;
+                float *acc = sums + jc * 16 + sub;
+                const bool shared_row = (conflict >> (t0 + st)) & 1; // wave-uniform
+                const float q0acc = *acc;                              // fetched early; only used when no other group adds to this row now
                 const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
                 const Bary b = barycentrics(q0, q1, fx, fy);
                 const float4 q2 = *(const float4 *)(row + 8);
@@ -520,7 +560,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, 
                 const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f); // exp(-0.5 pw)
                 const float opG = q1.w * G;
                 const float alpha = fminf(0.99f, opG);
-                const bool hit = (base + jc < last) && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f; // backward.cu:378,393,400
+                const bool hit = (jc < lrel) && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f; // backward.cu:378,393,400
                 // branch-free from here on: a lane that does not hit runs with alpha = 0, so T and B stay bit-unchanged and every
                 // value it feeds into the reduction is an exact 0
                 const float al = hit ? alpha : 0.0f;
@@ -560,24 +600,32 @@ __global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, 
                 v[bitrev4(7)] = dpr * contrib; v[bitrev4(8)] = dpg * contrib; v[bitrev4(9)] = dpb * contrib; // backward.cu:412
                 v[bitrev4(10)] = dnx * contrib; v[bitrev4(11)] = dny * contrib; v[bitrev4(12)] = dnz * contrib; // backward.cu:421-423
                 v[bitrev4(13)] = w * b.a1; v[bitrev4(14)] = w * b.a2; v[bitrev4(15)] = w * b.a3;             // backward.cu:429-431
-                const float red = row_reduce16(v, rsel, b0); // lane (l & 15) now holds column (l & 15) of its group's entry
-                float *acc = sums + jc * 16 + sub;
+                const float red = row_reduce16(v, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull); // lane (l & 15): column (l & 15) of its group's entry
+                if (!shared_row) *acc = q0acc + red;
+                else
+                {
 #pragma unroll
-                for (int g = 0; g < 4; g++)
-                    if (grp == g && jc >= 0) *acc += red;
+                    for (int g = 0; g < 4; g++)
+                    {
+                        if (grp == g) *acc += red;
+                        wave_lds_order();
+                    }
+                }
             }
         }
 
         // Batch flush: 16 consecutive lanes add the 16 floats (one 64-byte line) of one triangle's gradient record, four
-        // entries per instruction; the vertex columns get their 1 / area2 here.
+        // entries per instruction (the entries with work, compacted through group 0's list); the vertex columns get their
+        // 1 / area2 here.
         {
+            if ((any >> lane) & 1) list[lane_rank(any)] = (signed char)lane;
+            const int n = __popcll(any);
 #pragma unroll 1
-            for (int e0 = 0; e0 < 64; e0 += 4)
+            for (int e0 = 0; e0 < n; e0 += 4)
             {
-                if (((any >> e0) & 0xFull) == 0) continue;
-                const int e = e0 + grp;
-                if ((any >> e) & 1)
+                if (e0 + grp < n)
                 {
+                    const int e = list[e0 + grp];
                     const uint32_t eid = __float_as_uint(cst[e * ROW + 17]);
                     float val = sums[e * 16 + sub];
                     if (sub < 6) val *= cst[e * ROW + 6];
