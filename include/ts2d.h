@@ -165,11 +165,19 @@ int ts2d_sh_grad_expand(int32_t P, int32_t sh_degree, int32_t M, int32_t num_vie
  *   3 v_depth (P*3 f32)   4 depth key (P f32)      5 rgb (P*3 f32)       6 clamped (P u8, bits 0..2)
  *   7 instance offsets in depth order (P u32)  8 tiles_touched (P u32)  9 rect (P*4 u32: minx miny maxx maxy)
  *   10 sorted keys (N u64)   11 sorted triangle ids (N u32)   12 ranges (T*2 u32)
- *   13 n_contrib (H*W u32)   14 final_T (H*W f32)   15 unsorted tile ids (N u32)  16 unsorted ids (N u32)
+ *   13 n_contrib (H*W u32)   14 final_T (H*W f32)   15 / 16 the ping-pong partner of the sorted instance list (N u32 each)
  *   17 triangle ids in (depth, id) order (P u32)   18 raw render records (P*16 f32; with TS2D_FLAG_3D: v1_view v2_view
  *   v3_view normal_view opacity rgb -- fields 0-3 and 5 decode the 2D record layout only) */
 int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t num_rendered, int32_t width, int32_t height,
                           int32_t field, void *dst, size_t dst_bytes, void *stream);
+
+/* Test hooks for the binning primitives that replace cub::DeviceRadixSort::SortPairs / cub::DeviceScan::InclusiveSum
+ * (R2D/src/rasterizer.cu:210-218, 186): the hand-written stable LSD radix sort of (key, value) pairs on bits [0, end_bit)
+ * (which = 0; csrc/binning.hip) and AMD's rocPRIM on the same arrays (which = 1; comparator only, never on the product
+ * path).  Device pointers, n pairs, synchronous. */
+int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
+                         int32_t end_bit, int32_t which, void *stream);
+int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream);
 
 /* Timing hook used by bench.py: when enabled, ts2d_forward_render / ts2d_backward bracket each kernel
  * with HIP events on `stream`; ts2d_profile_read copies out (name, total_ms, launches) rows. */

@@ -109,15 +109,28 @@ def grazing_mask(of, cos_limit):
     return np.nan_to_num(cosv, nan=1.0) < cos_limit
 
 
-def robust_rel_l2(hip, ora, budget, exclude=None, ref=None):
-    """rel-L2 over triangles after dropping `exclude` (bool mask) and the `budget` largest per-triangle errors; `ref`
-    overrides the norm the error is measured against."""
+def robust_rel_l2(hip, ora, budget, exclude=None, ref=None, dropped_bound=None):
+    """rel-L2 over triangles (or pixels) after setting aside `exclude` (bool mask) and the `budget` largest per-row errors.
+    The error is measured against the norm of the KEPT rows of `ora` (or `ref` when given).  The rows that were set aside
+    must still be sane: finite, and -- when `dropped_bound` is given -- each within dropped_bound x max(its own reference
+    magnitude, the median magnitude of the non-zero rows), so that a garbage row cannot hide inside the budget."""
     P = hip.shape[0]
-    err = np.linalg.norm((hip.astype(np.float64) - ora).reshape(P, -1), axis=1)
-    ref = np.linalg.norm(ora.astype(np.float64)) if ref is None else ref
+    h = hip.astype(np.float64).reshape(P, -1)
+    o = ora.astype(np.float64).reshape(P, -1)
+    assert np.isfinite(h).all(), "non-finite values in the compared output"
+    err = np.linalg.norm(h - o, axis=1)
+    mag = np.linalg.norm(o, axis=1)
+    keep = np.ones(P, bool)
     if exclude is not None:
-        err = np.where(exclude, 0.0, err)
+        keep &= ~exclude
     if budget > 0:
-        err = np.sort(err)[: P - budget]
-    d = np.sqrt((err ** 2).sum())
-    return d / ref if ref > 0 else d
+        order = np.argsort(np.where(keep, err, -1.0))
+        keep[order[P - budget:]] = False
+    if dropped_bound is not None and (~keep).any():
+        nz = mag[mag > 0]
+        floor = float(np.median(nz)) if nz.size else 0.0
+        bad = err[~keep] > dropped_bound * np.maximum(mag[~keep], floor)
+        assert not bad.any(), f"{int(bad.sum())} set-aside rows are off by more than {dropped_bound}x their own scale"
+    d = np.sqrt((err[keep] ** 2).sum())
+    n = np.sqrt((mag[keep] ** 2).sum()) if ref is None else ref
+    return d / n if n > 0 else d

@@ -1,0 +1,84 @@
+"""The hand-written binning primitives (csrc/binning.hip) against AMD's rocPRIM on the same arrays and against numpy:
+stable LSD radix sort of (key, value) pairs (replaces cub::DeviceRadixSort::SortPairs, R2D/src/rasterizer.cu:210-218) and the
+tile-count prefix sum (replaces cub::DeviceScan::InclusiveSum, :186), bit for bit."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import helpers
+import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from diff_triangle_rasterization_2D import _C
+    L = _C._lib
+    L.ts2d_test_sort_pairs.restype = C.c_int
+    L.ts2d_test_sort_pairs.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_int32, C.c_int32, C.c_void_p]
+    L.ts2d_test_inclusive_scan_rocprim.restype = C.c_int
+    L.ts2d_test_inclusive_scan_rocprim.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    return L
+
+
+def _sort(keys, vals, end_bit, which):
+    import torch
+    k = torch.from_numpy(keys.view(np.int32)).cuda()
+    v = torch.from_numpy(vals.view(np.int32)).cuda()
+    ko, vo = torch.empty_like(k), torch.empty_like(v)
+    stream = torch.cuda.current_stream().cuda_stream
+    assert _lib().ts2d_test_sort_pairs(k.data_ptr(), v.data_ptr(), ko.data_ptr(), vo.data_ptr(), k.numel(), end_bit, which, stream) == 0
+    return ko.cpu().numpy().view(np.uint32), vo.cpu().numpy().view(np.uint32)
+
+
+@pytest.mark.parametrize("n,end_bit,kind", [
+    (1, 8, "uniform"), (63, 13, "uniform"), (64, 5, "uniform"), (1023, 32, "uniform"), (1024, 32, "uniform"), (1025, 32, "uniform"),
+    (65_537, 13, "uniform"),          # 1080p tile bits, one chunk past a slab of 64 chunks
+    (300_000, 32, "depth"),           # float depth keys (few distinct exponents), many exact ties
+    (1_000_000, 32, "depth"),
+    (4_610_735, 13, "tiles"),         # the headline scene's instance count and tile count
+    (200_000, 17, "uniform"),         # 3 passes (> 65536 tiles)
+    (50_000, 9, "constant"),          # every key equal: the pass must keep the input order
+])
+def test_radix_sort_matches_rocprim_and_numpy(n, end_bit, kind):
+    rng = np.random.default_rng(n + end_bit)
+    if kind == "depth":
+        keys = (1000.0 + 200.0 * rng.random(n, dtype=np.float32)).astype(np.float32)
+        keys[rng.random(n) < 0.05] = 0.0          # culled triangles
+        keys[rng.integers(0, n, n // 10)] = keys[rng.integers(0, n, n // 10)]  # exact ties
+        keys = keys.view(np.uint32)
+    elif kind == "tiles":
+        keys = rng.integers(0, 8160, n, dtype=np.uint32)
+    elif kind == "constant":
+        keys = np.full(n, 0x155 & ((1 << end_bit) - 1), np.uint32)
+    else:
+        keys = rng.integers(0, 1 << end_bit, n, dtype=np.uint64).astype(np.uint32)
+    vals = rng.permutation(n).astype(np.uint32)
+    ours = _sort(keys, vals, end_bit, 0)
+    theirs = _sort(keys, vals, end_bit, 1)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(ours[0], keys[order]) and np.array_equal(ours[1], vals[order])
+    assert np.array_equal(ours[0], theirs[0]) and np.array_equal(ours[1], theirs[1])
+
+
+@pytest.mark.parametrize("P,W,H", [(5, 64, 64), (1000, 300, 200), (1025, 128, 128), (300_000, 800, 800), (1_000_000, 1920, 1080)])
+def test_instance_offsets_match_rocprim_scan(P, W, H):
+    """offsets = inclusive prefix sum of tiles_touched in depth order (block sums + DPP wave scans fused into the emission
+    kernel) against rocPRIM's inclusive_scan of the same counts; N = the last offset."""
+    import torch
+    s = synthetic.scene(P, W, H, 0, seed=P)
+    hf = helpers.hip_forward_backward(s, rich_info=True, backward=False)
+    perm = helpers.hip_state(hf, s, "depth_perm").astype(np.int64)
+    tt = helpers.hip_state(hf, s, "tiles_touched").astype(np.uint32)
+    counts = torch.from_numpy(tt[perm].view(np.int32)).cuda()
+    out = torch.empty_like(counts)
+    assert _lib().ts2d_test_inclusive_scan_rocprim(counts.data_ptr(), out.data_ptr(), P, torch.cuda.current_stream().cuda_stream) == 0
+    off = helpers.hip_state(hf, s, "point_offsets").view(np.uint32)
+    assert np.array_equal(off, out.cpu().numpy().view(np.uint32))
+    assert int(off[-1]) == hf["num_rendered"]
+    # the emitted list is sorted by (tile, depth, id) and the ranges partition it
+    keys = helpers.hip_state(hf, s, "keys")
+    assert np.all(np.diff(keys) >= 0)
+    ranges = helpers.hip_state(hf, s, "ranges").astype(np.int64)
+    assert np.array_equal(ranges[:, 1] - ranges[:, 0], np.bincount(keys >> 32, minlength=ranges.shape[0]))

@@ -70,6 +70,23 @@ def test_reference_call_surface():
     a.grad = None
     ssimLoss(a, b).backward()
     assert helpers.rel_l2(a4.grad.reshape(3, 40, 50).cpu().numpy(), 3.0 * a.grad.cpu().numpy()) < 1e-6
+    # L1 with BOTH arguments requiring grad (the trainer's affine regulariser, VanillaTS_trainer.py:103) against torch autograd;
+    # the SSIM term differentiates its first argument only and refuses a second argument that requires grad
+    x = a.detach().clone().requires_grad_(True)
+    y = b.detach().clone().requires_grad_(True)
+    (2.0 * L1(x, y)).backward()
+    xr = a.detach().clone().requires_grad_(True)
+    yr = b.detach().clone().requires_grad_(True)
+    (2.0 * torch.abs(xr - yr).mean()).backward()
+    assert helpers.rel_l2(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 1e-6
+    assert helpers.rel_l2(y.grad.cpu().numpy(), yr.grad.cpu().numpy()) < 1e-6
+    y.grad = None
+    L1(a.detach(), y).backward()  # only the second argument requires grad
+    assert helpers.rel_l2(y.grad.cpu().numpy(), 0.5 * yr.grad.cpu().numpy()) < 1e-6
+    with pytest.raises(RuntimeError):
+        ssimLoss(a, y)
+    with pytest.raises(RuntimeError):
+        PhotometricLoss(0.8, 0.2)(a, y)
     with pytest.raises(ValueError):
         L1(a, b[:, :10])
     with pytest.raises(RuntimeError):

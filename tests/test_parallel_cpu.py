@@ -139,6 +139,50 @@ def test_factored_sh_exchange_world2(hip_lib_built):
     assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
 
 
+def _uneven_worker(rank, world, port, q):
+    """num_views = 3 over 2 ranks (shard_views gives 2 + 1): the factored exchange pads the shorter rank with zero rows."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diff_triangle_rasterization_2D import parallel
+
+        P, M = 23, 4
+        vertex = torch.rand((P, 3, 3), generator=torch.Generator().manual_seed(3)) * 10
+        views = {v: (torch.rand((P, 3), generator=torch.Generator().manual_seed(900 + v)),
+                     torch.rand(3, generator=torch.Generator().manual_seed(950 + v)) * 50 + 20) for v in range(3)}
+        sink = parallel.ShGradSink()
+        mine = parallel.shard_views(3, rank, world)
+        for v in mine:
+            sink.append(*views[v])
+        got = parallel.exchange_factored_sh_grads(sink, vertex, 1, M, expand_fn=_expand_reference)
+        want = _expand_reference(vertex, torch.stack([views[v][1] for v in range(3)]), torch.stack([views[v][0] for v in range(3)]), 1, M)
+        ok = len(mine) == (2 if rank == 0 else 1) and torch.allclose(got, want, atol=1e-6)
+        # a different triangle count on one rank is refused on every rank
+        sink.append(torch.zeros((P + rank, 3)), torch.zeros(3))
+        try:
+            parallel.exchange_factored_sh_grads(sink, torch.zeros((P + rank, 3, 3)), 1, M, expand_fn=_expand_reference)
+            ok = False
+        except RuntimeError:
+            pass
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_factored_sh_exchange_uneven_views_world2(hip_lib_built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_uneven_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
 def test_factored_sink_context_and_errors(hip_lib_built):
     import diff_triangle_rasterization_2D as pkg
     from diff_triangle_rasterization_2D import parallel

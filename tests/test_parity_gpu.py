@@ -231,19 +231,22 @@ def test_mfma_backward_variant_matches(monkeypatch):
 @pytest.mark.parametrize("P,W,H,D,variant", [
     (1_000_000, 1920, 1080, 3, 2),   # bench.py headline
     (300_000, 800, 800, 3, 2),       # BASELINE.json configs[1]
+    (2_000_000, 1920, 1080, 3, 2),   # configs[2]
     (93_000, 1600, 1600, 0, 3),      # configs[3] (3D rasterizer, 800^2 x render_up_scale 2)
 ])
 def test_full_size_against_oracle(P, W, H, D, variant):
     """Full-size parity against the oracle itself (not only through properties).  The OpenMP oracle needs a many-core host
     for this to stay within seconds (about 6 s for the headline on the GPU box); skipped on small hosts.
 
-    At 10^8 (pixel, triangle) pairs the DISCRETE decisions of the algorithm (arg-min barycentric, alpha >= 1/255,
-    T <= 1e-4) flip for a handful of pairs between any two fp32 evaluations (SURVEY.md 8c allows 1e-5 of pixels), and each
-    flip moves one pixel's worth of gradient between vertices.  Measured on the headline: dL_dvertex differs by 1.5e-3 over
-    all triangles but by 1.9e-5 once the 100 worst of 10^6 triangles are set aside.  So: images and the smooth gradients
-    (SH, opacity) must meet the bar outright; geometry gradients must meet a 10x TIGHTER bar (2D; the bar itself for 3D)
-    after an outlier budget of 2e-4 of the triangles.  For the 3D rasterizer, triangles seen within 2.9 degrees of edge-on are set aside as well:
-    there the reference's own fp32 ray/plane arithmetic is off by per cents (tests/triage notes)."""
+    2D rasterizer: NO outlier budget -- images, SH / opacity gradients and the geometry gradients meet the north-star bars
+    outright (measured at the headline: dL_dvertex 1.5e-4, dL_dcenter2D 1.9e-4 over all 10^6 triangles, which is the
+    distance between two faithful fp32 evaluations: the oracle and the reference's own kernels differ by 1.6e-4,
+    tests/test_reference_gpu.py::test_headline_size_three_way_noise_floor).  Round 1 needed a budget of 205 triangles here:
+    its blend kernels evaluated the barycentrics as affine forms of the pixel offset, ~10x noisier than the reference's
+    pixel-relative cross products on sub-pixel slivers (profiles/r02_noise_floor_1M_before.json).
+    3D rasterizer (render3d.hip, not yet moved to the reference-form arithmetic): triangles seen within 2.9 degrees of
+    edge-on are set aside (there the reference's own fp32 ray/plane arithmetic is off by per cents)
+    plus a budget of 2e-4 of the triangles for discrete flips; set-aside rows must still be within 10x their own scale."""
     import os
     if (os.cpu_count() or 1) < 32:
         pytest.skip("full-size oracle runs need a many-core host")
@@ -265,15 +268,19 @@ def test_full_size_against_oracle(P, W, H, D, variant):
     if variant == 3:
         grazing = helpers.grazing_mask(of, T3.GRAZING_COS)
         assert grazing.mean() < 0.1
+    if variant == 2:
+        for k in ("contrib_sum", "contrib_max"):
+            assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k
+        for k in ("dL_dshs", "dL_dopacity", "dL_dvertex", "dL_dcenter2D"):
+            assert helpers.rel_l2(hf[k], ob[k]) < GRAD_TOL, (k, helpers.rel_l2(hf[k], ob[k]))
+        return
     budget = int(2e-4 * P) + 5
     for k in ("contrib_sum", "contrib_max"):
-        assert helpers.robust_rel_l2(hf[k], of[k], budget if variant == 3 else 0, grazing) < IMG_TOL, k
+        assert helpers.robust_rel_l2(hf[k], of[k], budget, grazing) < IMG_TOL, k
     for k in ("dL_dshs", "dL_dopacity"):
-        assert helpers.robust_rel_l2(hf[k], ob[k], budget if variant == 3 else 0, grazing) < GRAD_TOL, k
-    # 2D: 10x tighter than the bar once the flips are set aside; 3D: the bar itself (its fp32 barycentrics are ~100x noisier),
-    # and its dL_dcenter2D -- the view-space xy of the SUM of the three vertex gradients, which largely cancel
+        assert helpers.robust_rel_l2(hf[k], ob[k], budget, grazing) < GRAD_TOL, k
+    # its dL_dcenter2D -- the view-space xy of the SUM of the three vertex gradients, which largely cancel
     # (R3D backward.cu:211-213) -- is measured against the vertex gradients it is summed from
-    tol = GRAD_TOL if variant == 3 else 0.1 * GRAD_TOL
-    assert helpers.robust_rel_l2(hf["dL_dvertex"], ob["dL_dvertex"], budget, grazing) < tol
-    vref = np.linalg.norm(ob["dL_dvertex"].astype(np.float64)) if variant == 3 else None
-    assert helpers.robust_rel_l2(hf["dL_dcenter2D"], ob["dL_dcenter2D"], budget, grazing, ref=vref) < tol
+    assert helpers.robust_rel_l2(hf["dL_dvertex"], ob["dL_dvertex"], budget, grazing) < GRAD_TOL
+    vref = np.linalg.norm(ob["dL_dvertex"].astype(np.float64))
+    assert helpers.robust_rel_l2(hf["dL_dcenter2D"], ob["dL_dcenter2D"], budget, grazing, ref=vref) < GRAD_TOL

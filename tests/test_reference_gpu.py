@@ -89,21 +89,81 @@ def test_feature_mode_against_the_reference_build():
         assert helpers.rel_l2(hf["dL_dopacity"], rf["dL_dopacity"]) < GRAD_TOL
 
 
-def test_headline_size_against_the_reference_build():
-    """BASELINE.json's metric configuration: 1 M triangles, 1920x1080, SH degree 3, through the reference's kernels and the
-    product; geometry gradients with the discrete-flip budget of test_full_size_against_oracle."""
+def _ref_n_contrib(s, variant=2):
+    """n_contrib out of the reference's private image state (R2D/src/param_struct.h:85-103: ranges uint2[WH], n_contrib u32[WH],
+    final_T f32[WH], each aligned to 128 bytes) -- used only to count pixels whose discrete termination decision differs."""
+    import torch
+    ref = ref_build.load("_ref2d_C")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    W, H = s["image_width"], s["image_height"]
+    out = ref.rasterize_triangles(W, H, s["tanfovx"], s["tanfovy"], t(s["viewmatrix"]), t(s["projmatrix"]), t(s["campos"]), int(s["sh_degree"]),
+                                  float(s["gamma"]), float(s["scale_modifier"]), float(s["background_depth"]), t(s["background"]), t(s["vertex"]),
+                                  t(s["shs"]), torch.empty(0, device="cuda"), t(s["opacity"]), False, True, False)
+    ib = out[9]
+    base, n = ib.data_ptr(), W * H
+    al = lambda p: (p + 127) & ~127
+    p_nc = al(al(base) + 8 * n)
+    return ib.cpu().numpy()[p_nc - base:p_nc - base + 4 * n].view(np.uint32).reshape(H, W).astype(np.int64)
+
+
+def test_headline_size_three_way_noise_floor():
+    """BASELINE.json's metric configuration (1 M triangles, 1920x1080, SH degree 3) through THREE independent fp32 evaluations:
+    R = the reference's kernels (oracle/_ref), O = the CPU oracle, H = the HIP product.  No outlier budget anywhere:
+      * every output of H meets the north-star bars against R outright (image 1e-4, gradients 1e-3);
+      * the geometry gradients of H are no further from R than 1.2 x the distance between O and R -- i.e. H sits inside the
+        noise floor that two faithful fp32 evaluations of the reference's own arithmetic have at this size (O and R differ in
+        FMA contraction only); measured in round 2: O-R 1.6e-4, H-R 5.8e-5, H-O 1.5e-4 (profiles/r02_noise_floor_1M_group.json;
+        before the lane-group kernels adopted the reference's pixel-relative barycentrics: H-R 1.4e-3, carried by ~5 000
+        sub-pixel slivers, profiles/r02_noise_floor_1M_before.json);
+      * the termination position (n_contrib, the T <= 1e-4 decision) differs on at most 1e-5 of the pixels."""
+    import json
+    import os
+    if (os.cpu_count() or 1) < 32:
+        pytest.skip("the full-size oracle run needs a many-core host")
     P, W, H, D = 1_000_000, 1920, 1080, 3
     s = synthetic.scene(P, W, H, D, seed=42)
     rf = ref_build.forward_backward(s, True, False)
     hf = helpers.hip_forward_backward(s, True, False)
+    of = helpers.oracle_forward(s, True, False)
+    ob = helpers.oracle_backward(s, of, True)
+    orc = dict(of, **ob)
     _same_integer_state(hf, rf, "headline")
     for k in ("out_feature", "depth", "normal", "contrib_sum", "contrib_max"):
         assert helpers.rel_l2(hf[k], rf[k]) < IMG_TOL, k
-    for k in ("dL_dshs", "dL_dopacity"):
-        assert helpers.rel_l2(hf[k], rf[k]) < GRAD_TOL, k
-    budget = int(2e-4 * P) + 5
-    for k in ("dL_dvertex", "dL_dcenter2D"):
-        assert helpers.robust_rel_l2(hf[k], rf[k], budget) < 0.1 * GRAD_TOL, k
+    report = {}
+    for k in ("dL_dshs", "dL_dopacity", "dL_dvertex", "dL_dcenter2D"):
+        d_or, d_hr, d_ho = helpers.rel_l2(orc[k], rf[k]), helpers.rel_l2(hf[k], rf[k]), helpers.rel_l2(hf[k], orc[k])
+        report[k] = {"oracle_vs_reference": d_or, "hip_vs_reference": d_hr, "hip_vs_oracle": d_ho}
+        print(f"{k}: O-R {d_or:.3e}  H-R {d_hr:.3e}  H-O {d_ho:.3e}")
+        assert d_hr < GRAD_TOL and d_ho < GRAD_TOL, (k, d_hr, d_ho)
+        if k in ("dL_dvertex", "dL_dcenter2D"):
+            assert d_hr <= 1.2 * d_or, (k, d_hr, d_or)
+    nc_r = _ref_n_contrib(s)
+    nc_h = helpers.hip_state(hf, s, "n_contrib").astype(np.int64).reshape(H, W)
+    nc_o = of["state"].field("n_contrib").astype(np.int64).reshape(H, W)
+    report["pixels_n_contrib_differs"] = {"hip_vs_reference": int((nc_h != nc_r).sum()), "oracle_vs_reference": int((nc_o != nc_r).sum()),
+                                          "hip_vs_oracle": int((nc_h != nc_o).sum()), "pixels": W * H}
+    print(report["pixels_n_contrib_differs"])
+    budget = int(1e-5 * W * H) + 1  # SURVEY.md 8c
+    assert report["pixels_n_contrib_differs"]["hip_vs_reference"] <= max(budget, 2 * report["pixels_n_contrib_differs"]["oracle_vs_reference"])
+    assert report["pixels_n_contrib_differs"]["hip_vs_oracle"] <= budget
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    json.dump(report, open(os.path.join(out_dir, "three_way_headline.json"), "w"), indent=1)
+
+
+def test_configs1_against_the_reference_build():
+    """BASELINE.json configs[1] (NerfSynthetic 'lego'-like: 300 k triangles, 800x800, SH degree 3) against the reference's kernels,
+    no outlier budget."""
+    P, W, H, D = 300_000, 800, 800, 3
+    s = synthetic.scene(P, W, H, D, seed=42)
+    rf = ref_build.forward_backward(s, True, False)
+    hf = helpers.hip_forward_backward(s, True, False)
+    _same_integer_state(hf, rf, "configs[1]")
+    for k in ("out_feature", "depth", "normal", "contrib_sum", "contrib_max"):
+        assert helpers.rel_l2(hf[k], rf[k]) < IMG_TOL, k
+    for k in ("dL_dshs", "dL_dopacity", "dL_dvertex", "dL_dcenter2D"):
+        assert helpers.rel_l2(hf[k], rf[k]) < GRAD_TOL, (k, helpers.rel_l2(hf[k], rf[k]))
 
 
 @pytest.mark.parametrize("n,g", [(9, 3), (3000, 3), (200_001, 1), (99_999, 3)])
@@ -135,8 +195,11 @@ def test_random_configurations_against_the_reference_build(seed):
         worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_worker.py")
         # own process: the reference aborts on some degenerate inputs, which must not end the test session
         r = subprocess.run([sys.executable, worker, str(1000 + seed), out], capture_output=True, timeout=300)
-        if r.returncode != 0 or not os.path.exists(out):
-            pytest.skip(f"the reference build did not survive this configuration (exit code {r.returncode})")
+        # skip ONLY when the reference process was killed by a signal (its kernels fault on some degenerate inputs it was
+        # never exercised on); any other failure -- an import error, a Python exception in the worker -- fails the test
+        if r.returncode < 0:
+            pytest.skip(f"the reference build died on this configuration (signal {-r.returncode})")
+        assert r.returncode == 0 and os.path.exists(out), (r.returncode, r.stderr.decode(errors="replace")[-2000:])
         z = np.load(out)
         rf = {k: (int(z[k]) if k == "num_rendered" else z[k]) for k in z.files}
     hf = helpers.hip_forward_backward(s, rich, back, use_feature=use_feature, variant=variant)
@@ -154,14 +217,26 @@ def test_random_configurations_against_the_reference_build(seed):
         for k in ("contrib_sum", "contrib_max"):
             assert helpers.robust_rel_l2(hf[k], rf[k], 0 if variant == 2 else 2, graz) < IMG_TOL, k
     P = len(rf["dL_dvertex"])
-    # discrete-flip budget (see test_full_size_against_oracle): the reference build's screen vertices differ from the
-    # product's by ulps (FMA contraction), so an arg-min or threshold decision flips for an isolated pair now and then
-    budget = (max(3, P // 500) if P > 20 else 1) if variant == 3 else (max(1, P // 1000) if P > 20 else 0)
     gk = "dL_dfeature" if use_feature else "dL_dshs"
     for k in ("dL_dopacity", gk):
         assert helpers.rel_l2(hf[k], rf[k]) < GRAD_TOL, k
     vref = np.linalg.norm(rf["dL_dvertex"].astype(np.float64))
-    if vref > 0:
-        graz = helpers.grazing_mask(helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant), T3.GRAZING_COS) if variant == 3 else None
-        assert helpers.robust_rel_l2(hf["dL_dvertex"], rf["dL_dvertex"], budget, graz) < GRAD_TOL
-        assert helpers.robust_rel_l2(hf["dL_dcenter2D"], rf["dL_dcenter2D"], budget, graz, ref=vref if variant == 3 else None) < GRAD_TOL
+    if vref == 0:
+        return
+    if variant == 2:
+        # No outlier budget.  These scenes are small (P <= 4000), so ONE discrete decision (arg-min barycentric, alpha >= 1/255,
+        # T <= 1e-4) that flips between two fp32 evaluations can move the whole gradient norm by more than the bar (the reference
+        # build's screen vertices differ from the contraction-free product's and oracle's by ulps).  The criterion is therefore
+        # the three-way one of the headline test: the product meets the bar against the reference outright, or it is no
+        # further from the reference than 1.5 x the distance between the oracle and the reference on the same scene.
+        of = helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant)
+        ob = helpers.oracle_backward(s, of, rich, use_feature=use_feature)
+        for k in ("dL_dvertex", "dL_dcenter2D"):
+            d_hr, d_or = helpers.rel_l2(hf[k], rf[k]), helpers.rel_l2(ob[k], rf[k])
+            assert d_hr < GRAD_TOL or d_hr <= 1.5 * d_or, (k, d_hr, d_or)
+        return
+    # 3D variant (render3d.hip): discrete-flip budget + edge-on triangles set aside, see test_full_size_against_oracle
+    budget = max(3, P // 500) if P > 20 else 1
+    graz = helpers.grazing_mask(helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant), T3.GRAZING_COS)
+    assert helpers.robust_rel_l2(hf["dL_dvertex"], rf["dL_dvertex"], budget, graz) < GRAD_TOL
+    assert helpers.robust_rel_l2(hf["dL_dcenter2D"], rf["dL_dcenter2D"], budget, graz, ref=vref) < GRAD_TOL

@@ -205,18 +205,20 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     TS_CHECK(flags, s, "preprocess_fwd");
     {
         ProfScope ps("depth_sort", s);
-        TS_HIP(ts_sort_by_depth(g, P, s));
+        ts_sort_by_depth(g, P, s);
     }
     TS_CHECK(flags, s, "depth_sort");
     {
         ProfScope ps("scan", s);
-        TS_HIP(ts_scan_offsets(g, P, s));
+        ts_scan_offsets(g, P, s);
     }
     TS_CHECK(flags, s, "scan");
-    uint32_t n = 0;
-    TS_HIP(hipMemcpyAsync(&n, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    unsigned long long n = 0;
+    TS_HIP(hipMemcpyAsync(&n, g.blocksum + (P + 1023) / 1024, sizeof(n), hipMemcpyDeviceToHost, s));
     TS_HIP(hipStreamSynchronize(s)); // the reference's blocking cudaMemcpy, rasterizer.cu:191
-    *num_rendered = (int64_t)(int32_t)n;
+    if (n > 0x7fffffffull) // the reference's int num_rendered wraps here; instance slots are 32-bit
+        return fail(TS2D_ERR_CAPACITY, "%llu tile instances exceed the 2^31 - 1 the instance list can address", n);
+    *num_rendered = (int64_t)n;
     return TS2D_OK;
 }
 
@@ -246,22 +248,21 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     const RenderArgs r = make_render(cam, geom, flags);
     const int ntiles = r.grid_x * r.grid_y;
 
-    TS_HIP(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)ntiles, s)); // rasterizer.cu:223
-    if (rich && P > 0)
-    {
-        TS_HIP(hipMemsetAsync(out->contrib_sum, 0, sizeof(float) * (size_t)P, s));
-        TS_HIP(hipMemsetAsync(out->contrib_max, 0, sizeof(float) * (size_t)P, s));
-    }
-    if (N > 0)
+    // tile ranges (rasterizer.cu:223) and the contribution statistics are cleared by the emission kernel, not by memsets
+    if (P > 0)
     {
         {
             ProfScope ps("emit_keys", s);
-            ts_launch_emit_keys(P, r.grid_x, g, b, s);
+            ts_launch_emit_keys(P, r.grid_x, ntiles, g, b, im, rich ? out->contrib_sum : nullptr, rich ? out->contrib_max : nullptr, s);
         }
         TS_CHECK(flags, s, "emit_keys");
+    }
+    else TS_HIP(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)ntiles, s));
+    if (N > 0)
+    {
         {
             ProfScope ps("tile_sort", s);
-            TS_HIP(ts_sort_pairs(b, N, ts_higher_msb((uint32_t)ntiles), s)); // tile bits only, see binning.hip
+            ts_sort_pairs(b, N, ntiles, s); // tile bits only, see binning.hip
         }
         TS_CHECK(flags, s, "tile_sort");
         {
@@ -527,8 +528,8 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
     case 12: src = im.ranges; bytes = (size_t)gx * gy * 8; break;
     case 13: src = im.n_contrib; bytes = (size_t)W * H * 4; break;
     case 14: src = im.final_T; bytes = (size_t)W * H * 4; break;
-    case 15: src = b.tile_unsorted; bytes = (size_t)N * 4; break;
-    case 16: src = b.vals_unsorted; bytes = (size_t)N * 4; break;
+    case 15: src = b.k[(b.passes & 1) ^ 1]; bytes = (size_t)N * 4; break; // the ping-pong partner of the sorted list
+    case 16: src = b.v[(b.passes & 1) ^ 1]; bytes = (size_t)N * 4; break;
     case 17: src = g.perm; bytes = (size_t)P * 4; break;
     case 18: src = g.rec; bytes = (size_t)P * TS_REC_FLOATS * 4; break; // raw 64-byte render records (2D or 3D layout)
     default: return fail(TS2D_ERR_INVALID, "unknown field %d", field);
@@ -540,6 +541,21 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
         TS_HIP(hipStreamSynchronize(s));
     }
     return TS2D_OK;
+}
+
+// Test hooks: the hand-written stable radix sort (which = 0) and AMD's rocPRIM (which = 1, the comparator) on device arrays.
+int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int32_t end_bit,
+                         int32_t which, void *stream)
+{
+    if (end_bit < 1 || end_bit > 32) return fail(TS2D_ERR_INVALID, "end_bit must be in 1..32");
+    if (n && (!keys_in || !vals_in || !keys_out || !vals_out)) return fail(TS2D_ERR_INVALID, "null pointer");
+    const int rc = which ? ts_compare_sort_pairs_rocprim(keys_in, vals_in, keys_out, vals_out, n, end_bit, (hipStream_t)stream)
+                         : ts_test_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, end_bit, (hipStream_t)stream);
+    return rc ? fail(TS2D_ERR_HIP, "sort_pairs test hook failed") : TS2D_OK;
+}
+int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream)
+{
+    return ts_compare_inclusive_scan_rocprim(in, out, n, (hipStream_t)stream) ? fail(TS2D_ERR_HIP, "scan comparator failed") : TS2D_OK;
 }
 
 void ts2d_profile_enable(int on)

@@ -1,67 +1,365 @@
-// binning.hip -- depth ordering, instance emission, tile grouping and tile ranges.
+// binning.hip -- depth ordering, instance emission, tile grouping and tile ranges, all hand-written for gfx950.
 //
 // Result contract (integer-exact, what the blend kernels and the parity tests rely on): the instance list is ordered
-// by (tile id, depth bit pattern, triangle id) -- exactly what the reference obtains with duplicateWithKeys +
-// one stable cub::DeviceRadixSort::SortPairs over N 64-bit (tile << 32 | depth) keys + identifyTileRanges
-// (R2D/src/rasterizer.cu:37-75, 210-218, 79-99).
+// by (tile id, depth bit pattern, triangle id) -- exactly what the reference obtains with cub::DeviceScan::InclusiveSum
+// + duplicateWithKeys + one stable cub::DeviceRadixSort::SortPairs over N 64-bit (tile << 32 | depth) keys +
+// identifyTileRanges (R2D/src/rasterizer.cu:186, 37-75, 210-218, 79-99).
 //
 // How it is obtained here (same order, ~4.5x less sort traffic; N ~ 4.6 x P for the headline scene):
 //   1. stable radix sort of the P triangles by their 32-bit depth key (values = ascending ids): 4 passes x P pairs;
-//   2. gather tiles_touched in that order + inclusive scan -> instance slots of the i-th nearest triangle;
-//   3. emit (tile, id) instances in depth order;
+//   2. tiles_touched gathered in that order + block sums + their prefix -> N (the one value the host reads back);
+//   3. per block: wave64 prefix scan (DPP) of the tile counts -> instance slots, and (tile, id) instances emitted in depth
+//      order; the same kernel clears the tile ranges and the contribution statistics (no memset launches);
 //   4. stable radix sort of the N instances by TILE ID ONLY (13 bits at 1080p -> 2 passes x N x 8 B instead of
 //      6 passes x N x 12 B); stability keeps the depth order (and the id order among equal depths) inside a tile;
 //   5. tile ranges from the sorted tile ids.
-// Sorting and scanning go through rocPRIM (AMD's native device primitives; its radix sort is the LDS-histogram
-// onesweep design tuned per gfx target); the emission / gather / range kernels are ours.
+//
+// One radix pass (8-bit digit) = three kernels, no look-back spinning:
+//   rs_hist     one workgroup per chunk of 4096 pairs counts its digits in a 1 KB LDS table (ds_add_u32);
+//   rs_prefix   column prefix of the chunks x 256 table: in place inside slabs of 64 chunks (one thread per digit, coalesced
+//               rows), then -- by the last slab to finish, elected with one atomic ticket -- over the slab totals and
+//               over the 256 digit totals;
+//   rs_scatter  the workgroup re-reads its chunk (each wave a contiguous quarter, 64 pairs per step): the lanes holding equal
+//               digits find each other with 8 ballots (wave64 match), rank = v_mbcnt of the match mask on top of the digit's
+//               running count; the pairs are parked in LDS in chunk-local sorted order and leave as coalesced runs.  Ranks
+//               follow lane order, steps follow list order, waves follow chunk order: stable by construction.
+// The round-1 rocPRIM calls (radix_sort_pairs, inclusive_scan) survive only as the comparators of tests/test_binning_gpu.py.
 #include "ts2d_common.h"
-#include <cstring>
+#include "ts2d_wave.h"
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
 
 namespace
 {
-__global__ void __launch_bounds__(256) gather_tiles_kernel(int P, const uint32_t *__restrict__ perm,
-                                                            const uint32_t *__restrict__ tiles_touched,
-                                                            uint32_t *__restrict__ tiles_sorted)
+constexpr int CH = TS_RS_CHUNK, NB = TS_RS_BINS;
+
+__device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) // DPP row shifts + two row broadcasts
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < P) tiles_sorted[i] = tiles_touched[perm[i]];
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true); // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true); // row_bcast:31 -> rows 2 and 3
+    return (uint32_t)x;
 }
 
-// One lane per depth-ordered triangle.  Triangles covering up to SMALL tiles are emitted by their own lane; larger
-// ones (stress scenes where a triangle spans thousands of tiles) are emitted cooperatively by the whole wave so that
-// a single lane never serialises a long loop.  Tiles of one triangle are emitted row-major like the reference's
-// loop (rasterizer.cu:63-73); the later sort is by tile id, so only the order BETWEEN triangles matters.
+__global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift, uint32_t mask,
+                                                       RadixScratchView r)
+{
+    __shared__ uint32_t bins[NB];
+    const int t = threadIdx.x, chunk = blockIdx.x;
+    bins[t] = 0u;
+    __syncthreads();
+    const int64_t base = (int64_t)chunk * CH;
+#pragma unroll 4
+    for (int b = 0; b < CH / 256; b++)
+    {
+        const int64_t i = base + 256 * b + t;
+        if (i < n) atomicAdd(&bins[(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    r.table[(size_t)chunk * NB + t] = bins[t];
+}
+
+// Column prefix of the chunks x 256 digit-count table.  Block = one slab (64 chunks), thread = one digit.  The block that
+// takes the last ticket has every slab total in memory behind an agent-scope release / acquire pair and finishes the job:
+// prefix of the slab totals per digit, then the exclusive prefix of the 256 digit totals.
+__global__ void __launch_bounds__(NB) rs_prefix_kernel(RadixScratchView r, uint32_t *ticket)
+{
+    __shared__ uint32_t tot[NB];
+    __shared__ bool last;
+    const int b = threadIdx.x, slab = blockIdx.x;
+    const int c0 = slab * 64, c1 = min(r.chunks, c0 + 64);
+    uint32_t run = 0;
+    for (int c = c0; c < c1; c += 8)
+    {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (c + k < c1) ? r.table[(size_t)(c + k) * NB + b] : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+        {
+            if (c + k < c1) r.table[(size_t)(c + k) * NB + b] = run;
+            run += v[k];
+        }
+    }
+    r.slabtot[(size_t)slab * NB + b] = run;
+    __syncthreads();
+    if (b == 0)
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // MI355X_MICROARCH.md: the compiler may drop this wait behind the release
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (t == (uint32_t)r.slabs - 1u);
+        if (last)
+        {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next pass
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+    uint32_t total = 0;
+    for (int s = 0; s < r.slabs; s++)
+    {
+        // sc1 loads: the other slabs' totals were written by other CUs (this CU's L1 may hold stale lines)
+        const uint32_t v = __hip_atomic_load(r.slabtot + (size_t)s * NB + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r.slabtot[(size_t)s * NB + b] = total;
+        total += v;
+    }
+    tot[b] = total;
+    __syncthreads();
+    for (int d = 1; d < NB; d <<= 1) // inclusive Hillis-Steele over the 256 digit totals
+    {
+        const uint32_t add = (b >= d) ? tot[b - d] : 0u;
+        __syncthreads();
+        tot[b] += add;
+        __syncthreads();
+    }
+    r.binbase[b] = tot[b] - total;
+}
+
+// One workgroup = one chunk of CH pairs; wave w owns the w-th quarter (KB steps of 64 consecutive pairs, held in registers).
+//   1. wave-local stable ranks: per step the lanes holding equal digits find each other with `nbits` ballots (wave64 match),
+//      rank = v_mbcnt of the match mask on top of the digit's running count in the wave's LDS counters;
+//   2. thread d turns the four waves' counts of digit d into the chunk-local start of every (wave, digit) run (wave64 DPP scan
+//      + the three other waves' totals) and the distance from the chunk-local order to the digit's global run;
+//   3. every pair is parked in LDS at its chunk-local sorted position, and the chunk leaves in that order: consecutive threads
+//      write consecutive addresses inside each digit's run (scattering straight from registers costs a 32-64 B fabric write
+//      per 4-byte store on this chip: measured 2x slower than rocPRIM; staged, the stores are coalesced runs).
+template <bool IDENTITY_VALUES>
+__global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                          uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n, int shift,
+                                                          int nbits, RadixScratchView r)
+{
+    constexpr int KB = CH / 256; // steps per wave
+    __shared__ uint32_t stage_k[CH], stage_v[CH];
+    __shared__ uint32_t wcnt[4][NB]; // per-wave digit counts, then the chunk-local start of the (wave, digit) run
+    __shared__ int32_t gdelta[NB];   // global run start of the digit minus its chunk-local start
+    __shared__ uint32_t wtot[4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int chunk = blockIdx.x;
+    const uint32_t mask = (1u << nbits) - 1u;
+    const int64_t base = (int64_t)chunk * CH + (int64_t)wave * (CH / 4);
+    uint32_t key[KB], val[KB], rk[KB];
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+    {
+        const int64_t i = base + 64 * b + lane;
+        key[b] = 0xFFFFFFFFu;
+        val[b] = 0u;
+        if (i < n) { key[b] = kin[i]; val[b] = IDENTITY_VALUES ? (uint32_t)i : vin[i]; }
+    }
+#pragma unroll
+    for (int k = 0; k < NB / 64; k++) wcnt[wave][lane + 64 * k] = 0u;
+    wave_lds_order();
+    uint32_t *cnt = wcnt[wave];
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+    {
+        const bool valid = base + 64 * b + lane < n;
+        const uint32_t d = (key[b] >> shift) & mask;
+        unsigned long long m = ballot64(valid);
+        for (int bit = 0; bit < nbits; bit++)
+        {
+            const bool one = (d >> bit) & 1u;
+            const unsigned long long bb = ballot64(one);
+            m &= one ? bb : ~bb;
+        }
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        const uint32_t c = (uint32_t)__popcll(m);
+        uint32_t seen = 0;
+        if (valid) seen = cnt[d];
+        wave_lds_order(); // every lane has read its digit's count before the group leaders advance it
+        if (valid && rank == c - 1u) cnt[d] = seen + c;
+        wave_lds_order();
+        rk[b] = seen + rank;
+    }
+    __syncthreads();
+    {
+        // thread t = digit t
+        const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        const uint32_t inc = wave_inclusive_scan(tot, lane);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t dbase = inc - tot;
+        for (int w = 0; w < wave; w++) dbase += wtot[w];
+        wcnt[0][t] = dbase; wcnt[1][t] = dbase + c0; wcnt[2][t] = dbase + c0 + c1; wcnt[3][t] = dbase + c0 + c1 + c2;
+        const uint32_t g = r.binbase[t] + r.slabtot[(size_t)(chunk >> 6) * NB + t] + r.table[(size_t)chunk * NB + t];
+        gdelta[t] = (int32_t)(g - dbase);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+        if (base + 64 * b + lane < n)
+        {
+            const uint32_t p = wcnt[wave][(key[b] >> shift) & mask] + rk[b];
+            stage_k[p] = key[b];
+            stage_v[p] = val[b];
+        }
+    __syncthreads();
+    const int64_t left = n - (int64_t)chunk * CH;
+    const int count = left < CH ? (int)left : CH;
+    for (int p = t; p < count; p += 256)
+    {
+        const uint32_t k = stage_k[p];
+        const int64_t dst = (int64_t)gdelta[(k >> shift) & mask] + p;
+        kout[dst] = k;
+        vout[dst] = stage_v[p];
+    }
+}
+
+void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift, int nbits,
+                const RadixScratchView &r, uint32_t *ticket, hipStream_t s)
+{
+    const dim3 grid((unsigned)r.chunks);
+    hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, s, kin, n, shift, (1u << nbits) - 1u, r);
+    hipLaunchKernelGGL(rs_prefix_kernel, dim3((unsigned)r.slabs), dim3(NB), 0, s, r, ticket);
+    if (vin) hipLaunchKernelGGL((rs_scatter_kernel<false>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits, r);
+    else hipLaunchKernelGGL((rs_scatter_kernel<true>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits, r);
+}
+
+// ---- step 2: tiles_sorted = tiles_touched[perm], 64-bit block sums, their prefix, N ---------------------------------------
+constexpr int SB = 1024; // triangles per scan block (256 threads x 4)
+
+__global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometryStateView g, uint32_t *ticket)
+{
+    __shared__ unsigned long long wsum[4];
+    __shared__ bool last;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i0 = blockIdx.x * SB + 4 * t;
+    uint32_t v[4];
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+    {
+        v[k] = (i0 + k < P) ? g.tiles_touched[g.perm[i0 + k]] : 0u;
+        sum += v[k];
+    }
+    if (i0 + 3 < P) *(uint4 *)(g.tiles_sorted + i0) = make_uint4(v[0], v[1], v[2], v[3]);
+    else
+        for (int k = 0; k < 4; k++)
+            if (i0 + k < P) g.tiles_sorted[i0 + k] = v[k];
+    // block sum: tile counts are < 2^32 each, a block's sum may not be
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) wsum[wave] = sum;
+    __syncthreads();
+    const int nblocks = gridDim.x;
+    if (t == 0)
+    {
+        g.blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = (tk == (uint32_t)nblocks - 1u);
+        if (last)
+        {
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+    }
+    __syncthreads();
+    if (!last) return;
+    // the last block to finish turns the block sums into their exclusive prefix; blocksum[nblocks] = N
+    __shared__ unsigned long long carry;
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblocks; b0 += 256)
+    {
+        const int b = b0 + t;
+        unsigned long long x = 0;
+        if (b < nblocks) x = __hip_atomic_load(g.blocksum + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // inclusive scan over the 256 threads: inside the wave by shuffles, across the four waves through LDS
+        unsigned long long inc = x;
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const unsigned long long y = __shfl_up(inc, o);
+            if (lane >= o) inc += y;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        unsigned long long wbase = 0;
+        for (int w = 0; w < wave; w++) wbase += wsum[w];
+        const unsigned long long c = carry;
+        if (b < nblocks) g.blocksum[b] = c + wbase + inc - x;
+        __syncthreads();
+        if (t == 255) carry = c + wbase + inc;
+        __syncthreads();
+    }
+    if (t == 0) g.blocksum[nblocks] = carry;
+}
+
+// ---- step 3: instance slots + emission ------------------------------------------------------------------------------------------
+// One lane per depth-ordered triangle.  Triangles covering up to SMALL tiles are emitted by their own lane; larger ones
+// (stress scenes where a triangle spans thousands of tiles) are emitted cooperatively by the whole wave so that a single
+// lane never serialises a long loop.  Tiles of one triangle are emitted row-major like the reference's loop
+// (rasterizer.cu:63-73); the later sort is by tile id, so only the order BETWEEN triangles matters.
 constexpr uint32_t SMALL = 32;
 
-__global__ void __launch_bounds__(256) emit_instances_kernel(int P, int grid_x, GeometryStateView g, BinningStateView b)
+__global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
+                                                         float *contrib_sum, float *contrib_max)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t wtot[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int i = blockIdx.x * 256 + t;
+    // output clears that used to be three memset launches: tile ranges (rasterizer.cu:223) and the contribution statistics
+    for (int k = i; k < ntiles; k += gridDim.x * 256) ranges[k] = make_uint2(0u, 0u);
+    if (contrib_sum && i < P)
+    {
+        contrib_sum[i] = 0.0f;
+        contrib_max[i] = 0.0f;
+    }
     const bool valid = i < P;
     const uint32_t tiles = valid ? g.tiles_sorted[i] : 0u;
+    // inclusive prefix inside the block (wave64 DPP scan + the three preceding waves' totals) on top of the block's base;
+    // scan blocks are 1024 triangles = four of these 256-lane blocks, so the three earlier quarters are summed here too
+    const uint32_t inc = wave_inclusive_scan(tiles, lane);
+    if (lane == 63) wtot[wave] = inc;
+    __syncthreads();
+    uint32_t before = 0;
+    for (int w = 0; w < wave; w++) before += wtot[w];
+    const int sblock = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+    unsigned long long qbase = g.blocksum[sblock];
+    for (int q = 0; q < quarter; q++)
+    {
+        // earlier quarters of this scan block: their 256 counts summed by this block's lanes (coalesced, L2-resident)
+        const int j = (sblock * 4 + q) * 256 + t;
+        uint32_t x = (j < P) ? g.tiles_sorted[j] : 0u;
+        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+        __syncthreads();
+        if (lane == 0) wtot[wave] = x;
+        __syncthreads();
+        qbase += (unsigned long long)wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    }
+    const uint32_t incl = (uint32_t)(qbase + before + inc); // N < 2^31 is checked on the host before anything is emitted
+    if (valid) g.offsets[i] = incl;
     uint2 rect = {0u, 0u};
-    uint32_t id = 0, off = 0;
+    uint32_t id = 0;
+    const uint32_t off = incl - tiles; // exclusive prefix
     if (tiles > 0)
     {
         id = g.perm[i];
         rect = g.rect[id];
-        off = g.offsets[i] - tiles; // exclusive prefix
     }
     const uint32_t minx = rect.x & 0xffffu, miny = rect.x >> 16, maxx = rect.y & 0xffffu, maxy = rect.y >> 16;
+    uint32_t *tile_out = b.k[0], *val_out = b.v[0];
     if (tiles > 0 && tiles <= SMALL)
     {
         uint32_t o = off;
         for (uint32_t y = miny; y < maxy; y++)
             for (uint32_t x = minx; x < maxx; x++)
             {
-                b.tile_unsorted[o] = y * grid_x + x;
-                b.vals_unsorted[o] = id;
+                tile_out[o] = y * grid_x + x;
+                val_out[o] = id;
                 o++;
             }
     }
-    unsigned long long big = __ballot(tiles > SMALL);
+    unsigned long long big = ballot64(tiles > SMALL);
     while (big)
     {
         const int j = __builtin_ctzll(big);
@@ -72,8 +370,8 @@ __global__ void __launch_bounds__(256) emit_instances_kernel(int P, int grid_x, 
         for (uint32_t k = lane; k < t_tiles; k += 64)
         {
             const uint32_t y = t_miny + k / w, x = t_minx + k % w;
-            b.tile_unsorted[t_off + k] = y * grid_x + x;
-            b.vals_unsorted[t_off + k] = t_id;
+            tile_out[t_off + k] = y * grid_x + x;
+            val_out[t_off + k] = t_id;
         }
     }
 }
@@ -95,68 +393,130 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t N, const uint3
     }
     if (i == N - 1) ranges[cur].y = (uint32_t)N;
 }
+
+__global__ void zero_words_kernel(uint32_t *p, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) p[i] = 0u;
+}
 } // namespace
 
-// rocPRIM's default switches from merge sort to Onesweep radix sort above 1 Mi items; measured on MI355X (rocprofv3,
-// profiles/r01_final_kernel_stats.csv) the merge path costs ten ~8 us merge passes at P = 1 M, about twice the four
-// Onesweep passes, so the switch-over is lowered.
-using SortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 128 * 1024>;
-
-size_t ts_scan_temp_bytes(int32_t P)
-{
-    size_t scan = 0, sort = 0;
-    if (P <= 0) return 0;
-    (void)rocprim::inclusive_scan(nullptr, scan, (uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)P, rocprim::plus<uint32_t>());
-    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, sort, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                    (uint32_t *)nullptr, (size_t)P, 0u, 32u);
-    return scan > sort ? scan : sort;
-}
-
-size_t ts_sort_temp_bytes(int64_t N, int end_bit)
-{
-    size_t bytes = 0;
-    if (N <= 0) return 0;
-    (void)rocprim::radix_sort_pairs<SortConfig>(nullptr, bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                    (uint32_t *)nullptr, (size_t)N, 0u, (unsigned)end_bit);
-    return bytes;
-}
+// The tickets of the "last block finishes" kernels: one word per geometry / binning state, kept at zero between launches
+// by the electing block itself; it lives in the last word of the state's digit-base array padding (binbase has 256 words,
+// the ticket is a separate word right behind the per-slab totals).
+static uint32_t *ticket_of(const RadixScratchView &r) { return r.binbase + TS_RS_BINS; }
 
 // Step 1: (depth bits, id) -> perm.  Depth keys are view-space z of visible triangles (> 0, so the unsigned bit
 // pattern is monotone) and 0 for culled ones, which emit nothing wherever they land.
-hipError_t ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s)
-{
-    if (P <= 0) return hipSuccess;
-    size_t bytes = g.scan_temp_bytes;
-    return rocprim::radix_sort_pairs<SortConfig>(g.scan_temp, bytes, (const uint32_t *)g.depth, g.depth_sorted, g.ids, g.perm, (size_t)P,
-                                     0u, 32u, s);
-}
-
-// Step 2: tiles_sorted = tiles_touched[perm], offsets = inclusive_scan(tiles_sorted).
-hipError_t ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
-{
-    if (P <= 0) return hipSuccess;
-    hipLaunchKernelGGL(gather_tiles_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, g.perm, g.tiles_touched, g.tiles_sorted);
-    size_t bytes = g.scan_temp_bytes;
-    return rocprim::inclusive_scan(g.scan_temp, bytes, g.tiles_sorted, g.offsets, (size_t)P, rocprim::plus<uint32_t>(), s);
-}
-
-void ts_launch_emit_keys(int P, int grid_x, const GeometryStateView &g, const BinningStateView &b, hipStream_t s)
+void ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
     if (P <= 0) return;
-    hipLaunchKernelGGL(emit_instances_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, grid_x, g, b);
+    uint32_t *ticket = ticket_of(g.rs);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, ticket, 2);
+    const uint32_t *depth = (const uint32_t *)g.depth;
+    radix_pass(depth, nullptr, g.sk[0], g.sv[0], P, 0, 8, g.rs, ticket, s);
+    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, 8, 8, g.rs, ticket, s);
+    radix_pass(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, 16, 8, g.rs, ticket, s);
+    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, 24, 8, g.rs, ticket, s);
 }
 
-// Step 4: stable sort of the instances by tile id (end_bit = bits needed for the tile count).
-hipError_t ts_sort_pairs(const BinningStateView &b, int64_t N, int end_bit, hipStream_t s)
+// Step 2: tiles_sorted = tiles_touched[perm], block sums -> exclusive prefix, blocksum[nblocks] = N.
+void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
-    if (N <= 0) return hipSuccess;
-    size_t bytes = b.sort_temp_bytes;
-    return rocprim::radix_sort_pairs<SortConfig>(b.sort_temp, bytes, b.tile_unsorted, b.tile, b.vals_unsorted, b.vals, (size_t)N, 0u,
-                                     (unsigned)end_bit, s);
+    if (P <= 0) return;
+    const int nblocks = (P + SB - 1) / SB;
+    hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, ticket_of(g.rs) + 1);
+}
+
+void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
+                         float *contrib_sum, float *contrib_max, hipStream_t s)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(scan_emit_kernel, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges,
+                       contrib_sum, contrib_max);
+}
+
+// Step 4: stable sort of the instances by tile id: ceil(bits / 8) passes, ping-pong from (k[0], v[0]).
+void ts_sort_pairs(const BinningStateView &b, int64_t N, int ntiles, hipStream_t s)
+{
+    if (N <= 0) return;
+    uint32_t *ticket = ticket_of(b.rs);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, ticket, 2);
+    const int bits = ts_higher_msb((uint32_t)ntiles);
+    int src = 0;
+    for (int p = 0; p < b.passes; p++)
+    {
+        const int nbits = min(8, bits - 8 * p);
+        radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, 8 * p, nbits, b.rs, ticket, s);
+        src ^= 1;
+    }
 }
 
 void ts_launch_tile_ranges(int64_t N, const BinningStateView &b, const ImageStateView &im, hipStream_t s)
 {
     if (N <= 0) return;
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, b.tile, im.ranges);
+}
+
+// ---- rocPRIM comparators (tests/test_binning_gpu.py; never on the product path) --------------------------------------------------
+int ts_compare_sort_pairs_rocprim(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
+                                  int end_bit, hipStream_t s)
+{
+    size_t bytes = 0;
+    if (rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s) != hipSuccess) return 2;
+    void *tmp = nullptr;
+    if (hipMalloc(&tmp, bytes ? bytes : 1) != hipSuccess) return 2;
+    hipError_t e = rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    return e == hipSuccess ? 0 : 2;
+}
+
+int ts_compare_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s)
+{
+    size_t bytes = 0;
+    if (rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<uint32_t>(), s) != hipSuccess) return 2;
+    void *tmp = nullptr;
+    if (hipMalloc(&tmp, bytes ? bytes : 1) != hipSuccess) return 2;
+    hipError_t e = rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::plus<uint32_t>(), s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(tmp);
+    return e == hipSuccess ? 0 : 2;
+}
+
+// Test hook (include/ts2d.h: ts2d_test_sort_pairs): the hand-written passes on caller-provided device arrays, scratch from hipMalloc.
+int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit,
+                       hipStream_t s)
+{
+    if (n == 0) return 0;
+    BinningStateView b{};
+    RadixScratchView r{};
+    char *p = nullptr;
+    ts_carve_radix(p, n, r);
+    const size_t scratch = (size_t)p + TS_ALIGN, bytes = scratch + 4 * (n * 4 + TS_ALIGN);
+    char *base = nullptr;
+    if (hipMalloc((void **)&base, bytes) != hipSuccess) return 2;
+    p = base;
+    ts_carve_radix(p, n, b.rs);
+    for (int i = 0; i < 2; i++) { ts_carve(p, b.k[i], n); ts_carve(p, b.v[i], n); }
+    b.passes = (end_bit + 7) / 8;
+    hipError_t e = hipMemcpyAsync(b.k[0], keys_in, n * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess) e = hipMemcpyAsync(b.v[0], vals_in, n * 4, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess)
+    {
+        uint32_t *ticket = ticket_of(b.rs);
+        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, ticket, 2);
+        int src = 0;
+        for (int ps = 0; ps < b.passes; ps++)
+        {
+            radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, 8 * ps, min(8, end_bit - 8 * ps), b.rs, ticket, s);
+            src ^= 1;
+        }
+        e = hipMemcpyAsync(keys_out, b.k[src], n * 4, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(vals_out, b.v[src], n * 4, hipMemcpyDeviceToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e == hipSuccess) e = hipGetLastError();
+    }
+    (void)hipFree(base);
+    return e == hipSuccess ? 0 : 2;
 }

@@ -118,7 +118,6 @@ __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int3
     g.rect[idx] = out_rect;
     g.clamped[idx] = out_clamped;
     g.depth[idx] = out_depth;
-    g.ids[idx] = (uint32_t)idx; // values of the depth sort (binning.hip step 1)
     float4 *r = g.rec + 4 * (size_t)idx;
     r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
     r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);

@@ -94,7 +94,6 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
     g.rect[idx] = out_rect;
     g.clamped[idx] = out_clamped;
     g.depth[idx] = out_depth;
-    g.ids[idx] = (uint32_t)idx;
     float4 *r = g.rec + 4 * (size_t)idx;
     r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
     r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);

@@ -42,15 +42,6 @@ constexpr int ROW = 20; // floats per entry row of the constants table:
 // (u_k = screen vertex k relative to the quadrant origin); row -1 is a dummy that fails every pixel's ecc test.
 
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-// Orders this wave's LDS accesses ACROSS LANES at this point of the program: the per-thread language model lets the
-// compiler merge or reorder the accesses of different lanes (it did: three groups' read-add-write sequences became three
-// reads and one common write); a wavefront-scope fence + wave_barrier pins them (no instruction is emitted: LDS executes a
-// wave's accesses in order).
-__device__ __forceinline__ void wave_lds_order()
-{
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-}
 __device__ __forceinline__ int lane_rank(unsigned long long m) // set bits of m below this lane
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));

@@ -28,6 +28,18 @@
 //   [0..5] dL/dv{1,2,3}_2D   [6] dL/dopacity   [7..9] dL/drgb   [10..12] dL/dnormal_view   [13..15] dL/dv_depth
 #define TS_GRAD_FLOATS 16
 
+// Scratch of one stable LSD radix pass over n (key, value) pairs (binning.hip): per-chunk digit counts, their per-slab
+// and per-digit prefixes.  One chunk = TS_RS_CHUNK consecutive pairs = one workgroup; one slab = 64 chunks.
+#define TS_RS_CHUNK 4096
+#define TS_RS_BINS 256
+struct RadixScratchView
+{
+    uint32_t *table;   // chunks x 256   count of digit d in chunk c, then (in place) its exclusive prefix inside the slab
+    uint32_t *slabtot; // slabs x 256    per-slab totals, then (in place) their exclusive prefix over the slabs
+    uint32_t *binbase; // 256            exclusive prefix of the digit totals
+    int chunks, slabs;
+};
+
 struct GeometryStateView
 {
     float4 *rec;             // P * 4 float4
@@ -35,23 +47,22 @@ struct GeometryStateView
     uint32_t *tiles_touched; // P
     uint2 *rect;             // P   x = minx | miny << 16, y = maxx | maxy << 16
     uint8_t *clamped;        // P   bit c set when colour channel c was clamped at 0
-    uint32_t *ids;           // P   0..P-1 (values of the depth sort)
-    uint32_t *depth_sorted;  // P   depth keys in ascending order (sort output, unused afterwards)
-    uint32_t *perm;          // P   triangle ids in (depth, id) order
+    uint32_t *sk[2], *sv[2]; // P each: ping-pong (key, value) buffers of the depth sort
+    uint32_t *depth_sorted;  //     = sk[1]: depth keys in ascending order (after the 4th pass)
+    uint32_t *perm;          //     = sv[1]: triangle ids in (depth, id) order
     uint32_t *tiles_sorted;  // P   tiles_touched[perm[i]]
     uint32_t *offsets;       // P   inclusive prefix sum of tiles_sorted: instance slots of the i-th nearest triangle
-    void *scan_temp;         //     shared by the depth sort and the scan
-    size_t scan_temp_bytes;
+    uint64_t *blocksum;      // ceil(P / 1024) + 2   per-block sums of tiles_sorted, then their exclusive prefix; [nblocks] = N
+    RadixScratchView rs;
 };
 
 struct BinningStateView
 {
-    uint32_t *tile_unsorted; // N   tile id of each instance, emitted in depth order
-    uint32_t *tile;          // N   sorted by tile (stable => depth order inside a tile)
-    uint32_t *vals_unsorted; // N
-    uint32_t *vals;          // N   triangle id per sorted instance
-    void *sort_temp;
-    size_t sort_temp_bytes;
+    uint32_t *k[2], *v[2];   // N each: ping-pong (tile id, triangle id) buffers; instances are emitted into k[0] / v[0]
+    uint32_t *tile;          //     = k[passes & 1]: sorted by tile (stable => depth order inside a tile)
+    uint32_t *vals;          //     = v[passes & 1]: triangle id per sorted instance
+    int passes;              // radix passes of 8 bits needed for the tile count
+    RadixScratchView rs;
 };
 
 struct ImageStateView
@@ -71,8 +82,14 @@ static inline void ts_carve(char *&p, T *&out, size_t count)
     p += count * sizeof(T);
 }
 
-size_t ts_scan_temp_bytes(int32_t P);                 // max(depth sort of P pairs, scan of P)
-size_t ts_sort_temp_bytes(int64_t N, int end_bit);    // tile sort of N pairs
+static inline void ts_carve_radix(char *&p, size_t n, RadixScratchView &r)
+{
+    r.chunks = (int)((n + TS_RS_CHUNK - 1) / TS_RS_CHUNK);
+    r.slabs = (r.chunks + 63) / 64;
+    ts_carve(p, r.table, (size_t)r.chunks * TS_RS_BINS);
+    ts_carve(p, r.slabtot, (size_t)r.slabs * TS_RS_BINS);
+    ts_carve(p, r.binbase, (size_t)TS_RS_BINS + 4); // + the tickets of the "last block finishes" kernels
+}
 
 static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView &v)
 {
@@ -83,15 +100,16 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.tiles_touched, n);
     ts_carve(p, v.rect, n);
     ts_carve(p, v.clamped, n);
-    ts_carve(p, v.ids, n);
-    ts_carve(p, v.depth_sorted, n);
-    ts_carve(p, v.perm, n);
+    ts_carve(p, v.sk[0], n);
+    ts_carve(p, v.sk[1], n);
+    ts_carve(p, v.sv[0], n);
+    ts_carve(p, v.sv[1], n);
+    v.depth_sorted = v.sk[1]; // four 8-bit passes: depth -> sk[0] -> sk[1] -> sk[0] -> sk[1]
+    v.perm = v.sv[1];
     ts_carve(p, v.tiles_sorted, n);
     ts_carve(p, v.offsets, n);
-    v.scan_temp_bytes = ts_scan_temp_bytes(P);
-    char *t;
-    ts_carve(p, t, v.scan_temp_bytes);
-    v.scan_temp = t;
+    ts_carve(p, v.blocksum, (n + 1023) / 1024 + 2);
+    ts_carve_radix(p, n, v.rs);
     return (size_t)(p - base) + TS_ALIGN;
 }
 
@@ -113,14 +131,14 @@ static inline size_t ts_carve_binning(char *base, int64_t N, int32_t W, int32_t 
     char *p = base;
     size_t n = (size_t)(N > 0 ? N : 0);
     int gx = (W + TS_TILE - 1) / TS_TILE, gy = (H + TS_TILE - 1) / TS_TILE;
-    ts_carve(p, v.tile_unsorted, n);
-    ts_carve(p, v.tile, n);
-    ts_carve(p, v.vals_unsorted, n);
-    ts_carve(p, v.vals, n);
-    v.sort_temp_bytes = ts_sort_temp_bytes(N, ts_higher_msb((uint32_t)(gx * gy)));
-    char *t;
-    ts_carve(p, t, v.sort_temp_bytes);
-    v.sort_temp = t;
+    ts_carve(p, v.k[0], n);
+    ts_carve(p, v.k[1], n);
+    ts_carve(p, v.v[0], n);
+    ts_carve(p, v.v[1], n);
+    v.passes = (ts_higher_msb((uint32_t)(gx * gy)) + 7) / 8; // tile bits only (see binning.hip)
+    v.tile = v.k[v.passes & 1];
+    v.vals = v.v[v.passes & 1];
+    ts_carve_radix(p, n, v.rs);
     return (size_t)(p - base) + TS_ALIGN;
 }
 
@@ -146,11 +164,19 @@ struct PreprocessArgs
 };
 
 void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s);
-hipError_t ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s);
-hipError_t ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);
-void ts_launch_emit_keys(int P, int grid_x, const GeometryStateView &g, const BinningStateView &b, hipStream_t s);
-hipError_t ts_sort_pairs(const BinningStateView &b, int64_t N, int end_bit, hipStream_t s);
+// binning.hip -- every step hand-written for gfx950 (the round-1 rocPRIM calls survive only as test comparators)
+void ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s);                 // (depth bits, id) -> perm
+void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);                  // tiles_sorted, block sums, N
+void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
+                         float *contrib_sum, float *contrib_max, hipStream_t s);             // offsets + instances (+ output clears)
+void ts_sort_pairs(const BinningStateView &b, int64_t N, int ntiles, hipStream_t s);          // stable, tile bits only
 void ts_launch_tile_ranges(int64_t N, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
+// rocPRIM comparators (tests only): same contracts as the hand-written steps, results into caller-provided device buffers
+int ts_compare_sort_pairs_rocprim(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
+                                  int end_bit, hipStream_t s);
+int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit,
+                       hipStream_t s);
+int ts_compare_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);
 
 struct RenderArgs
 {

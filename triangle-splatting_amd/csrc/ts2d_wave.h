@@ -14,6 +14,16 @@ __device__ __forceinline__ float bcast(float v, int j)
 }
 __device__ __forceinline__ uint32_t bcast(uint32_t v, int j) { return (uint32_t)__builtin_amdgcn_readlane((int)v, j); }
 
+// Orders this wave's LDS accesses ACROSS LANES at this point of the program: the per-thread language model lets the compiler
+// merge or reorder the accesses of different lanes (it did: three lane groups' read-add-write sequences became three reads and
+// one common write); a wavefront-scope fence + wave_barrier pins them.  No instruction is emitted: LDS executes a wave's
+// accesses in order.
+__device__ __forceinline__ void wave_lds_order()
+{
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int CTRL, int ROW_MASK = 0xF>
 __device__ __forceinline__ float dpp(float v)
 {

@@ -1,8 +1,9 @@
 """Photometric losses backed by the fused HIP kernels of libts2d.so (include/ts_loss.h).
 
 Same call surface as the reference's `L1`, `SSIMLoss`, `ssimLoss` (src/diff_recon/trainers/trainer_utils.py:323-324, 96-103,
-349): `L1(t1, t2)` and `ssimLoss(img1, img2)` return 0-dim tensors and are differentiable with respect to their FIRST
-argument (the render; the ground truth never requires grad in the trainers).  Inputs of 2, 3 or 4 dimensions are accepted
+349): `L1(t1, t2)` is differentiable with respect to both arguments (the trainer's affine regulariser passes two renders,
+VanillaTS_trainer.py:103); `ssimLoss(img1, img2)` and the fused loss with respect to their FIRST argument (the render; the
+ground truth never requires grad in the trainers) -- a second argument that requires grad raises instead of dropping it.  Inputs of 2, 3 or 4 dimensions are accepted
 like `normalize_shape` (trainer_utils.py:80-93); a batch dimension folds into channels, which is what the reference's
 depthwise convolution + global mean computes.
 
@@ -61,7 +62,13 @@ class _Photometric(torch.autograd.Function):
         _check_inputs(image, gt)
         image_c, gt_c = image.contiguous(), gt.contiguous()
         dev = image.device
-        need_grad = bool(image.requires_grad)
+        # the SSIM term is differentiated with respect to its FIRST argument only (as every caller in the reference uses it); a
+        # second argument that requires grad there would silently lose its gradient, so it is refused.  The L1 term is
+        # antisymmetric and hands -g to the second argument (VanillaTS_trainer.py:103 passes two renders to L1).
+        if gt.requires_grad and float(w_ssim) != 0.0:
+            raise RuntimeError("ssimLoss / photometric_loss (MI355X build) differentiate with respect to the first argument only; "
+                               "detach the second one or swap the arguments")
+        need_grad = bool(image.requires_grad or gt.requires_grad)
         with torch.cuda.device(dev):
             nbytes = _lib.tsl_workspace_bytes(c, h, w)
             ws = torch.empty((nbytes,), device=dev, dtype=torch.uint8)
@@ -86,7 +93,7 @@ class _Photometric(torch.autograd.Function):
             _native._check(_lib.tsl_photometric_backward(image.data_ptr(), gt.data_ptr(), c, h, w, w_l1, w_ssim, ws.data_ptr(),
                                                          ws.numel(), go.data_ptr(), g.data_ptr(),
                                                          torch.cuda.current_stream().cuda_stream), "photometric_loss backward")
-        return g, None, None, None
+        return (g if ctx.needs_input_grad[0] else None), (-g if ctx.needs_input_grad[1] else None), None, None
 
 
 def photometric_loss(image: torch.Tensor, gt: torch.Tensor, w_L1: float, w_ssim: float) -> torch.Tensor:

@@ -159,8 +159,8 @@ class factored_sh_grads:
 def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree: int, M: int, group=None,
                                mean: bool = False, expand_fn=None) -> torch.Tensor:
     """All-gathers the sink's factors over the ranks and returns the dense dL_dshs (P, M, 3) summed over every view of
-    every rank (divided by the world size with mean=True, like GradBucket).  Every rank must hold the same number of
-    views.  `expand_fn(vertex, campos (V,3), dL_dcolor (V,P,3), sh_degree, M)` defaults to the HIP kernel behind
+    every rank (divided by the world size with mean=True, like GradBucket).  Ranks may hold different numbers of views
+    (the shorter ones are padded with zero-colour rows).  `expand_fn(vertex, campos (V,3), dL_dcolor (V,P,3), sh_degree, M)` defaults to the HIP kernel behind
     `_C.sh_grad_expand`; the CPU tests inject a reference implementation to exercise the protocol over gloo."""
     if not sink.colors:
         raise RuntimeError("no SH-mode backward pass ran under factored_sh_grads()")
@@ -177,6 +177,17 @@ def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree
         local[v, 3 * P + 3] = 0.0
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
     if world > 1:
+        # ranks may hold different numbers of views (shard_views with num_views % world != 0): agree on the largest count
+        # and pad with zero-colour rows, which add nothing to the sum; a different triangle count is a caller error
+        meta = torch.tensor([V, -V, P, -P], device=local.device, dtype=torch.int64)
+        dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
+        vmax, pmax, pmin = int(meta[0]), int(meta[2]), -int(meta[3])
+        if pmax != pmin:
+            raise RuntimeError(f"exchange_factored_sh_grads: ranks disagree on the number of triangles ({pmin} .. {pmax})")
+        if vmax != V:
+            pad = torch.zeros((vmax - V, 3 * P + 4), device=local.device, dtype=torch.float32)
+            local = torch.cat([local, pad], dim=0)
+            V = vmax
         gathered = torch.empty((world * V, 3 * P + 4), device=local.device, dtype=torch.float32)
         dist.all_gather_into_tensor(gathered, local, group=group)
     else:
