@@ -204,6 +204,11 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
 {
     __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
     __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+    // contrib_sum / contrib_max of the tile's first TCAP list entries, merged over the four quadrant waves before they leave
+    // as global atomics (one L2 line operation per (tile, triangle) instead of one per (quadrant, triangle))
+    constexpr int TCAP = 1024;
+    __shared__ float tsum[RICH ? TCAP : 1];
+    __shared__ int tmax[RICH ? TCAP : 1];
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -216,6 +221,11 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
     const float fx = (float)lx, fy = (float)ly, OX = (float)X0, OY = (float)Y0;
     const uint2 range = ranges[tile];
     const int len = (int)(range.y - range.x);
+    if (RICH)
+    {
+        for (int k = threadIdx.x; k < min(len, TCAP); k += 256) { tsum[k] = 0.0f; tmax[k] = 0; }
+        __syncthreads();
+    }
     const float g2 = 2.0f * a.gamma;
     const float bg0 = a.background[0], bg1 = a.C > 1 ? a.background[1] : 0.0f, bg2 = a.C > 2 ? a.background[2] : 0.0f;
     float *cst = cst_all[wave] + ROW;
@@ -348,10 +358,19 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
         if (RICH && ((any >> lane) & 1))
         {
             const float2 o = *(const float2 *)(cst + lane * ROW + 18);
-            if (o.x > 0.0f)
+            if (o.x > 0.0f && base + lane < TCAP)
             {
+                atomicAdd(&tsum[base + lane], o.x);                  // LDS; the four waves of the tile meet here
+                atomicMax(&tmax[base + lane], __float_as_int(o.y)); // both >= 0: int order == float order
+            }
+            else if (o.x > 0.0f)
+            {
+                // Scattered global atomics cost one L2 line operation each (~20 G/s chip-wide, tools/atomic_scope_bench.hip): at two
+                // per (entry, quadrant) the forward was bound by them, not by its arithmetic.  A running maximum only grows, so a
+                // (possibly stale, hence smaller) plain read that already exceeds this wave's value proves the atomic redundant:
+                // ~60 % of the max operations disappear.
                 unsafeAtomicAdd(contrib_sum + id, o.x);
-                atomicMax((int *)contrib_max + id, __float_as_int(o.y));
+                if (o.y > contrib_max[id]) atomicMax((int *)contrib_max + id, __float_as_int(o.y));
             }
         }
 #endif
@@ -361,6 +380,24 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
     if (lane == 0)
         for (int i = 0; i < 8; i++) atomicAdd(&g_stats_group[i], stat_acc[i]);
 #endif
+    if (RICH)
+    {
+        __syncthreads(); // the only rendezvous of the four quadrant waves: the tile's merged contribution statistics leave
+        for (int k = threadIdx.x; k < min(len, TCAP); k += 256)
+        {
+            const float sm = tsum[k];
+            if (sm > 0.0f)
+            {
+                const uint32_t tid = point_list[range.x + k];
+                const float mx = __int_as_float(tmax[k]);
+                // scattered global atomics cost one L2 line operation each (~20 G/s chip-wide, tools/atomic_scope_bench.hip): at two
+                // per (entry, quadrant) the forward was bound by them, not by its arithmetic.  A running maximum only grows, so a
+                // (possibly stale, hence smaller) plain read that already exceeds this tile's value proves the atomic redundant.
+                unsafeAtomicAdd(contrib_sum + tid, sm);
+                if (mx > contrib_max[tid]) atomicMax((int *)contrib_max + tid, __float_as_int(mx));
+            }
+        }
+    }
     if (inside)
     {
         const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
