@@ -220,11 +220,13 @@ def main():
             dom, dom_ms, dom_n = rows[0]
             dom_avg = dom_ms / max(dom_n, 1)
             ach = alg[dom] / (dom_avg * 1e-3) / 1e9
+            headline = (P, W, H, D, args.rasterizer) == (1_000_000, 1920, 1080, 3, "2D")
             result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
-                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom),
+                                  "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom) if headline else None,
                                   "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(dom_avg, 4),
-                                  "launches_timed": dom_n, "valu": valu_util(dom),
-                                  "note": "blend kernels are VALU-bound (PMC), not HBM-bound; see DESIGN.md section 4"}
+                                  "launches_timed": dom_n, "compute": compute_side(dom, dom_avg, headline),
+                                  "note": "the blend kernels are bound by VALU issue, not by HBM (DESIGN.md section 4): `compute` is the "
+                                          "roofline they sit on; every duration is this run's timed-region HIP events"}
         else:
             result["roofline"] = None
         if world == 1 and not args.no_cpu_baseline:
@@ -238,23 +240,44 @@ def main():
         dist.destroy_process_group()
 
 
-def valu_util(kernel):
-    """VALU utilisation of `kernel` from the committed SQ-counter pass (profiles/valu_util.json, tools/collect_valu_util.sh):
-    the blend kernels are bound by VALU issue, so this -- not the HBM fraction -- is the roofline they sit on."""
+PMC_NAMES = {"render_fwd": "render_fwd_group_kernel<rich>", "render_bwd": "render_bwd_group_kernel<rich>"}
+TRAFFIC_NAMES = {"render_fwd": "render_fwd_group", "render_bwd": "render_bwd_group", "emit_keys": "scan_emit", "scan": "gather_blocksum"}
+USEFUL_FLOP_PER_PAIR = {"render_fwd": 60, "render_bwd": 175}  # fp32 operations a blended (pixel, triangle) pair needs
+FP32_VECTOR_PEAK = 157.3e12                                   # MI355X_MICROARCH.md
+
+
+def compute_side(kernel, avg_ms, headline):
+    """The roofline the blend kernels actually sit on (they are VALU-bound), from the committed SQ-counter pass
+    of the same workload (profiles/blend_pmc.json, tools/collect_blend_pmc.sh) and the lane-group statistics
+    (profiles/blend_stats.json): VALU issue-slot utilisation = SQ_INSTS_VALU x 2 cycles (wave64 on a SIMD-32) over
+    SIMDs x kernel cycles -- at most 1 by construction --, blended (pixel, triangle) pairs per second and the useful fp32
+    rate as a fraction of the 157 TFLOP/s vector peak.  Durations: the timed-region HIP events of THIS run."""
+    out = {}
     try:
-        v = json.load(open(os.path.join(ROOT, "profiles", "valu_util.json"))).get(kernel)
-        return None if v is None else {"busy_frac": v["valu_busy_frac"], "cycles_per_inst": v["cycles_per_valu_inst"],
-                                       "insts_per_launch": v["valu_insts_per_launch"]}
+        v = json.load(open(os.path.join(ROOT, "profiles", "blend_pmc.json"))).get(PMC_NAMES.get(kernel, ""))
+        if v:
+            out.update(valu_insts_per_launch=v["SQ_INSTS_VALU"], valu_issue_slot_frac=v["valu_issue_frac_at_2cyc"],
+                       transcendental_insts_per_launch=v.get("SQ_INSTS_VALU_TRANS_F32"), lds_busy_frac=v.get("lds_busy_frac"),
+                       avg_waves_per_simd=v.get("avg_waves_per_simd"), wave_cycle_split=v.get("wave_cycle_split"))
     except Exception:
-        return None
+        pass
+    try:
+        st = json.load(open(os.path.join(ROOT, "profiles", "blend_stats.json")))
+        if headline and kernel in USEFUL_FLOP_PER_PAIR:
+            pairs = st["pixel_entry_pairs_blended"]
+            out.update(pairs_per_launch=pairs, pairs_per_s=round(pairs / (avg_ms * 1e-3), 1), lane_occupancy=round(st["lane_occupancy"], 4),
+                       useful_flop_frac_of_fp32_vector_peak=round(pairs * USEFUL_FLOP_PER_PAIR[kernel] / (avg_ms * 1e-3) / FP32_VECTOR_PEAK, 5))
+    except Exception:
+        pass
+    return out or None
 
 
 def hbm_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/hbm_traffic.json, produced by
-    tools/collect_hbm_traffic.sh on the same workload), or None when that file has no entry."""
+    tools/collect_hbm_traffic.sh on the same workload: FETCH_SIZE x2, WRITE_SIZE calibrated on the gradient-record memset), or None."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
-        return json.load(open(path)).get(kernel, {}).get("hbm_bytes_per_launch")
+        return json.load(open(path)).get(TRAFFIC_NAMES.get(kernel, kernel), {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 

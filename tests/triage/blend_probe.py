@@ -27,5 +27,12 @@ if hasattr(_C._lib, "ts2d_stats_read_group"):
     v = list(buf); N = hf["num_rendered"]
     print(f"N {N}; visits {v[0]}; (entry,block) survivors {v[1]}; (entry,quadrant) survivors {v[7]}; steps {v[2]}; windows {v[3]}; "
           f"pairs {v[4]}; waves {v[5]}; batches {v[6]}")
+    import json
+    json.dump({"scene": f"S(P={P}, {W}x{H}, D={D}, seed=42)", "num_rendered": N, "list_entries_visited_per_quadrant_wave_total": v[0],
+               "entry_block_survivors": v[1], "entry_quadrant_survivors": v[7], "wave_steps": v[2], "windows": v[3],
+               "pixel_entry_pairs_blended": v[4], "quadrant_waves": v[5], "batches_with_work": v[6],
+               "lanes_hit_per_step": v[4] / max(v[2], 1), "lane_occupancy": v[4] / max(v[2], 1) / 64,
+               "steps_per_entry_quadrant_survivor": v[2] / max(v[7], 1)},
+              open(os.path.join(ROOT, "gpurun_out", "blend_stats.json"), "w"), indent=1)
     print(f"steps per (entry,quadrant) survivor {v[2]/max(v[7],1):.3f}; lanes per step {v[4]/max(v[2],1):.1f} ({v[4]/max(v[2],1)/64:.3f}); "
           f"steps per batch {v[2]/max(v[6],1):.1f}; windows per batch {v[3]/max(v[6],1):.2f}; block-survivors per step {v[1]/max(v[2],1):.2f}")

@@ -1,13 +1,22 @@
-# Round-end evidence: bench line (with cpu_baseline + reference_gpu) and rocprofv3 kernel stats for the 2D headline and the
-# 3D variant; PMC HBM traffic with tools/collect_hbm_traffic.sh (separate passes).  Outputs under gpurun_out/; the summaries
-# are condensed into profiles/ by tools/rocprof_summary.py.
+# Round evidence on one MI355X (gpurun): bench lines (2D headline with cpu_baseline + reference_gpu, 3D variant), rocprofv3 kernel
+# stats of the same bench command, SQ counters of the blend kernels, HBM traffic (separate --pmc passes), lane-group statistics
+# (stats build shipped as tools/bin/libts2d_stats.so).  Outputs under gpurun_out/; copy the summaries into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out
-timeout 300 python $R/bench.py > $R/gpurun_out/final_bench.json 2> $R/gpurun_out/final_bench.err
-timeout 300 python $R/bench.py --rasterizer 3D > $R/gpurun_out/final_bench3d.json 2>> $R/gpurun_out/final_bench.err
-rm -rf $R/gpurun_out/prof_final $R/gpurun_out/prof_final3d
+timeout 300 python $R/bench.py > $R/gpurun_out/${TAG}_bench.json 2> $R/gpurun_out/${TAG}_bench.err
+timeout 300 python $R/bench.py --rasterizer 3D > $R/gpurun_out/${TAG}_bench3d.json 2>> $R/gpurun_out/${TAG}_bench.err
+rm -rf $R/gpurun_out/prof_final
 timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final -- python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_final.log 2>&1
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_final3d -- python $R/bench.py --rasterizer 3D --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/prof_final3d.log 2>&1
+python $R/tools/rocprof_summary.py $(ls $R/gpurun_out/prof_final/*/*kernel_stats.csv | head -1) "python bench.py --steps 20 --warmup 3 --no-cpu-baseline" > $R/gpurun_out/${TAG}_kernel_stats.csv
 find $R/gpurun_out -name "*kernel_trace.csv" -delete
-tail -c 300 $R/gpurun_out/final_bench.json
+bash $R/tools/collect_blend_pmc.sh > /dev/null 2>&1
+bash $R/tools/collect_hbm_traffic.sh > /dev/null 2>&1
+if [ -f $R/tools/bin/libts2d_stats.so ]; then
+  L=$R/triangle-splatting_amd/diff_triangle_rasterization_2D/libts2d.so
+  cp $L /tmp/keep.so; cp $R/tools/bin/libts2d_stats.so $L
+  timeout 200 python $R/tests/triage/blend_probe.py > $R/gpurun_out/blend_stats.log 2>&1
+  cp /tmp/keep.so $L
+fi
+tail -c 400 $R/gpurun_out/${TAG}_bench.json

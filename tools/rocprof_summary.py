@@ -2,7 +2,7 @@
 import csv, re, sys
 
 def short(name):
-    m = re.search(r"(render_fwd_kernel|render_bwd_kernel|preprocess_fwd_kernel|preprocess_bwd_kernel|emit_keys_kernel|tile_ranges_kernel)(<[^>]*>)?", name)
+    m = re.search(r"(render\w*_kernel|preprocess\w*_kernel|scan_emit_kernel|gather_blocksum_kernel|rs_\w+_kernel|tile_ranges_kernel|zero_words_kernel)(<[^>]*>)?", name)
     if m:
         return m.group(0)
     m = re.search(r"rocprim::[A-Za-z0-9_]+::detail::(\w+)<rocprim::[A-Za-z0-9_]+::detail::(\w+)", name)

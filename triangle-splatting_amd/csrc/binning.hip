@@ -14,11 +14,11 @@
 //      6 passes x N x 12 B); stability keeps the depth order (and the id order among equal depths) inside a tile;
 //   5. tile ranges from the sorted tile ids.
 //
-// One radix pass (8-bit digit) = three kernels, no look-back spinning:
-//   rs_hist     one workgroup per chunk of 4096 pairs counts its digits in a 1 KB LDS table (ds_add_u32);
-//   rs_prefix   column prefix of the chunks x 256 table: in place inside slabs of 64 chunks (one thread per digit, coalesced
-//               rows), then -- by the last slab to finish, elected with one atomic ticket -- over the slab totals and
-//               over the 256 digit totals;
+// One radix pass (8-bit digit) = two kernels, no look-back spinning:
+//   rs_hist     one workgroup per chunk of 4096 pairs counts its digits in a 1 KB LDS table (ds_add_u32); the workgroup that
+//               arrives LAST in its slab of 64 chunks (one atomic ticket; the counts travel as write-through stores and
+//               L1-bypassing loads, so no L2 write-back fence is needed) turns the slab's rows into exclusive column
+//               prefixes, and the last slab to finish does the same over the slab totals and over the 256 digit totals;
 //   rs_scatter  the workgroup re-reads its chunk (each wave a contiguous quarter, 64 pairs per step): the lanes holding equal
 //               digits find each other with 8 ballots (wave64 match), rank = v_mbcnt of the match mask on top of the digit's
 //               running count; the pairs are parked in LDS in chunk-local sorted order and leave as coalesced runs.  Ranks
@@ -47,6 +47,32 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) //
     return (uint32_t)x;
 }
 
+// Elects the block that arrives last at `ticket` among `count` arrivals; the elected block resets the ticket for the next
+// launch and returns true on all of its threads.  Data handed to the elected block travels as write-through (sc0 sc1) stores and
+// L1-bypassing (sc1) loads on both sides (peer_store / peer_load): with every store drained (s_waitcnt vmcnt(0)) before the ticket
+// is taken, no L2 write-back fence is needed (MI355X_MICROARCH.md, "valid forms": a release fence per block costs 2-6 us).
+__device__ __forceinline__ bool last_arrival(uint32_t *ticket, uint32_t count)
+{
+    __shared__ bool elected;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        elected = (t == count - 1u);
+        if (elected) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return elected;
+}
+template <typename T>
+__device__ __forceinline__ T peer_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ void peer_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Digit counts of every chunk, and -- by the blocks that arrive last -- their prefixes: the last block of a slab (64 chunks)
+// turns the slab's rows into exclusive column prefixes and its totals; the last slab to finish turns the slab totals into
+// their prefix over the slabs and forms the exclusive prefix of the 256 digit totals.  One launch, no spinning.
 __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift, uint32_t mask,
                                                        RadixScratchView r)
 {
@@ -62,65 +88,50 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
         if (i < n) atomicAdd(&bins[(keys[i] >> shift) & mask], 1u);
     }
     __syncthreads();
-    r.table[(size_t)chunk * NB + t] = bins[t];
-}
+    peer_store(r.table + (size_t)chunk * NB + t, bins[t]);
 
-// Column prefix of the chunks x 256 digit-count table.  Block = one slab (64 chunks), thread = one digit.  The block that
-// takes the last ticket has every slab total in memory behind an agent-scope release / acquire pair and finishes the job:
-// prefix of the slab totals per digit, then the exclusive prefix of the 256 digit totals.
-__global__ void __launch_bounds__(NB) rs_prefix_kernel(RadixScratchView r, uint32_t *ticket)
-{
-    __shared__ uint32_t tot[NB];
-    __shared__ bool last;
-    const int b = threadIdx.x, slab = blockIdx.x;
-    const int c0 = slab * 64, c1 = min(r.chunks, c0 + 64);
+    const int slab = chunk >> 6, c0 = slab * 64, c1 = min(r.chunks, c0 + 64);
+    if (!last_arrival(r.tickets + 2 + slab, (uint32_t)(c1 - c0))) return;
     uint32_t run = 0;
-    for (int c = c0; c < c1; c += 8)
+    for (int c = c0; c < c1; c += 16)
     {
-        uint32_t v[8];
+        uint32_t v[16];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (c + k < c1) ? r.table[(size_t)(c + k) * NB + b] : 0u;
+        for (int k = 0; k < 16; k++) v[k] = (c + k < c1) ? peer_load(r.table + (size_t)(c + k) * NB + t) : 0u;
 #pragma unroll
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < 16; k++)
         {
-            if (c + k < c1) r.table[(size_t)(c + k) * NB + b] = run;
+            if (c + k < c1) r.table[(size_t)(c + k) * NB + t] = run;
             run += v[k];
         }
     }
-    r.slabtot[(size_t)slab * NB + b] = run;
-    __syncthreads();
-    if (b == 0)
+    peer_store(r.slabtot + (size_t)slab * NB + t, run);
+
+    if (!last_arrival(r.tickets, (uint32_t)r.slabs)) return;
+    uint32_t total = 0;
+    for (int s = 0; s < r.slabs; s += 8)
     {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // MI355X_MICROARCH.md: the compiler may drop this wait behind the release
-        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (t == (uint32_t)r.slabs - 1u);
-        if (last)
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = (s + k < r.slabs) ? peer_load(r.slabtot + (size_t)(s + k) * NB + t) : 0u;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
         {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // ready for the next pass
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (s + k < r.slabs) r.slabtot[(size_t)(s + k) * NB + t] = total;
+            total += v[k];
         }
     }
-    __syncthreads();
-    if (!last) return;
-    uint32_t total = 0;
-    for (int s = 0; s < r.slabs; s++)
-    {
-        // sc1 loads: the other slabs' totals were written by other CUs (this CU's L1 may hold stale lines)
-        const uint32_t v = __hip_atomic_load(r.slabtot + (size_t)s * NB + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r.slabtot[(size_t)s * NB + b] = total;
-        total += v;
-    }
-    tot[b] = total;
+    __shared__ uint32_t tot[NB];
+    tot[t] = total;
     __syncthreads();
     for (int d = 1; d < NB; d <<= 1) // inclusive Hillis-Steele over the 256 digit totals
     {
-        const uint32_t add = (b >= d) ? tot[b - d] : 0u;
+        const uint32_t add = (t >= d) ? tot[t - d] : 0u;
         __syncthreads();
-        tot[b] += add;
+        tot[t] += add;
         __syncthreads();
     }
-    r.binbase[b] = tot[b] - total;
+    r.binbase[t] = tot[t] - total;
 }
 
 // One workgroup = one chunk of CH pairs; wave w owns the w-th quarter (KB steps of 64 consecutive pairs, held in registers).
@@ -215,11 +226,10 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
 }
 
 void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift, int nbits,
-                const RadixScratchView &r, uint32_t *ticket, hipStream_t s)
+                const RadixScratchView &r, hipStream_t s)
 {
     const dim3 grid((unsigned)r.chunks);
     hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, s, kin, n, shift, (1u << nbits) - 1u, r);
-    hipLaunchKernelGGL(rs_prefix_kernel, dim3((unsigned)r.slabs), dim3(NB), 0, s, r, ticket);
     if (vin) hipLaunchKernelGGL((rs_scatter_kernel<false>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits, r);
     else hipLaunchKernelGGL((rs_scatter_kernel<true>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits, r);
 }
@@ -230,7 +240,6 @@ constexpr int SB = 1024; // triangles per scan block (256 threads x 4)
 __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometryStateView g, uint32_t *ticket)
 {
     __shared__ unsigned long long wsum[4];
-    __shared__ bool last;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i0 = blockIdx.x * SB + 4 * t;
     uint32_t v[4];
@@ -250,21 +259,8 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
     if (lane == 0) wsum[wave] = sum;
     __syncthreads();
     const int nblocks = gridDim.x;
-    if (t == 0)
-    {
-        g.blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        last = (tk == (uint32_t)nblocks - 1u);
-        if (last)
-        {
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        }
-    }
-    __syncthreads();
-    if (!last) return;
+    if (t == 0) peer_store((unsigned long long *)g.blocksum + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (!last_arrival(ticket, (uint32_t)nblocks)) return;
     // the last block to finish turns the block sums into their exclusive prefix; blocksum[nblocks] = N
     __shared__ unsigned long long carry;
     if (t == 0) carry = 0;
@@ -273,7 +269,7 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
     {
         const int b = b0 + t;
         unsigned long long x = 0;
-        if (b < nblocks) x = __hip_atomic_load(g.blocksum + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b < nblocks) x = peer_load((const unsigned long long *)g.blocksum + b);
         // inclusive scan over the 256 threads: inside the wave by shuffles, across the four waves through LDS
         unsigned long long inc = x;
         for (int o = 1; o < 64; o <<= 1)
@@ -309,6 +305,8 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     const int i = blockIdx.x * 256 + t;
     // output clears that used to be three memset launches: tile ranges (rasterizer.cu:223) and the contribution statistics
     for (int k = i; k < ntiles; k += gridDim.x * 256) ranges[k] = make_uint2(0u, 0u);
+    if (b.rs.tickets)
+        for (int k = i; k < b.rs.slabs + 8; k += gridDim.x * 256) b.rs.tickets[k] = 0u; // the tile sort's tickets
     if (contrib_sum && i < P)
     {
         contrib_sum[i] = 0.0f;
@@ -401,23 +399,16 @@ __global__ void zero_words_kernel(uint32_t *p, int n)
 }
 } // namespace
 
-// The tickets of the "last block finishes" kernels: one word per geometry / binning state, kept at zero between launches
-// by the electing block itself; it lives in the last word of the state's digit-base array padding (binbase has 256 words,
-// the ticket is a separate word right behind the per-slab totals).
-static uint32_t *ticket_of(const RadixScratchView &r) { return r.binbase + TS_RS_BINS; }
-
 // Step 1: (depth bits, id) -> perm.  Depth keys are view-space z of visible triangles (> 0, so the unsigned bit
 // pattern is monotone) and 0 for culled ones, which emit nothing wherever they land.
 void ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
     if (P <= 0) return;
-    uint32_t *ticket = ticket_of(g.rs);
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, ticket, 2);
     const uint32_t *depth = (const uint32_t *)g.depth;
-    radix_pass(depth, nullptr, g.sk[0], g.sv[0], P, 0, 8, g.rs, ticket, s);
-    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, 8, 8, g.rs, ticket, s);
-    radix_pass(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, 16, 8, g.rs, ticket, s);
-    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, 24, 8, g.rs, ticket, s);
+    radix_pass(depth, nullptr, g.sk[0], g.sv[0], P, 0, 8, g.rs, s);
+    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, 8, 8, g.rs, s);
+    radix_pass(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, 16, 8, g.rs, s);
+    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, 24, 8, g.rs, s);
 }
 
 // Step 2: tiles_sorted = tiles_touched[perm], block sums -> exclusive prefix, blocksum[nblocks] = N.
@@ -425,7 +416,7 @@ void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
     if (P <= 0) return;
     const int nblocks = (P + SB - 1) / SB;
-    hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, ticket_of(g.rs) + 1);
+    hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, g.rs.tickets + 1);
 }
 
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
@@ -440,14 +431,12 @@ void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView 
 void ts_sort_pairs(const BinningStateView &b, int64_t N, int ntiles, hipStream_t s)
 {
     if (N <= 0) return;
-    uint32_t *ticket = ticket_of(b.rs);
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, ticket, 2);
     const int bits = ts_higher_msb((uint32_t)ntiles);
     int src = 0;
     for (int p = 0; p < b.passes; p++)
     {
         const int nbits = min(8, bits - 8 * p);
-        radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, 8 * p, nbits, b.rs, ticket, s);
+        radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, 8 * p, nbits, b.rs, s);
         src ^= 1;
     }
 }
@@ -504,12 +493,11 @@ int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
     if (e == hipSuccess) e = hipMemcpyAsync(b.v[0], vals_in, n * 4, hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess)
     {
-        uint32_t *ticket = ticket_of(b.rs);
-        hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, ticket, 2);
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((b.rs.slabs + 8 + 255) / 256)), dim3(256), 0, s, b.rs.tickets, b.rs.slabs + 8);
         int src = 0;
         for (int ps = 0; ps < b.passes; ps++)
         {
-            radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, 8 * ps, min(8, end_bit - 8 * ps), b.rs, ticket, s);
+            radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, 8 * ps, min(8, end_bit - 8 * ps), b.rs, s);
             src ^= 1;
         }
         e = hipMemcpyAsync(keys_out, b.k[src], n * 4, hipMemcpyDeviceToDevice, s);

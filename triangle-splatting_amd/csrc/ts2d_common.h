@@ -37,6 +37,7 @@ struct RadixScratchView
     uint32_t *table;   // chunks x 256   count of digit d in chunk c, then (in place) its exclusive prefix inside the slab
     uint32_t *slabtot; // slabs x 256    per-slab totals, then (in place) their exclusive prefix over the slabs
     uint32_t *binbase; // 256            exclusive prefix of the digit totals
+    uint32_t *tickets; // TS_RS_TICKETS  "last block finishes" tickets: [0] pass, [1] scan blocks, [2 + slab] per slab; zero between launches
     int chunks, slabs;
 };
 
@@ -88,7 +89,8 @@ static inline void ts_carve_radix(char *&p, size_t n, RadixScratchView &r)
     r.slabs = (r.chunks + 63) / 64;
     ts_carve(p, r.table, (size_t)r.chunks * TS_RS_BINS);
     ts_carve(p, r.slabtot, (size_t)r.slabs * TS_RS_BINS);
-    ts_carve(p, r.binbase, (size_t)TS_RS_BINS + 4); // + the tickets of the "last block finishes" kernels
+    ts_carve(p, r.binbase, (size_t)TS_RS_BINS);
+    ts_carve(p, r.tickets, (size_t)r.slabs + 8);
 }
 
 static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView &v)
