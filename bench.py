@@ -129,26 +129,27 @@ def main():
     M = shs.shape[1]
     if world > 1:
         shapes = [vertex.shape, opacity.shape, torch.Size((P, 2))] + ([] if factored else [shs.shape])
-        bucket = GradBucket(shapes, dev)
+        bucket = GradBucket(shapes, dev, names=["vertex", "opacity", "center2D"] + ([] if factored else ["color"]))
     sink = parallel.ShGradSink()
 
     state = {}
 
     def step():
         center2D = torch.zeros((P, 2), device=dev, requires_grad=True)  # like triangle_renderer.py:67
-        if factored:  # SH gradients leave the backward as (dL_dRGB, campos) factors, see parallel.py
-            with parallel.factored_sh_grads(sink):
+        if bucket is not None:
+            # N > 1: the backward kernels write dL_dvertex / dL_dopacity / dL_dcenter2D (and, with --dense-exchange, dL_dshs)
+            # straight into the exchange bucket; its reduce-scatter + all-gather starts on a side stream as soon as the backward
+            # is queued and overlaps the factored SH-gradient exchange + expansion (parallel.py)
+            with bucket.capture(), parallel.factored_sh_grads(sink, enabled=factored):
                 out = raster(vertex, center2D, opacity, shs=shs)
                 torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
-            bucket.pack([vertex.grad, opacity.grad, center2D.grad])
-            bucket.all_reduce_async()
-            state["shs_grad"] = parallel.exchange_factored_sh_grads(sink, vertex, D, M)  # summed over all ranks' views
-            bucket.wait()
+            bucket.reduce_async()
+            if factored:
+                state["shs_grad"] = parallel.exchange_factored_sh_grads(sink, vertex, D, M)  # summed over all ranks' views
+            state["grads"] = bucket.wait()
         else:
             out = raster(vertex, center2D, opacity, shs=shs)
             torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
-            if bucket is not None:
-                bucket.all_reduce([vertex.grad, opacity.grad, center2D.grad, shs.grad])
         state["num_rendered"] = out[0].grad_fn.num_rendered
         state["image"] = out[0]
         vertex.grad = None

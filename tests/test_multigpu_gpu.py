@@ -1,0 +1,123 @@
+"""Image-parallel equivalence through the REAL rasterizer: two ranks (two processes sharing the one GPU of the test box, gloo
+transport) render one view each, exchange gradients exactly as bench.py --gpus N does (backward kernels writing into the
+exchange bucket, factored SH-gradient exchange, reduced render statistics), and the result must equal one process rendering both
+views and summing.  Hardware with >= 2 GPUs runs the same code over RCCL (bench.py); this test pins the protocol and the
+"2 ranks x 1 view == 1 rank x 2 views" semantics."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+P, W, H, D = 6000, 200, 144, 2
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _view(rank):
+    import synthetic
+    cam = synthetic.camera(W, H)
+    if rank > 0:
+        view = cam["viewmatrix"].copy()
+        shift = np.array([9.0 * rank, -4.0 * rank, 0.0], np.float32)
+        view[3, :3] -= shift * np.array([-1, 1, -1], np.float32)
+        cam["viewmatrix"] = view
+        cam["projmatrix"] = (view @ synthetic.projection_matrix(cam["tanfovx"], cam["tanfovy"]).T).astype(np.float32)
+        cam["campos"] = np.array([0, 0, synthetic.CAM_DIST], np.float32) + shift
+    return cam
+
+
+def _render(s, cam, variant, dev, vertex, shs, opacity, bucket=None, sink=None):
+    from diff_triangle_rasterization_2D import TriangleRasterizationSettings, parallel
+    if variant == 3:
+        from diff_triangle_rasterization_3D import TriangleRasterizer
+    else:
+        from diff_triangle_rasterization_2D import TriangleRasterizer
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs = TriangleRasterizationSettings(
+        image_width=W, image_height=H, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], viewmatrix=t(cam["viewmatrix"]),
+        projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]), sh_degree=D, gamma=1.0, scale_modifier=1.0, background_depth=50.0,
+        background=t(s["background"]), back_culling=False, rich_info=True, debug=False)
+    c2d = torch.zeros((P, 2), device=dev, requires_grad=True)
+    g = [t(s["dL_dout_feature"]), t(s["dL_dout_depth"]), t(s["dL_dout_normal"])]
+    if bucket is not None:
+        with bucket.capture(), parallel.factored_sh_grads(sink):
+            out = TriangleRasterizer(rs)(vertex, c2d, opacity, shs=shs)
+            torch.autograd.backward([out[0], out[2], out[3]], g)
+    else:
+        out = TriangleRasterizer(rs)(vertex, c2d, opacity, shs=shs)
+        torch.autograd.backward([out[0], out[2], out[3]], g)
+    return out, c2d
+
+
+def _worker(rank, world, port, variant, q):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    sys.path[:0] = [root, os.path.join(root, "triangle-splatting_amd"), here]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synthetic
+        from diff_triangle_rasterization_2D import parallel
+        dev = torch.device("cuda", 0)
+        s = synthetic.scene(P, W, H, D, seed=77)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        M = s["shs"].shape[1]
+        mk = lambda: (t(s["vertex"]).requires_grad_(True), t(s["shs"]).requires_grad_(True), t(s["opacity"]).requires_grad_(True))
+
+        # --- this rank's view, exchanged like bench.py --gpus 2 ---
+        vertex, shs, opacity = mk()
+        bucket = parallel.GradBucket([vertex.shape, opacity.shape, torch.Size((P, 2))], dev, names=["vertex", "opacity", "center2D"])
+        sink = parallel.ShGradSink()
+        out, _ = _render(s, _view(rank), variant, dev, vertex, shs, opacity, bucket, sink)
+        bucket.reduce_async()
+        shs_grad = parallel.exchange_factored_sh_grads(sink, vertex, D, M)
+        g_vertex, g_opacity, g_c2d = [x.clone() for x in bucket.wait()]
+        stats = parallel.reduce_render_stats({"radii": out[1].clone(), "contrib_sum": out[4].clone(), "contrib_max": out[5].clone(),
+                                              "visible_count": (out[1] > 0).to(torch.int32)})
+
+        # --- reference: this process renders BOTH views and sums ---
+        v2, s2, o2 = mk()
+        c2d_sum = torch.zeros((P, 2), device=dev)
+        ref_stats = None
+        for r in range(world):
+            o, c2d = _render(s, _view(r), variant, dev, v2, s2, o2)
+            c2d_sum += c2d.grad
+            cur = {"radii": o[1], "contrib_sum": o[4], "contrib_max": o[5], "visible_count": (o[1] > 0).to(torch.int32)}
+            ref_stats = cur if ref_stats is None else {k: (ref_stats[k] + cur[k] if "count" in k else torch.maximum(ref_stats[k], cur[k]))
+                                                       for k in cur}
+        rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+        errs = {"vertex": rel(g_vertex, v2.grad), "opacity": rel(g_opacity, o2.grad), "center2D": rel(g_c2d, c2d_sum), "shs": rel(shs_grad, s2.grad)}
+        ok = all(e < 2e-5 for e in errs.values())  # fp32 summation order only (atomics, all-reduce)
+        ok = ok and all(torch.equal(stats[k], ref_stats[k]) for k in ("radii", "visible_count"))
+        ok = ok and all(torch.allclose(stats[k], ref_stats[k], rtol=1e-6, atol=0) for k in ("contrib_sum", "contrib_max"))
+        ok = ok and shs.grad is None  # factored: the dense per-view dL_dshs was never formed
+        q.put((rank, bool(ok), errs))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_two_ranks_one_view_each_equals_one_rank_two_views(variant):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, variant, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    res = [q.get(timeout=10) for _ in range(2)]
+    assert all(ok for _, ok, _ in res), res

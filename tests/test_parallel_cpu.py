@@ -183,6 +183,66 @@ def test_factored_sh_exchange_uneven_views_world2(hip_lib_built):
     assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
 
 
+def _oracle_views_worker(rank, world, port, q):
+    """2 ranks x 1 view == 1 rank x 2 views, with REAL gradients and no GPU: the CPU oracle (test infrastructure) stands in for the
+    rasterizer, the exchange is the product's (GradBucket + reduce_render_stats over gloo)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.dirname(here), os.path.join(os.path.dirname(here), "triangle-splatting_amd"), here]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        import helpers
+        import synthetic
+        from diff_triangle_rasterization_2D import parallel
+
+        P, W, H, D = 400, 64, 48, 1
+        s = synthetic.scene(P, W, H, D, seed=11)
+
+        def view(r):
+            sv = dict(s)
+            if r > 0:
+                vm = s["viewmatrix"].copy()
+                shift = np.array([6.0 * r, -2.0 * r, 0.0], np.float32)
+                vm[3, :3] -= shift * np.array([-1, 1, -1], np.float32)
+                sv["viewmatrix"] = vm
+                sv["projmatrix"] = (vm @ synthetic.projection_matrix(s["tanfovx"], s["tanfovy"]).T).astype(np.float32)
+                sv["campos"] = np.array([0, 0, synthetic.CAM_DIST], np.float32) + shift
+            of = helpers.oracle_forward(sv, True)
+            return of, helpers.oracle_backward(sv, of, True)
+
+        of, ob = view(rank)
+        bucket = parallel.GradBucket([torch.Size(ob[k].shape) for k in ("dL_dvertex", "dL_dopacity", "dL_dcenter2D", "dL_dshs")], "cpu",
+                                     names=["vertex", "opacity", "center2D", "color"])
+        got = bucket.all_reduce([torch.from_numpy(ob[k]) for k in ("dL_dvertex", "dL_dopacity", "dL_dcenter2D", "dL_dshs")])
+        stats = parallel.reduce_render_stats({"radii": torch.from_numpy(of["radii"]), "contrib_max": torch.from_numpy(of["contrib_max"])})
+        both = [view(r) for r in range(world)]
+        ok = True
+        for g, k in zip(got, ("dL_dvertex", "dL_dopacity", "dL_dcenter2D", "dL_dshs")):
+            want = sum(torch.from_numpy(b[1][k]).double() for b in both)
+            ok = ok and torch.allclose(g.double(), want, rtol=1e-5, atol=1e-6 * float(want.abs().max()))
+        ok = ok and torch.equal(stats["radii"], torch.from_numpy(np.maximum(both[0][0]["radii"], both[1][0]["radii"])))
+        ok = ok and torch.equal(stats["contrib_max"], torch.from_numpy(np.maximum(both[0][0]["contrib_max"], both[1][0]["contrib_max"])))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_one_view_each_equals_one_rank_two_views_oracle(hip_lib_built):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_oracle_views_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(2)) == {0: True, 1: True}
+
+
 def test_factored_sink_context_and_errors(hip_lib_built):
     import diff_triangle_rasterization_2D as pkg
     from diff_triangle_rasterization_2D import parallel

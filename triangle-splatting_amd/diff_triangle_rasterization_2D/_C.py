@@ -236,9 +236,11 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
 def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                                  background_depth, background, vertex, shs, feature, opacity, num_rendered, radii,
                                  geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
-                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False):
+                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False, out=None):
     """`sh_factored=True` (SH mode only; TS2D_FLAG_SH_FACTORED): dL_dshs is not formed (returned as None) and the fourth
-    result holds the clamp-masked colour gradient dL_dRGB (P, 3) for `sh_grad_expand` -- see parallel.py."""
+    result holds the clamp-masked colour gradient dL_dRGB (P, 3) for `sh_grad_expand` -- see parallel.py.
+    `out`: optional dict of preallocated contiguous float32 device tensors ("vertex" (P,3,3), "center2D" (P,2), "opacity" (P,1),
+    "color" = dL_dshs (P,M,3) or dL_dfeature (P,C)) that the library writes instead of fresh allocations (parallel.GradBucket)."""
     P = vertex.size(0)
     H, W = dL_dout_feature.size(1), dL_dout_feature.size(2)  # extension_interface.cu:182-183
     use_shs = _use_shs(shs, feature)
@@ -258,15 +260,27 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
         stream = torch.cuda.current_stream().cuda_stream
         alloc = torch.zeros if P == 0 else torch.empty  # every element is written by the library when P > 0
         opts = dict(device=dev, dtype=vertex.dtype)
-        dL_dvertex = alloc((P, 3, 3), **opts)
-        dL_dcenter2D = alloc((P, 2), **opts)
+        out = out or {}
+
+        def placed(name, shape, fallback):
+            t = out.get(name)
+            if t is None:
+                return fallback(shape, **opts)
+            if tuple(t.shape) != tuple(shape) or not t.is_contiguous() or t.dtype != torch.float32 or t.device != dev:
+                raise RuntimeError(f"preallocated gradient output '{name}' must be a contiguous float32 {tuple(shape)} tensor on {dev}")
+            if P == 0:
+                t.zero_()
+            return t
+
+        dL_dvertex = placed("vertex", (P, 3, 3), alloc)
+        dL_dcenter2D = placed("center2D", (P, 2), alloc)
         sh_factored = bool(sh_factored and use_shs)
         if sh_factored:
             dL_dshs = None
         else:
-            dL_dshs = alloc((P, M, 3), **opts) if use_shs else torch.zeros((P, M, 3), **opts)
-        dL_dfeature = alloc((P, Cn), **opts)
-        dL_dopacity = alloc((P, 1), **opts)
+            dL_dshs = placed("color", (P, M, 3), alloc) if use_shs else torch.zeros((P, M, 3), **opts)
+        dL_dfeature = alloc((P, Cn), **opts) if use_shs else placed("color", (P, Cn), alloc)
+        dL_dopacity = placed("opacity", (P, 1), alloc)
         if P == 0:
             return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
         flags = ((FLAG_RICH_INFO if rich_info else 0) | (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) |

@@ -78,6 +78,9 @@ def _camera_and_geometry_args(rs: TriangleRasterizationSettings, background_dept
 # dL_dshs; they append (dL_dRGB (P,3), campos (3,)) to the sink and return no gradient for `shs` (parallel.py rebuilds the
 # sum over all ranks' views from the exchanged factors).
 _sh_grad_sink = None
+# Set by parallel.GradBucket.capture(): while a bucket is installed, backward passes write dL_dvertex / dL_dopacity /
+# dL_dcenter2D (and the dense colour gradient when the bucket has a slot for it) straight into the bucket's views.
+_grad_bucket = None
 
 
 class _RasterizeTriangles(torch.autograd.Function):
@@ -123,10 +126,21 @@ class _RasterizeTriangles(torch.autograd.Function):
             g_feature.contiguous(), g_depth.contiguous(), g_normal.contiguous(), rs.rich_info, rs.debug)
         with _snapshot_on_error("rasterize_triangles_backward", native_args, rs.debug):
             sink = _sh_grad_sink if (ctx.needs_input_grad[2] and shs.numel() > 0) else None
+            bucket = _grad_bucket
+            place = bucket.named_views() if (bucket is not None and not bucket._filled) else None
             g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(
-                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None)
+                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place)
             if sink is not None:
                 sink.append(g_feat, rs.campos)
+            if bucket is not None:
+                if place is None:  # a further view under the same capture: added to what the first one wrote
+                    nv = bucket.named_views()
+                    use_shs = shs.numel() > 0
+                    for name, g in (("vertex", g_vertex), ("opacity", g_opacity), ("center2D", g_center2D),
+                                    ("color", (g_shs if use_shs else g_feat) if sink is None else None)):
+                        if name in nv and g is not None:
+                            nv[name].add_(g.view(nv[name].shape))
+                bucket._filled = True
         # The placeholder standing in for the unused one of shs/feature is a CPU `torch.Tensor([])`
         # (reference :183-184) that never requires grad; hand autograd None for it.
         if not ctx.needs_input_grad[2]:

@@ -8,10 +8,11 @@ over the views of a step; the densification statistics that the reference model 
 (src/diff_recon/models/VanillaTS_model.py:347-363) are reduced with the operator the model itself applies
 across iterations: radii / contrib_sum / contrib_max with MAX, visibility counts with SUM.
 
-Design for xGMI: the gradient tensors are flattened into ONE contiguous fp32 bucket per step (P*(9+2+1+3M)
-floats; 1 M triangles at M=16 -> 240 MB) so RCCL sees a single large message -- on the 8-GPU fully connected
-xGMI mesh large messages are what reach link bandwidth -- issued on a side stream so that it overlaps whatever
-the caller still has queued on the compute stream (e.g. the loss/backward of a second view).
+Design for xGMI: the gradient tensors live in ONE contiguous fp32 bucket per step (P*(9+2+1) floats, plus 3M for a dense
+SH exchange) that the backward kernels write directly (GradBucket.capture), so RCCL sees a single large message --
+on the 8-GPU fully connected xGMI mesh large messages are what reach link bandwidth -- reduced as reduce-scatter +
+all-gather on a side stream, so that it overlaps whatever the caller still has queued on the compute stream (the SH
+gradient expansion, the loss/backward of a second view).
 
 Works on any torch.distributed backend: "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU tensors (used by the
 world_size-2 tests that run without a GPU).
@@ -30,16 +31,35 @@ def shard_views(num_views: int, rank: int, world_size: int) -> List[int]:
 
 
 class GradBucket:
-    """Flattens a fixed list of gradient tensors into one contiguous buffer and all-reduces it."""
+    """One contiguous fp32 buffer for a fixed list of gradient tensors, summed over the ranks on a side stream.
 
-    def __init__(self, shapes: Sequence[torch.Size], device, dtype=torch.float32, group=None, mean: bool = False):
+    * `capture()`: while active, the backward pass of TriangleRasterizer (2D and 3D packages) writes dL_dvertex / dL_dopacity /
+      dL_dcenter2D (and a dense dL_dshs / dL_dfeature when the bucket has a slot for it) STRAIGHT into the bucket's views --
+      the kernels take the output pointers through the C ABI, so no pack copy exists.  A second backward under the same capture
+      (several views per rank) is added to the first.
+    * `reduce_async()` = reduce-scatter + all-gather of the flat buffer: on the fully connected xGMI mesh every
+      GPU sends each peer exactly the 1 / world slice that peer owns, over all seven links at once, and gets the reduced slices
+      back the same way; between the two halves a rank owns its reduced slice, which is where a sharded optimizer step would go.
+      `mode="all_reduce"` keeps the single collective.  Expected exchange times are tabulated in DESIGN.md section 6 (unmeasured:
+      no multi-GPU node was available to this project so far)."""
+
+    SLOTS = ("vertex", "opacity", "center2D", "color")  # names a capture can fill; `color` = dL_dshs or dL_dfeature
+
+    def __init__(self, shapes: Sequence[torch.Size], device, dtype=torch.float32, group=None, mean: bool = False,
+                 names: Optional[Sequence[str]] = None, mode: str = "rs_ag"):
         self.shapes = [torch.Size(s) for s in shapes]
         self.numels = [int(torch.Size(s).numel()) for s in self.shapes]
-        self.flat = torch.empty(sum(self.numels), device=device, dtype=dtype)
+        self.names = list(names) if names is not None else [None] * len(self.shapes)
         self.group = group
         self.mean = mean
+        self.mode = mode
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        total = sum(self.numels)
+        self.padded = -(-total // (4 * world)) * (4 * world)  # equal 16-byte-aligned slices for reduce-scatter
+        self.flat = torch.zeros(self.padded, device=device, dtype=dtype)
         self._stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self._work = None
+        self._filled = False
 
     def views(self) -> List[torch.Tensor]:
         out, off = [], 0
@@ -48,23 +68,45 @@ class GradBucket:
             off += n
         return out
 
+    def named_views(self) -> Dict[str, torch.Tensor]:
+        return {n: v for n, v in zip(self.names, self.views()) if n is not None}
+
     def pack(self, grads: Iterable[Optional[torch.Tensor]]):
         for dst, g in zip(self.views(), grads):
             if g is None:
                 dst.zero_()
-            else:
+            elif g.data_ptr() != dst.data_ptr():
                 dst.copy_(g)
 
-    def all_reduce_async(self):
-        """Starts the all-reduce; on GPUs it runs on a side stream ordered after the current stream."""
+    def capture(self):
+        """Context manager: rasterizer backward passes inside it write their gradients into this bucket (see class doc)."""
+        return _BucketCapture(self)
+
+    def reduce_async(self):
+        """Starts the cross-rank sum of the bucket; on GPUs it runs on a side stream ordered after the current stream."""
+        self._filled = False
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return
+        world = dist.get_world_size(self.group)
+
+        def issue():
+            # gloo (the CPU / functional-test backend) has no reduce_scatter_tensor: it takes the single all-reduce
+            if self.mode == "rs_ag" and dist.get_backend(self.group) != "gloo":
+                rank = dist.get_rank(self.group)
+                n = self.padded // world
+                mine = self.flat[rank * n:(rank + 1) * n]
+                dist.reduce_scatter_tensor(mine, self.flat, op=dist.ReduceOp.SUM, group=self.group)
+                return dist.all_gather_into_tensor(self.flat, mine, group=self.group, async_op=True)
+            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self._stream):
-                self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self._work = issue()
         else:
-            self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._work = issue()
+
+    all_reduce_async = reduce_async  # round-1 name
 
     def wait(self) -> List[torch.Tensor]:
         if self._work is not None:
@@ -78,8 +120,25 @@ class GradBucket:
 
     def all_reduce(self, grads: Iterable[Optional[torch.Tensor]]) -> List[torch.Tensor]:
         self.pack(grads)
-        self.all_reduce_async()
+        self.reduce_async()
         return self.wait()
+
+
+class _BucketCapture:
+    def __init__(self, bucket: GradBucket):
+        self.bucket = bucket
+
+    def __enter__(self):
+        import diff_triangle_rasterization_2D as pkg
+        self._prev = pkg._grad_bucket
+        pkg._grad_bucket = self.bucket
+        self.bucket._filled = False
+        return self.bucket
+
+    def __exit__(self, *exc):
+        import diff_triangle_rasterization_2D as pkg
+        pkg._grad_bucket = self._prev
+        return False
 
 
 def all_reduce_triangle_grads(params: Sequence[torch.Tensor], group=None, mean: bool = False,
@@ -141,13 +200,15 @@ class factored_sh_grads:
     """Context manager: backward passes of TriangleRasterizer (2D and 3D packages) run inside it hand their SH gradients
     to the returned sink in factored form and leave `shs.grad` untouched; `exchange_factored_sh_grads` finishes the job."""
 
-    def __init__(self, sink: Optional[ShGradSink] = None):
+    def __init__(self, sink: Optional[ShGradSink] = None, enabled: bool = True):
         self.sink = sink if sink is not None else ShGradSink()
+        self.enabled = enabled
 
     def __enter__(self) -> ShGradSink:
         import diff_triangle_rasterization_2D as pkg
         self._prev = pkg._sh_grad_sink
-        pkg._sh_grad_sink = self.sink
+        if self.enabled:
+            pkg._sh_grad_sink = self.sink
         return self.sink
 
     def __exit__(self, *exc):
