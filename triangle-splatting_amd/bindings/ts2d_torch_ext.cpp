@@ -1,0 +1,140 @@
+// ts2d_torch_ext.cpp -- the reference-side binding of libts2d.so: a torch C++ extension with EXACTLY the two entry points
+// the reference exports through pybind (R2D/ext.cpp:4-9) and their signatures (R2D/src/extension_interface.h:7-62):
+//     rasterize_triangles(...)           replaces rasterizeTrianglesForward   (R2D/src/extension_interface.cu:19-152)
+//     rasterize_triangles_backward(...)  replaces rasterizeTrianglesBackward  (R2D/src/extension_interface.cu:154-260)
+// A maintainer who keeps the reference's build (setup.py + ext.cpp) swaps extension_interface.cu / rasterizer.cu / forward.cu /
+// backward.cu for this one file and links -lts2d; `diff_triangle_rasterization_2D/__init__.py` of the reference then works
+// unchanged on top of it.  Argument checks, error texts, output shapes / dtypes and ownership mirror the reference; device
+// memory comes from torch's allocator, kernels are enqueued on torch's current stream.
+// Built by bindings/build_torch_ext.py (hipcc, in-tree); exercised by tests/test_binding_gpu.py.
+#include <torch/extension.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h> // ROCm builds of torch: guard / stream types behind the "cuda" device type
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <tuple>
+
+#include "../../include/ts2d.h"
+
+namespace
+{
+struct Shape
+{
+    int P, H, W, C, M;
+    bool use_shs;
+};
+
+Shape derive(const torch::Tensor &vertex, const torch::Tensor &shs, const torch::Tensor &feature, int H, int W)
+{
+    Shape s;
+    s.P = (int)vertex.size(0);
+    s.H = H;
+    s.W = W;
+    s.use_shs = feature.dim() <= 1 || (feature.size(0) == 0 && shs.size(0) > 0); // extension_interface.cu:44
+    s.C = s.use_shs ? 3 : (int)feature.size(1);
+    s.M = (shs.dim() >= 2 && shs.size(0) != 0) ? (int)shs.size(1) : 0;
+    return s;
+}
+
+const float *fptr(const torch::Tensor &t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
+float *fptr_mut(torch::Tensor &t) { return t.numel() ? t.data_ptr<float>() : nullptr; }
+
+void check(int rc, const char *what)
+{
+    if (rc != TS2D_OK) AT_ERROR(what, ": ", ts2d_last_error());
+}
+} // namespace
+
+std::tuple<int, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+rasterizeTrianglesForward(const int image_width, const int image_height, const float tan_fovx, const float tan_fovy,
+                          const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix, const torch::Tensor &campos, const int sh_degree,
+                          const float gamma, const float scale_modifier, const float background_depth, const torch::Tensor &background,
+                          const torch::Tensor &vertex, const torch::Tensor &shs, const torch::Tensor &feature, const torch::Tensor &opacity,
+                          const bool back_culling, const bool rich_info, const bool debug)
+{
+    // extension_interface.cu:53-81
+    if (vertex.ndimension() != 3 || vertex.size(1) != 3 || vertex.size(2) != 3) AT_ERROR("vertex must have dimensions (num_points, 3, 3)");
+    const Shape s = derive(vertex, shs, feature, image_height, image_width);
+    if (!s.use_shs && feature.ndimension() != 2) AT_ERROR("feature must have dimensions (num_points, num_channels)");
+    if (s.use_shs && shs.ndimension() != 3) AT_ERROR("shs must have dimensions (num_points, (1 + sh_degree) ** 2, 3)");
+    if (s.C > TS2D_MAX_CHANNELS) AT_ERROR("feature's num_channels can't be larger than MAX_CHANNELS");
+    if (s.C != background.size(0)) AT_ERROR("background must have the same number of channels as feature");
+    if (gamma < 0.0f) AT_ERROR("gamma must be larger than 0");
+    for (const torch::Tensor *t : {&viewmatrix, &projmatrix, &campos, &background, &vertex, &shs, &feature, &opacity})
+        if (!t->is_contiguous()) AT_ERROR("input tensors must be contiguous");
+
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA device_guard(vertex.device());
+    void *stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    auto f32 = vertex.options().dtype(torch::kFloat32), i32 = vertex.options().dtype(torch::kInt32), u8 = vertex.options().dtype(torch::kByte);
+    const int P = s.P, H = s.H, W = s.W;
+    // the library writes every element when P > 0 (culled triangles get explicit zeros): no zero-fill pass
+    auto alloc = [&](std::vector<int64_t> shape, const torch::TensorOptions &o) { return P == 0 ? torch::zeros(shape, o) : torch::empty(shape, o); };
+    torch::Tensor out_feature = alloc({s.C, H, W}, f32), radii = alloc({P}, i32);
+    torch::Tensor depth = rich_info ? alloc({H, W}, f32) : torch::empty({0}, f32);
+    torch::Tensor normal = rich_info ? alloc({3, H, W}, f32) : torch::empty({0}, f32);
+    torch::Tensor contrib_sum = rich_info ? alloc({P}, f32) : torch::empty({0}, f32);
+    torch::Tensor contrib_max = rich_info ? alloc({P}, f32) : torch::empty({0}, f32);
+    torch::Tensor geometryBuffer = torch::empty({0}, u8), binningBuffer = torch::empty({0}, u8), imageBuffer = torch::empty({0}, u8);
+    int64_t num_rendered = 0;
+    if (P != 0) // extension_interface.cu:130
+    {
+        ts2d_camera cam{W, H, tan_fovx, tan_fovy, fptr(viewmatrix), fptr(projmatrix), fptr(campos)};
+        ts2d_geometry geom{P, sh_degree, s.M, s.C, gamma, scale_modifier, background_depth, fptr(background), fptr(vertex),
+                           s.use_shs ? fptr(shs) : nullptr, s.use_shs ? nullptr : fptr(feature), fptr(opacity)};
+        const uint32_t flags = (back_culling ? TS2D_FLAG_BACK_CULLING : 0u) | (rich_info ? TS2D_FLAG_RICH_INFO : 0u) |
+                               (debug ? TS2D_FLAG_DEBUG : 0u) | (s.use_shs ? TS2D_FLAG_USE_SHS : 0u);
+        geometryBuffer = torch::empty({(int64_t)ts2d_geometry_state_bytes(P)}, u8);
+        imageBuffer = torch::empty({(int64_t)ts2d_image_state_bytes(W, H)}, u8);
+        ts2d_state st{geometryBuffer.data_ptr(), (size_t)geometryBuffer.numel(), nullptr, 0, imageBuffer.data_ptr(), (size_t)imageBuffer.numel()};
+        check(ts2d_forward_bin(&cam, &geom, flags, radii.data_ptr<int>(), &st, &num_rendered, stream), "rasterize_triangles"); // rasterizer.cu:116-193
+        binningBuffer = torch::empty({(int64_t)ts2d_binning_state_bytes(num_rendered, W, H)}, u8);                           // rasterizer.cu:195
+        st.binning = binningBuffer.data_ptr();
+        st.binning_bytes = (size_t)binningBuffer.numel();
+        ts2d_forward_out out{fptr_mut(out_feature), fptr_mut(depth), fptr_mut(normal), fptr_mut(contrib_sum), fptr_mut(contrib_max)};
+        check(ts2d_forward_render(&cam, &geom, flags, num_rendered, &st, &out, stream), "rasterize_triangles"); // rasterizer.cu:199-266
+    }
+    return std::make_tuple((int)num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max, geometryBuffer, binningBuffer, imageBuffer);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor>
+rasterizeTrianglesBackward(const float tan_fovx, const float tan_fovy, const torch::Tensor &viewmatrix, const torch::Tensor &projmatrix,
+                           const torch::Tensor &campos, const int sh_degree, const float gamma, const float scale_modifier,
+                           const float background_depth, const torch::Tensor &background, const torch::Tensor &vertex, const torch::Tensor &shs,
+                           const torch::Tensor &feature, const torch::Tensor &opacity, const int num_rendered, const torch::Tensor &radii,
+                           const torch::Tensor &geometryBuffer, const torch::Tensor &binningBuffer, const torch::Tensor &imageBuffer,
+                           const torch::Tensor &dL_dout_feature, const torch::Tensor &dL_dout_depth, const torch::Tensor &dL_dout_normal,
+                           const bool rich_info, const bool debug)
+{
+    const Shape s = derive(vertex, shs, feature, (int)dL_dout_feature.size(1), (int)dL_dout_feature.size(2)); // extension_interface.cu:182-183
+    for (const torch::Tensor *t : {&viewmatrix, &projmatrix, &campos, &background, &vertex, &shs, &feature, &opacity, &radii, &geometryBuffer,
+                                   &binningBuffer, &imageBuffer, &dL_dout_feature, &dL_dout_depth, &dL_dout_normal})
+        if (!t->is_contiguous()) AT_ERROR("input tensors must be contiguous"); // extension_interface.cu:193-199
+    c10::hip::OptionalHIPGuardMasqueradingAsCUDA device_guard(vertex.device());
+    void *stream = c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream();
+    auto opts = vertex.options();
+    const int P = s.P;
+    auto alloc = [&](std::vector<int64_t> shape) { return P == 0 ? torch::zeros(shape, opts) : torch::empty(shape, opts); };
+    torch::Tensor dL_dvertex = alloc({P, 3, 3}), dL_dcenter2D = alloc({P, 2}), dL_dopacity = alloc({P, 1});
+    torch::Tensor dL_dshs = s.use_shs ? alloc({P, s.M, 3}) : torch::zeros({P, s.M, 3}, opts);
+    torch::Tensor dL_dfeature = alloc({P, s.C});
+    if (P != 0) // extension_interface.cu:242
+    {
+        ts2d_camera cam{s.W, s.H, tan_fovx, tan_fovy, fptr(viewmatrix), fptr(projmatrix), fptr(campos)};
+        ts2d_geometry geom{P, sh_degree, s.M, s.C, gamma, scale_modifier, background_depth, fptr(background), fptr(vertex),
+                           s.use_shs ? fptr(shs) : nullptr, s.use_shs ? nullptr : fptr(feature), fptr(opacity)};
+        const uint32_t flags = (rich_info ? TS2D_FLAG_RICH_INFO : 0u) | (debug ? TS2D_FLAG_DEBUG : 0u) | (s.use_shs ? TS2D_FLAG_USE_SHS : 0u);
+        ts2d_state st{geometryBuffer.data_ptr(), (size_t)geometryBuffer.numel(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
+                      (size_t)binningBuffer.numel(), imageBuffer.data_ptr(), (size_t)imageBuffer.numel()};
+        ts2d_loss_grads loss{fptr(dL_dout_feature), rich_info ? fptr(dL_dout_depth) : nullptr, rich_info ? fptr(dL_dout_normal) : nullptr};
+        torch::Tensor scratch = torch::empty({(int64_t)ts2d_backward_scratch_bytes(P)}, opts.dtype(torch::kByte));
+        ts2d_backward_out bo{fptr_mut(dL_dvertex), fptr_mut(dL_dcenter2D), fptr_mut(dL_dshs), fptr_mut(dL_dfeature), fptr_mut(dL_dopacity)};
+        check(ts2d_backward(&cam, &geom, flags, num_rendered, radii.data_ptr<int>(), &st, &loss, scratch.data_ptr(), (size_t)scratch.numel(), &bo,
+                            stream),
+              "rasterize_triangles_backward"); // rasterizer.cu:269-358
+    }
+    return std::make_tuple(dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity);
+}
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) // R2D/ext.cpp:4-9
+{
+    m.def("rasterize_triangles", &rasterizeTrianglesForward);
+    m.def("rasterize_triangles_backward", &rasterizeTrianglesBackward);
+}
