@@ -13,6 +13,11 @@ Fixtures are data only (inputs + expected outputs):
   gamma_rescale.npz : gamma -> the triangle rescale ratio of src/diff_recon/models/VanillaTS_model.py:615-617
                 (restated formula 1/sqrt(2^beta * beta * Gamma(beta)), beta = 1/gamma, evaluated with scipy like the
                  reference; the model class itself is not importable here).
+  model_update.npz : one model state (300 triangles: the four per-triangle parameters, their Adam moments after a real optimizer
+                step, the six densification statistics) and the state after each of the reference's own update methods
+                _prune_points, _densification (+ _grow_points), _opacity_pruning, _opacity_clipping, _scale_pruning,
+                _scale_clipping, _opacity_reset, _contribution_pruning (src/diff_recon/models/VanillaTS_model.py:214-537),
+                executed by importing the reference's VanillaTSModel class (see load_reference_model_class).
   photometric.npz : image pairs, (w_L1, w_ssim) -> L1, ssimLoss, img_loss and d img_loss / d image (torch autograd) of
                 src/diff_recon/trainers/trainer_utils.py:9-103,323-324 combined as VanillaTS_trainer.py:80-81,111.
                 trainer_utils.py imports two third-party packages at module level that this image lacks and that the
@@ -134,5 +139,154 @@ def main():
     print("wrote", sorted(os.listdir(HERE)))
 
 
+
+
+
+# ---- model_update.npz: the reference's own VanillaTSModel update methods, executed on CPU tensors ------------------------------------
+def load_reference_model_class():
+    """Imports src/diff_recon/models/VanillaTS_model.py without running the package __init__ (which pulls in trainers, datasets and
+    tensorboard): empty package shells with the real paths, a no-op Logger, and empty placeholders for the mesh / point-cloud IO
+    packages this image lacks (plyfile, trimesh, ...: imported at module level by point_cloud.py / raw_triangle.py; nothing used here
+    touches them).  The drop-in rasterizer / simple_knn packages stand in for the CUDA
+    extensions the model module imports -- none of their functions is called by the methods exercised below."""
+    import importlib
+    root = "/root/reference/src/diff_recon"
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(HERE)), "triangle-splatting_amd"))
+
+    def pkg(name, path):
+        m = types.ModuleType(name)
+        m.__path__ = [path]
+        m.__package__ = name
+        sys.modules[name] = m
+
+    pkg("diff_recon", root)
+    for sub in ("models", "utils", "renderer"):
+        pkg("diff_recon." + sub, os.path.join(root, sub))
+
+    class Logger:
+        def info(self, *a, **k):
+            pass
+        warning = info
+
+    lg = types.ModuleType("diff_recon.utils.logger")
+    lg.Logger, lg.stdout_logger = Logger, Logger()
+    sys.modules["diff_recon.utils.logger"] = lg
+    ply = types.ModuleType("plyfile")
+    ply.PlyData = ply.PlyElement = None
+    sys.modules["plyfile"] = ply
+    for third_party in ("trimesh", "pygltflib", "open3d"):  # mesh / GLB IO of raw_triangle.py and point_cloud.py: imported, never called here
+        if third_party not in sys.modules:
+            try:
+                importlib.import_module(third_party)
+            except ModuleNotFoundError:
+                sys.modules[third_party] = types.ModuleType(third_party)
+    while True:
+        try:
+            return importlib.import_module("diff_recon.models.VanillaTS_model").VanillaTSModel, Logger
+        except ModuleNotFoundError as e:  # any further IO-only third-party module this image lacks
+            if e.name is None or e.name.startswith("diff_recon"):
+                raise
+            sys.modules[e.name] = types.ModuleType(e.name)
+
+
+def model_update(rng):
+    from types import SimpleNamespace as NS
+    from copy import deepcopy
+    Model, Logger = load_reference_model_class()
+    P, M = 300, 4
+
+    def fresh():
+        g = torch.Generator().manual_seed(1234)
+        m = Model.__new__(Model)
+        torch.nn.Module.__init__(m) if isinstance(m, torch.nn.Module) else None
+        m.device = torch.device("cpu")
+        m.logger = Logger()
+        m.scene_bbox = None
+        m.ste_threshold = None
+        centre = torch.rand((P, 1, 3), generator=g) * 10
+        size = torch.rand((P, 1, 1), generator=g) ** 3 * 1.5 + 0.02
+        m._vertex = torch.nn.Parameter(centre + torch.randn((P, 3, 3), generator=g) * size)
+        m._opacity = torch.nn.Parameter(torch.randn((P, 1), generator=g) * 3)
+        m._f_dc = torch.nn.Parameter(torch.rand((P, 1, 3), generator=g))
+        m._f_rest = torch.nn.Parameter(torch.rand((P, M - 1, 3), generator=g))
+        groups = [{"params": [getattr(m, "_" + n)], "lr": 0.01, "name": n} for n in ("vertex", "opacity", "f_dc", "f_rest")]
+        m.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        for n in ("vertex", "opacity", "f_dc", "f_rest"):  # one real Adam step populates exp_avg / exp_avg_sq
+            getattr(m, "_" + n).grad = torch.randn(getattr(m, "_" + n).shape, generator=g)
+        m.optimizer.step()
+        m.optimizer.zero_grad(set_to_none=True)
+        m.gradient_accum = torch.rand((P,), generator=g) * 5
+        m.gradient_denom = torch.randint(0, 12, (P,), generator=g).float()
+        m.max_radii2D = torch.rand((P,), generator=g) * 60
+        m.contrib_sum = torch.rand((P,), generator=g) * 9
+        m.contrib_max = torch.rand((P,), generator=g)
+        m.contrib_denom = torch.randint(0, 9, (P,), generator=g).float()
+        it = NS(start_iter=0, end_iter=1000, hold_iter=1000, interval_iter=100)
+        m.config = NS(model_update=NS(
+            densification=NS(**vars(it), min_view_count=4, split_num=2, split_scale_threshold=0.6),
+            opacity_pruning=NS(**vars(it)), opacity_clipping=NS(**vars(it)),
+            scale_pruning=NS(**vars(it), radii_threshold=50.0, scale_threshold=1.2),
+            scale_clipping=NS(**vars(it)), opacity_reset=NS(**vars(it), reset_value=0.3),
+            contribution_pruning=NS(**vars(it), min_view_count=3, target_point_num=150, prune_ratio=0.5, max_prune_ratio=0.6, contrib_max_ratio=0.4,
+                                    sparsity_retain_ratio=0.0, downsample_iteration=[], downsample_point_num=[])))
+        m.grad_threshold_scheduler = lambda step: 0.21
+        m.opacity_pruning_scheduler = lambda step: 0.25
+        m.opacity_clipping_scheduler = lambda step: 0.9
+        m.scale_max_scheduler = lambda step: 0.8
+        return m
+
+    def snapshot(m, prefix, out):
+        for n in ("vertex", "opacity", "f_dc", "f_rest"):
+            p = getattr(m, "_" + n)
+            out[f"{prefix}/{n}"] = p.detach().numpy().copy()
+            st = m.optimizer.state[p]
+            out[f"{prefix}/{n}.exp_avg"] = st["exp_avg"].numpy().copy()
+            out[f"{prefix}/{n}.exp_avg_sq"] = st["exp_avg_sq"].numpy().copy()
+        for n in ("gradient_accum", "gradient_denom", "max_radii2D", "contrib_sum", "contrib_max", "contrib_denom"):
+            out[f"{prefix}/{n}"] = getattr(m, n).numpy().copy()
+
+    out = {}
+    snapshot(fresh(), "input", out)
+    prune_mask = torch.rand((P,), generator=torch.Generator().manual_seed(5)) < 0.3
+    out["prune_mask"] = prune_mask.numpy()
+    cases = {
+        "prune_points": lambda m: m._prune_points(prune_mask),
+        "densification": lambda m: m._densification(100),
+        "opacity_pruning": lambda m: m._opacity_pruning(100),
+        "opacity_clipping": lambda m: m._opacity_clipping(100),
+        "scale_pruning": lambda m: m._scale_pruning(100),
+        "scale_clipping": lambda m: m._scale_clipping(100),
+        "opacity_reset": lambda m: m._opacity_reset(100),
+        "contribution_pruning": lambda m: m._contribution_pruning(100),
+    }
+    for name, fn in cases.items():
+        m = fresh()
+        with torch.no_grad():
+            fn(m)
+        snapshot(m, name, out)
+    # _training_statistic (:347-363), three consecutive iterations of render outputs
+    m = fresh()
+    m.config.model_update.statistic = NS(start_iter=0, end_iter=1000)
+    g = torch.Generator().manual_seed(99)
+    for it in range(3):
+        radii = torch.randint(-2, 40, (P,), generator=g).clamp(min=0).int()
+        c2d = torch.zeros((P, 2), requires_grad=True)
+        c2d.grad = torch.randn((P, 2), generator=g)
+        pkg = {"center2D": c2d, "visible_mask": radii > 0, "radii": radii, "contrib_sum": torch.rand((P,), generator=g) * 3,
+               "contrib_max": torch.rand((P,), generator=g)}
+        for k in ("radii", "contrib_sum", "contrib_max"):
+            out[f"statistic_in{it}/{k}"] = pkg[k].numpy().copy()
+        out[f"statistic_in{it}/center2D_grad"] = c2d.grad.numpy().copy()
+        with torch.no_grad():
+            m._training_statistic(it + 1, pkg)
+    snapshot(m, "training_statistic", out)
+    np.savez_compressed(os.path.join(HERE, "model_update.npz"), **out)
+    print("model_update.npz:", {k: out[f"{k}/vertex"].shape[0] for k in cases})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "model_update":
+        model_update(np.random.default_rng(1))  # only this fixture (the others are unchanged since round 1)
+    else:
+        main()
+        model_update(np.random.default_rng(1))

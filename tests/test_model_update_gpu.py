@@ -1,52 +1,113 @@
-"""GPU test of the fused densification statistics (csrc/model_update.hip through diff_recon_hip.DensificationStats) against
-the reference's six boolean-mask statements (src/diff_recon/models/VanillaTS_model.py:355-363) restated with eager torch
-indexing -- the same torch operations, applied to the same tensors."""
+"""GPU tests of the model-update operators (csrc/model_update.hip, include/ts_model.h, diff_recon_hip/model_update.py) against
+tests/golden/model_update.npz: one model state and the state after each of the REFERENCE's own update methods, produced by
+executing the reference's VanillaTSModel class (tests/golden/make_golden.py::model_update; src/diff_recon/models/VanillaTS_model.py:
+214-537).  Row surgery (pruning, growth, Adam moments) must match bit for bit; the arithmetic updates (scale clipping, opacity
+reset, split geometry, gradient norms) to 1e-6."""
+import os
+from types import SimpleNamespace as NS
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "model_update.npz")
+PARAMS = ("vertex", "opacity", "f_dc", "f_rest")
+STATS = ("gradient_accum", "gradient_denom", "max_radii2D", "contrib_sum", "contrib_max", "contrib_denom")
 
 
-def _eager_update(state, radii, c2d_grad, csum, cmax):
+def _model(z, prefix="input"):
+    """A model-like object with the reference's attribute names, loaded from the fixture onto the GPU."""
     import torch
-    vis = radii > 0
-    state["gradient_accum"][vis] += torch.norm(c2d_grad[vis, :2], dim=-1)
-    state["gradient_denom"][vis] += 1
-    state["contrib_sum"][vis] = torch.max(state["contrib_sum"][vis], csum[vis])
-    state["contrib_max"][vis] = torch.max(state["contrib_max"][vis], cmax[vis])
-    state["contrib_denom"][vis] += 1
-    state["max_radii2D"][vis] = torch.max(state["max_radii2D"][vis], radii[vis])
+    t = lambda k: torch.from_numpy(z[f"{prefix}/{k}"]).cuda()
+    m = NS()
+    groups = []
+    for n in PARAMS:
+        setattr(m, "_" + n, torch.nn.Parameter(t(n)))
+        groups.append({"params": [getattr(m, "_" + n)], "lr": 0.01, "name": n})
+    m.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+    for n in PARAMS:
+        m.optimizer.state[getattr(m, "_" + n)] = {"step": torch.tensor(1.0), "exp_avg": t(n + ".exp_avg"), "exp_avg_sq": t(n + ".exp_avg_sq")}
+    for n in STATS:
+        setattr(m, n, t(n))
+    it = NS(start_iter=0, end_iter=1000, hold_iter=1000, interval_iter=100)
+    m.config = NS(model_update=NS(
+        densification=NS(**vars(it), min_view_count=4, split_num=2, split_scale_threshold=0.6),
+        opacity_pruning=NS(**vars(it)), opacity_clipping=NS(**vars(it)),
+        scale_pruning=NS(**vars(it), radii_threshold=50.0, scale_threshold=1.2),
+        scale_clipping=NS(**vars(it)), opacity_reset=NS(**vars(it), reset_value=0.3),
+        contribution_pruning=NS(**vars(it), min_view_count=3, target_point_num=150, prune_ratio=0.5, max_prune_ratio=0.6, contrib_max_ratio=0.4,
+                                sparsity_retain_ratio=0.0, downsample_iteration=[], downsample_point_num=[])))
+    m.grad_threshold_scheduler = lambda step: 0.21
+    m.opacity_pruning_scheduler = lambda step: 0.25
+    m.opacity_clipping_scheduler = lambda step: 0.9
+    m.scale_max_scheduler = lambda step: 0.8
+    m.scene_bbox = None
+    m.ste_threshold = None
+    return m
 
 
-def test_statistics_match_reference_statements():
+def _compare(m, z, case, exact):
+    for n in PARAMS:
+        p = getattr(m, "_" + n)
+        assert m.optimizer.param_groups[PARAMS.index(n)]["params"][0] is p and p.requires_grad
+        st = m.optimizer.state[p]
+        for got, key in ((p.detach(), n), (st["exp_avg"], n + ".exp_avg"), (st["exp_avg_sq"], n + ".exp_avg_sq")):
+            want = z[f"{case}/{key}"]
+            assert tuple(got.shape) == want.shape, (case, key, tuple(got.shape), want.shape)
+            if exact:
+                assert np.array_equal(got.cpu().numpy(), want), (case, key)
+            else:
+                np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-6, atol=2e-7, err_msg=f"{case}/{key}")
+    for n in STATS:
+        assert np.array_equal(getattr(m, n).cpu().numpy(), z[f"{case}/{n}"]), (case, n)
+
+
+@pytest.mark.parametrize("case,exact", [("prune_points", True), ("densification", False), ("opacity_pruning", True), ("opacity_clipping", True),
+                                        ("scale_pruning", True), ("scale_clipping", False), ("opacity_reset", False),
+                                        ("contribution_pruning", True)])
+def test_update_rules_match_the_reference_methods(case, exact):
+    import torch
+    import diff_recon_hip as D
+    z = np.load(GOLD)
+    m = _model(z)
+    if case == "prune_points":
+        D.prune_points(m, torch.from_numpy(z["prune_mask"]).cuda())
+    else:
+        assert getattr(D, case)(m, 100) is not None
+        assert getattr(D, case)(m, 101) is None  # off-interval iterations leave the model alone
+    _compare(m, z, case, exact)
+
+
+def test_training_statistic_matches_the_reference_method():
+    """VanillaTSModel._training_statistic (:347-363) over three iterations, through DensificationStats."""
     import torch
     from diff_recon_hip import DensificationStats
+    z = np.load(GOLD)
+    P = z["input/gradient_accum"].shape[0]
+    stats = DensificationStats(P, "cuda")
+    for n in STATS:
+        getattr(stats, n).copy_(torch.from_numpy(z[f"input/{n}"]))
+    for it in range(3):
+        c2d = torch.zeros((P, 2), device="cuda", requires_grad=True)
+        c2d.grad = torch.from_numpy(z[f"statistic_in{it}/center2D_grad"]).cuda()
+        stats.update({"radii": torch.from_numpy(z[f"statistic_in{it}/radii"]).cuda(), "center2D": c2d,
+                      "contrib_sum": torch.from_numpy(z[f"statistic_in{it}/contrib_sum"]).cuda(),
+                      "contrib_max": torch.from_numpy(z[f"statistic_in{it}/contrib_max"]).cuda()})
+    for n in STATS:
+        np.testing.assert_allclose(getattr(stats, n).cpu().numpy(), z[f"training_statistic/{n}"], rtol=1e-6, atol=0, err_msg=n)
 
+
+def test_statistics_without_rich_info_prune_grow_and_errors():
+    import torch
+    from diff_recon_hip import DensificationStats
     P = 100_003
     g = torch.Generator(device="cuda").manual_seed(5)
     stats = DensificationStats(P, "cuda")
-    ref = {k: torch.zeros(P, device="cuda") for k in ("gradient_accum", "gradient_denom", "max_radii2D", "contrib_sum", "contrib_max",
-                                                     "contrib_denom")}
-    for it in range(4):
-        radii = torch.randint(-1, 40, (P,), device="cuda", generator=g, dtype=torch.int32).clamp(min=0)
-        c2d = torch.zeros((P, 2), device="cuda", requires_grad=True)
-        c2d.grad = torch.randn((P, 2), device="cuda", generator=g)
-        csum = torch.rand(P, device="cuda", generator=g) * 3
-        cmax = torch.rand(P, device="cuda", generator=g)
-        stats.update({"radii": radii, "center2D": c2d, "contrib_sum": csum, "contrib_max": cmax})
-        _eager_update(ref, radii, c2d.grad, csum, cmax)
-    for k, v in ref.items():
-        assert torch.allclose(getattr(stats, k), v, rtol=1e-6, atol=0), k
-    assert (stats.gradient_denom == stats.contrib_denom).all() and stats.gradient_denom.max() <= 4
-
-    # without rich_info only the gradient / radius statistics move
     before = stats.contrib_sum.clone()
     c2d = torch.zeros((P, 2), device="cuda", requires_grad=True)
     c2d.grad = torch.ones((P, 2), device="cuda")
-    stats.update({"radii": torch.ones(P, device="cuda", dtype=torch.int32), "center2D": c2d})
+    stats.update({"radii": torch.ones(P, device="cuda", dtype=torch.int32), "center2D": c2d})  # no rich_info: contributions untouched
     assert torch.equal(stats.contrib_sum, before) and stats.gradient_denom.min() >= 1
-
-    # prune / grow keep the six arrays aligned (VanillaTS_model.py:228-235, 309-315)
     mask = torch.rand(P, device="cuda", generator=g) < 0.3
     kept = stats.gradient_accum[~mask].clone()
     stats.prune(mask)
@@ -54,13 +115,11 @@ def test_statistics_match_reference_statements():
     assert len(stats) == int((~mask).sum()) + 17 and torch.equal(stats.gradient_accum[:-17], kept)
     assert (stats.max_radii2D[-17:] == 0).all()
     with pytest.raises(RuntimeError):
-        stats.update({"radii": torch.ones(len(stats), device="cuda", dtype=torch.int32),
-                      "center2D": torch.zeros((len(stats), 2), device="cuda")})
+        stats.update({"radii": torch.ones(len(stats), device="cuda", dtype=torch.int32), "center2D": torch.zeros((len(stats), 2), device="cuda")})
 
 
 def test_multi_view_update_equals_sequential_updates():
     """num_views > 1 (the all-gathered inputs of image-parallel training) == applying the views one after another."""
-    import ctypes as C
     import torch
     from diff_recon_hip import DensificationStats
     from diff_recon_hip.model_update import _lib
@@ -80,5 +139,46 @@ def test_multi_view_update_equals_sequential_updates():
                                      b.contrib_sum.data_ptr(), b.contrib_max.data_ptr(), b.contrib_denom.data_ptr(),
                                      torch.cuda.current_stream().cuda_stream)
     assert rc == 0
-    for k in ("gradient_accum", "gradient_denom", "max_radii2D", "contrib_sum", "contrib_max", "contrib_denom"):
+    for k in STATS:
         assert torch.allclose(getattr(a, k), getattr(b, k), rtol=1e-6), k
+
+
+def test_large_growth_and_sparsity_retention_run_on_the_native_operators():
+    """A 200 k-triangle state through densification, pruning and contribution pruning WITH sparsity retention (needs the drop-in
+    simple_knn): sizes stay consistent, the optimizer keeps working on the rebuilt parameters."""
+    import torch
+    import diff_recon_hip as D
+    P = 200_000
+    g = torch.Generator(device="cuda").manual_seed(3)
+    z = {"input/vertex": None}
+    m = NS()
+    centre = torch.rand((P, 1, 3), device="cuda", generator=g) * 50
+    m._vertex = torch.nn.Parameter(centre + torch.randn((P, 3, 3), device="cuda", generator=g) * 0.2)
+    m._opacity = torch.nn.Parameter(torch.randn((P, 1), device="cuda", generator=g) * 2)
+    m._f_dc = torch.nn.Parameter(torch.rand((P, 1, 3), device="cuda", generator=g))
+    m._f_rest = torch.nn.Parameter(torch.rand((P, 15, 3), device="cuda", generator=g))
+    m.optimizer = torch.optim.Adam([{"params": [getattr(m, "_" + n)], "lr": 1e-3, "name": n} for n in PARAMS], lr=0.0, eps=1e-15)
+    for n in PARAMS:
+        getattr(m, "_" + n).grad = torch.randn_like(getattr(m, "_" + n))
+    m.optimizer.step()
+    for n in STATS:
+        setattr(m, n, torch.rand((P,), device="cuda", generator=g) * 8)
+    it = NS(start_iter=0, end_iter=1000, hold_iter=1000, interval_iter=100)
+    m.config = NS(model_update=NS(densification=NS(**vars(it), min_view_count=4, split_num=2, split_scale_threshold=0.4),
+                                  contribution_pruning=NS(**vars(it), min_view_count=3, target_point_num=100_000, prune_ratio=0.5, max_prune_ratio=0.6,
+                                                          contrib_max_ratio=0.4, sparsity_retain_ratio=0.3, downsample_iteration=[],
+                                                          downsample_point_num=[])))
+    m.grad_threshold_scheduler = lambda step: 0.9
+    m.scene_bbox, m.ste_threshold = None, None
+    grown, cloned, split = D.densification(m, 100)
+    n1 = m._vertex.shape[0]
+    assert grown > 0 and cloned > 0 and split > 0 and n1 == P + cloned + split  # clones add one, splits replace one by two
+    pruned = D.contribution_pruning(m, 200)
+    assert pruned > 0 and m._vertex.shape[0] == n1 - pruned
+    for n in PARAMS:
+        p = getattr(m, "_" + n)
+        assert p.shape[0] == m._vertex.shape[0] and m.optimizer.state[p]["exp_avg"].shape == p.shape
+        p.grad = torch.ones_like(p)
+    for n in STATS:
+        assert getattr(m, n).shape[0] == m._vertex.shape[0]
+    m.optimizer.step()  # the rebuilt parameters are live in the optimizer

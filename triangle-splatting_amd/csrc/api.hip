@@ -446,6 +446,78 @@ int tsm_training_statistic(int32_t P, int32_t num_views, const int32_t *radii, c
     return TS2D_OK;
 }
 
+size_t tsm_select_scratch_bytes(int32_t P) { return ts_model_select_scratch_bytes(P); }
+
+int tsm_select_rows(int32_t P, const uint8_t *mask, int32_t match, uint32_t *pos, void *scratch, size_t scratch_bytes, uint32_t *count,
+                    void *stream)
+{
+    if (P < 0 || !count) return fail(TS2D_ERR_INVALID, "P must be >= 0 and count non-null");
+    *count = 0;
+    if (P == 0) return TS2D_OK;
+    if (!mask || !pos) return fail(TS2D_ERR_INVALID, "null pointer");
+    if (!scratch || scratch_bytes < ts_model_select_scratch_bytes(P)) return fail(TS2D_ERR_CAPACITY, "select scratch too small");
+    TS_HIP(ts_model_select_rows(P, mask, match, pos, (uint32_t *)scratch, count, (hipStream_t)stream));
+    return TS2D_OK;
+}
+
+static int rows_ok(int64_t rows, int32_t row_bytes, const void *a, const void *b, const void *c)
+{
+    if (rows < 0 || row_bytes <= 0 || (row_bytes & 3)) return fail(TS2D_ERR_INVALID, "rows must be >= 0 and row_bytes a positive multiple of 4");
+    if (rows > 0 && (!a || !b || !c)) return fail(TS2D_ERR_INVALID, "null pointer");
+    return TS2D_OK;
+}
+int tsm_scatter_rows(int64_t rows, int32_t row_bytes, const uint32_t *pos, const void *src, void *dst, int64_t dst_row0, void *stream)
+{
+    if (int rc = rows_ok(rows, row_bytes, pos, src, dst)) return rc;
+    TS_HIP(ts_model_scatter_rows(rows, row_bytes / 4, pos, src, dst, dst_row0, (hipStream_t)stream));
+    return TS2D_OK;
+}
+int tsm_gather_rows(int64_t rows, int32_t row_bytes, const uint32_t *idx, const void *src, void *dst, int64_t dst_row0, void *stream)
+{
+    if (int rc = rows_ok(rows, row_bytes, idx, src, dst)) return rc;
+    TS_HIP(ts_model_gather_rows(rows, row_bytes / 4, idx, src, dst, dst_row0, (hipStream_t)stream));
+    return TS2D_OK;
+}
+int tsm_grow_classify(int32_t P, const float *vertex, float *gradient_accum, float *gradient_denom, float min_view_count, float grad_threshold,
+                      float split_scale_threshold, uint8_t *code, void *stream)
+{
+    if (P < 0) return fail(TS2D_ERR_INVALID, "P must be >= 0");
+    if (P > 0 && (!vertex || !gradient_accum || !gradient_denom || !code)) return fail(TS2D_ERR_INVALID, "null pointer");
+    TS_HIP(ts_model_grow_classify(P, vertex, gradient_accum, gradient_denom, min_view_count, grad_threshold, split_scale_threshold, code,
+                                  (hipStream_t)stream));
+    return TS2D_OK;
+}
+int tsm_split_vertex(int32_t n_split, const uint32_t *parents, const float *vertex, float *child1, float *child2, void *stream)
+{
+    if (n_split < 0) return fail(TS2D_ERR_INVALID, "n_split must be >= 0");
+    if (n_split > 0 && (!parents || !vertex || !child1 || !child2)) return fail(TS2D_ERR_INVALID, "null pointer");
+    TS_HIP(ts_model_split_vertex(n_split, parents, vertex, child1, child2, (hipStream_t)stream));
+    return TS2D_OK;
+}
+int tsm_update_mask(int32_t P, int32_t mode, const float *opacity, const float *vertex, const float *max_radii2D, float a, float b, uint8_t *mask,
+                    void *stream)
+{
+    if (P < 0 || mode < 0 || mode > 3) return fail(TS2D_ERR_INVALID, "bad P / mode");
+    if (P > 0 && (!mask || (mode <= 1 && !opacity) || (mode >= 2 && !vertex) || (mode == 2 && !max_radii2D)))
+        return fail(TS2D_ERR_INVALID, "null pointer");
+    TS_HIP(ts_model_update_mask(P, mode, opacity, vertex, max_radii2D, a, b, mask, (hipStream_t)stream));
+    return TS2D_OK;
+}
+int tsm_clip(int32_t P, int32_t mode, const uint8_t *mask, float value, float *param, float *exp_avg, float *exp_avg_sq, void *stream)
+{
+    if (P < 0 || mode < 0 || mode > 1) return fail(TS2D_ERR_INVALID, "bad P / mode");
+    if (P > 0 && (!mask || !param || ((exp_avg == nullptr) != (exp_avg_sq == nullptr)))) return fail(TS2D_ERR_INVALID, "null pointer");
+    TS_HIP(ts_model_clip(P, mode, mask, value, param, exp_avg, exp_avg_sq, (hipStream_t)stream));
+    return TS2D_OK;
+}
+int tsm_opacity_reset(int32_t P, float reset_value, float *opacity, float *exp_avg, float *exp_avg_sq, void *stream)
+{
+    if (P < 0) return fail(TS2D_ERR_INVALID, "P must be >= 0");
+    if (P > 0 && (!opacity || ((exp_avg == nullptr) != (exp_avg_sq == nullptr)))) return fail(TS2D_ERR_INVALID, "null pointer");
+    TS_HIP(ts_model_opacity_reset(P, reset_value, opacity, exp_avg, exp_avg_sq, (hipStream_t)stream));
+    return TS2D_OK;
+}
+
 int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t W, int32_t H, int32_t field, void *dst,
                           size_t dst_bytes, void *stream)
 {

@@ -241,3 +241,14 @@ hipError_t ts_knn_nearest_other(int P, int group, const float *points, uint32_t 
 hipError_t ts_model_training_statistic(int P, int V, const int32_t *radii, const float *c2d_grad, const float *csum, const float *cmax,
                                        float *g_accum, float *g_denom, float *max_radii, float *s_csum, float *s_cmax, float *c_denom,
                                        hipStream_t s);
+size_t ts_model_select_scratch_bytes(int P);
+hipError_t ts_model_select_rows(int P, const uint8_t *mask, int match, uint32_t *pos, uint32_t *scratch, uint32_t *count_host, hipStream_t s);
+hipError_t ts_model_scatter_rows(int64_t rows, int row_words, const uint32_t *pos, const void *src, void *dst, int64_t dst_row0, hipStream_t s);
+hipError_t ts_model_gather_rows(int64_t rows, int row_words, const uint32_t *idx, const void *src, void *dst, int64_t dst_row0, hipStream_t s);
+hipError_t ts_model_grow_classify(int P, const float *vertex, float *g_accum, float *g_denom, float min_view_count, float grad_threshold,
+                                  float split_scale_threshold, uint8_t *code, hipStream_t s);
+hipError_t ts_model_split_vertex(int n_split, const uint32_t *parents, const float *vertex, float *child1, float *child2, hipStream_t s);
+hipError_t ts_model_update_mask(int P, int mode, const float *opacity, const float *vertex, const float *max_radii, float a, float b, uint8_t *mask,
+                                hipStream_t s);
+hipError_t ts_model_clip(int P, int mode, const uint8_t *mask, float value, float *param, float *exp_avg, float *exp_avg_sq, hipStream_t s);
+hipError_t ts_model_opacity_reset(int P, float reset_value, float *opacity, float *exp_avg, float *exp_avg_sq, hipStream_t s);

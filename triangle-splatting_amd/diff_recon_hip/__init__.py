@@ -4,14 +4,17 @@
                           (reference: src/diff_recon/trainers/trainer_utils.py:9-103, 323-324, 349;
                            combined as in src/diff_recon/trainers/VanillaTS_trainer.py:80-81,111)
     triangle_renderer.py  TriangleRenderer (reference: src/diff_recon/renderer/triangle_renderer.py:15-95)
-    model_update.py       DensificationStats: the per-iteration `_training_statistic` as one fused kernel
-                          (reference: src/diff_recon/models/VanillaTS_model.py:194-201, 347-363, 228-235, 309-315)
+    model_update.py       DensificationStats (the per-iteration `_training_statistic` as one fused kernel) and the periodic rules
+                          prune_points / densification / opacity_pruning / opacity_clipping / scale_pruning / scale_clipping /
+                          opacity_reset / contribution_pruning with their Adam-state surgery on native row operators
+                          (reference: src/diff_recon/models/VanillaTS_model.py:194-201, 214-345, 347-537)
     model_forward.py      render_view = the argument construction of VanillaTSModel.forward
                           (reference: src/diff_recon/models/VanillaTS_model.py:585-694)
 
-Native code: libts2d.so (include/ts_loss.h, include/ts2d.h).  No CPU / eager fallback anywhere.
+Native code: libts2d.so (include/ts_loss.h, include/ts_model.h, include/ts2d.h).  No CPU / eager fallback anywhere.
 """
 from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss  # noqa: F401
 from .triangle_renderer import TriangleRenderer  # noqa: F401
 from .model_forward import gamma_rescale_ratio, rescale_triangles, ste_opacity, render_view  # noqa: F401
-from .model_update import DensificationStats  # noqa: F401
+from .model_update import (DensificationStats, prune_points, densification, opacity_pruning, opacity_clipping, scale_pruning,  # noqa: F401
+                           scale_clipping, opacity_reset, contribution_pruning)
