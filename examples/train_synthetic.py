@@ -1,16 +1,25 @@
-"""End-to-end training loop on a synthetic target, using only this repository's drop-in pieces the way the reference's
-trainer uses its own (src/diff_recon/trainers/VanillaTS_trainer.py:60-130, src/diff_recon/models/VanillaTS_model.py:585-694):
+"""End-to-end training loop on a synthetic multi-view target, using only this repository's drop-in pieces the way the reference's
+trainer + model use their own (src/diff_recon/trainers/VanillaTS_trainer.py:60-130, src/diff_recon/models/VanillaTS_model.py:560-694):
 
     render_view (argument construction of VanillaTSModel.forward)  ->  TriangleRenderer  ->  2D or 3D HIP rasterizer
-    photometric_loss (fused L1 + SSIM)  ->  backward through the rasterizer  ->  Adam  ->  DensificationStats.update
+    photometric_loss (fused L1 + SSIM)  ->  backward through the rasterizer  ->  Adam
+    model_update(iteration) in the reference's order (:560-575): training statistic, densification, opacity pruning / clipping,
+    scale pruning / clipping, contribution pruning, opacity reset, gamma schedule, SH-degree schedule
+    -- every structural update through the native row operators of include/ts_model.h (diff_recon_hip/model_update.py).
 
-A "ground truth" image is rendered from a hidden set of triangles; a perturbed copy is optimised towards it.
-    python examples/train_synthetic.py [--rasterizer 2D|3D] [--iters 200] [--triangles 20000]
+`views_per_step` views are rendered per optimisation step and their gradients summed, which is what one step of image-parallel
+training computes across ranks (BASELINE.json configs[3]: 8 views per step over 8 GPUs; here the views run one after the other
+on one GPU -- the cross-rank exchange itself is covered by tests/test_multigpu_gpu.py and bench.py --gpus N).
+
+A "ground truth" is rendered from a hidden set of triangles from several cameras; a perturbed, sparser copy is optimised.
+    python examples/train_synthetic.py [--rasterizer 2D|3D] [--iters 400] [--triangles 20000] [--views 4]
 """
 import argparse
+import math
 import os
 import sys
 import time
+from types import SimpleNamespace as NS
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "triangle-splatting_amd")]
@@ -19,58 +28,133 @@ import numpy as np
 import torch
 
 import synthetic
+import diff_recon_hip as D
 from diff_recon_hip import DensificationStats, photometric_loss, render_view
 
 
 class Camera:
     """The attributes of the reference's Camera that the renderer reads (src/diff_recon/utils/camera.py:70-117)."""
 
-    def __init__(self, s, device):
+    def __init__(self, s, device, shift=(0.0, 0.0, 0.0)):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        view = s["viewmatrix"].copy()
+        sh = np.asarray(shift, np.float32)
+        view[3, :3] -= sh * np.array([-1, 1, -1], np.float32)  # translate the camera centre by `shift`
+        proj = (view @ synthetic.projection_matrix(s["tanfovx"], s["tanfovy"]).T).astype(np.float32)
         self.image_width, self.image_height = s["image_width"], s["image_height"]
         self.tan_fovx, self.tan_fovy = s["tanfovx"], s["tanfovy"]
-        self.world_view_transform, self.full_proj_transform, self.camera_center = t(s["viewmatrix"]), t(s["projmatrix"]), t(s["campos"])
+        self.world_view_transform, self.full_proj_transform = t(view), t(proj)
+        self.camera_center = t(np.array([0, 0, synthetic.CAM_DIST], np.float32) + sh)
         self.device = device
 
 
-def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, seed=0, log=print):
+def exponential_scheduler(v_init, v_final, max_steps):
+    """src/diff_recon/utils/scheduler.py:5-23 without the delay terms."""
+    def f(step):
+        if step <= 0:
+            return v_init
+        if step >= max_steps:
+            return v_final
+        t = step / max_steps
+        return math.exp(math.log(v_init) * (1 - t) + math.log(v_final) * t)
+    return f
+
+
+class SyntheticModel(DensificationStats):
+    """The state VanillaTSModel carries through training, under the reference's attribute names: four per-triangle parameters in
+    named Adam groups (:119-135), the six statistics arrays (:196-201, inherited), gamma / active_sh_degree and the schedulers of
+    _setup_model_update_utils (:150-194)."""
+
+    def __init__(self, vertex, f_dc, f_rest, raw_opacity, iters, max_sh_degree):
+        super().__init__(vertex.shape[0], vertex.device)
+        self._vertex, self._opacity = torch.nn.Parameter(vertex), torch.nn.Parameter(raw_opacity)
+        self._f_dc, self._f_rest = torch.nn.Parameter(f_dc), torch.nn.Parameter(f_rest)
+        self.optimizer = torch.optim.Adam([{"params": [self._vertex], "lr": 0.03, "name": "vertex"}, {"params": [self._opacity], "lr": 0.05, "name": "opacity"},
+                                           {"params": [self._f_dc], "lr": 0.01, "name": "f_dc"}, {"params": [self._f_rest], "lr": 0.0005, "name": "f_rest"}],
+                                          lr=0.0, eps=1e-15)
+        self.max_sh_degree, self.active_sh_degree, self.gamma = max_sh_degree, 0, 1.0
+        self.scene_bbox, self.ste_threshold = None, None
+        q = max(iters // 4, 1)
+        every = lambda a, b, k, **kw: NS(start_iter=a, end_iter=b, hold_iter=b, interval_iter=k, **kw)
+        self.config = NS(model_update=NS(
+            densification=every(q // 2, 3 * q, max(q // 3, 1), min_view_count=8, split_num=2, split_scale_threshold=60.0),
+            opacity_pruning=every(q, iters, max(q // 2, 1)), opacity_clipping=every(q, iters, max(q // 2, 1)),
+            scale_pruning=every(q, iters, q, radii_threshold=200.0, scale_threshold=200.0), scale_clipping=every(q, iters, max(q // 2, 1)),
+            contribution_pruning=every(2 * q, iters, q, min_view_count=8, target_point_num=int(0.8 * vertex.shape[0]), prune_ratio=0.3,
+                                       max_prune_ratio=0.3, contrib_max_ratio=0.5, sparsity_retain_ratio=0.2, downsample_iteration=[],
+                                       downsample_point_num=[]),
+            opacity_reset=every(2 * q, 2 * q + 1, 2 * q + 1, reset_value=0.7),
+            gamma_schedule=NS(start_iter=q, end_iter=iters), sh_schedule=NS(one_up_iters=[q, 2 * q, 3 * q])))
+        self.grad_threshold_scheduler = exponential_scheduler(1.2e-5, 8e-6, 3 * q)
+        self.opacity_pruning_scheduler = exponential_scheduler(0.02, 0.05, iters - q)
+        self.opacity_clipping_scheduler = exponential_scheduler(0.999, 0.99, iters - q)
+        self.scale_max_scheduler = exponential_scheduler(120.0, 100.0, iters - q)  # world units: the scene's mean side is ~55
+        self.gamma_scheduler = exponential_scheduler(1.0, 4.0, iters - q)  # the reference's configs go 1 -> 50 over 30 k iterations
+        self.log = []
+
+    def model_update(self, iteration, render_pkgs):
+        """VanillaTSModel.model_update (:560-575), same order."""
+        for pkg in render_pkgs:
+            self.update(pkg)  # _training_statistic
+        mu = self.config.model_update
+        for name in ("densification", "opacity_pruning", "opacity_clipping", "scale_pruning", "scale_clipping", "contribution_pruning", "opacity_reset"):
+            res = getattr(D, name)(self, iteration)
+            if res is not None:
+                self.log.append((iteration, name, res, self._vertex.shape[0]))
+        if mu.gamma_schedule.start_iter < iteration <= mu.gamma_schedule.end_iter:  # _set_gamma
+            self.gamma = self.gamma_scheduler(iteration - mu.gamma_schedule.start_iter)
+        self.active_sh_degree = min(sum(iteration > it for it in mu.sh_schedule.one_up_iters), self.max_sh_degree)  # _set_sh_degree
+
+
+def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, seed=0, views=2, views_per_step=2, log=print, updates=True):
     dev = torch.device("cuda")
-    s = synthetic.scene(triangles, width, height, 1, seed=seed, edge_px=10.0)
-    cam = Camera(s, dev)
+    D_sh = 2
+    s = synthetic.scene(triangles, width, height, D_sh, seed=seed, edge_px=10.0)
+    cams = [Camera(s, dev, (6.0 * v, -3.0 * v, 0.0)) for v in range(views)]
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     bg = torch.zeros(3)
-    kw = dict(bg_color=bg, gamma=1.0, active_sh_degree=1, max_sh_degree=1, rasterizer_type=rasterizer)
-    with torch.no_grad():  # hidden target
-        gt = render_view(cam, t(s["vertex"]), t(s["shs"][:, :1]), t(s["shs"][:, 1:]), torch.logit(t(s["opacity"]).clamp(0.05, 0.95)),
-                         is_training=False, **kw)["render"].clamp(0, 1)
+    kw = dict(bg_color=bg, max_sh_degree=D_sh, rasterizer_type=rasterizer)
+    with torch.no_grad():  # hidden targets
+        gts = [render_view(c, t(s["vertex"]), t(s["shs"][:, :1]), t(s["shs"][:, 1:]), torch.logit(t(s["opacity"]).clamp(0.05, 0.95)), is_training=False,
+                           gamma=1.0, active_sh_degree=D_sh, **kw)["render"].clamp(0, 1) for c in cams]
     g = torch.Generator(device="cuda").manual_seed(seed + 1)
-    vertex = (t(s["vertex"]) + 1.5 * torch.randn(s["vertex"].shape, device=dev, generator=g)).requires_grad_(True)
-    f_dc = torch.full_like(t(s["shs"][:, :1]), 0.5).requires_grad_(True)
-    f_rest = torch.zeros_like(t(s["shs"][:, 1:])).requires_grad_(True)
-    raw_op = torch.zeros((triangles, 1), device=dev).requires_grad_(True)
-    opt = torch.optim.Adam([{"params": [vertex], "lr": 0.05}, {"params": [f_dc], "lr": 0.01}, {"params": [f_rest], "lr": 0.0005},
-                            {"params": [raw_op], "lr": 0.05}])
-    stats = DensificationStats(triangles, dev)
+    keep = torch.rand(triangles, device=dev, generator=g) < 0.7  # start sparser than the target: densification has work to do
+    vertex = (t(s["vertex"]) + 1.5 * torch.randn(s["vertex"].shape, device=dev, generator=g))[keep].contiguous()
+    n0 = vertex.shape[0]
+    m = SyntheticModel(vertex, torch.full((n0, 1, 3), 0.5, device=dev), torch.zeros((n0, (D_sh + 1) ** 2 - 1, 3), device=dev),
+                       torch.zeros((n0, 1), device=dev), iters, D_sh)
     losses, t0 = [], time.perf_counter()
-    for it in range(iters):
-        pkg = render_view(cam, vertex, f_dc, f_rest, raw_op, is_training=True, **kw)
-        loss = photometric_loss(pkg["render"], gt, 0.8, 0.2)  # w_L1 = 1 - w_ssim, VanillaTS_trainer.py:72,111
-        opt.zero_grad(set_to_none=True)
-        loss.backward()
-        opt.step()
-        stats.update(pkg)
-        losses.append(loss.item())
-        if log and (it % 50 == 0 or it == iters - 1):
-            log(f"iter {it:4d}  loss {losses[-1]:.5f}  visible {int((pkg['radii'] > 0).sum())}")
+    for it in range(1, iters + 1):
+        m.optimizer.zero_grad(set_to_none=True)
+        pkgs, total = [], 0.0
+        for k in range(views_per_step):  # the views of one step: gradients are summed, like ranks' gradients in image-parallel training
+            v = (it * views_per_step + k) % views
+            pkg = render_view(cams[v], m._vertex, m._f_dc, m._f_rest, m._opacity, is_training=True, gamma=m.gamma, active_sh_degree=m.active_sh_degree, **kw)
+            loss = photometric_loss(pkg["render"], gts[v], 0.8, 0.2)  # w_L1 = 1 - w_ssim, VanillaTS_trainer.py:72,111
+            loss.backward()
+            pkgs.append(pkg)
+            total += loss.item()
+        m.optimizer.step()
+        if updates:
+            m.model_update(it, pkgs)
+        else:
+            for pkg in pkgs:
+                m.update(pkg)
+        losses.append(total / views_per_step)
+        if log and (it % 50 == 0 or it == 1 or it == iters):
+            log(f"iter {it:4d}  loss {losses[-1]:.5f}  triangles {m._vertex.shape[0]}  gamma {m.gamma:.2f}  sh {m.active_sh_degree}")
     torch.cuda.synchronize()
-    return losses, stats, (time.perf_counter() - t0) / iters
+    return losses, m, (time.perf_counter() - t0) / iters
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--rasterizer", default="2D", choices=["2D", "3D"])
-    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--iters", type=int, default=400)
     ap.add_argument("--triangles", type=int, default=20000)
+    ap.add_argument("--views", type=int, default=4)
     a = ap.parse_args()
-    losses, stats, sec = train(a.rasterizer, a.iters, a.triangles)
+    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views)
+    for row in m.log:
+        print("  update", row)
     print(f"{a.rasterizer}: loss {losses[0]:.5f} -> {losses[-1]:.5f} in {a.iters} iterations, {sec * 1e3:.2f} ms/iteration (incl. Python)")

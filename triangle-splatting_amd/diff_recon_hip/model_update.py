@@ -140,7 +140,7 @@ def select_rows(mask: torch.Tensor, match: int = 1):
 
 def scatter_rows(src: torch.Tensor, pos: torch.Tensor, dst: torch.Tensor, dst_row0: int = 0):
     """dst[dst_row0 + pos[i]] = src[i] for the selected rows."""
-    if src.shape[0] == 0:
+    if src.shape[0] == 0 or dst.numel() == 0:  # nothing selected
         return
     src = src.contiguous()
     with torch.cuda.device(src.device):
