@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--dense-exchange", action="store_true",
                     help="N > 1: all-reduce the dense dL_dshs (60 floats/triangle) instead of the factored exchange (15 + 3 per view)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--sync-free", action="store_true",
+                    help="use the sync-free forward (ts2d_forward, capacity = 1.25 x the instance count of the cold step) instead of the "
+                         "reference's sequence with its blocking read of num_rendered; overflow is checked after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -168,6 +171,11 @@ def main():
     events = not args.no_kernel_events
     step()  # cold step (library initialisation, allocator growth) -- never timed
     barrier()
+    if args.sync_free:
+        import diff_triangle_rasterization_2D as _pkg
+        _pkg.set_instance_capacity(int(1.25 * int(state["num_rendered"])) + 1024)
+        step()
+        barrier()
     if events:
         _C.profile_reset()
         _C.profile_only("")
@@ -193,9 +201,14 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    true_n = int(state["num_rendered"])
+    if args.sync_free:
+        over, true_n = _pkg.forward_overflowed(state["image"])
+        if over:
+            raise SystemExit("sync-free forward overflowed its instance capacity: the timed steps rendered nothing")
     ms_per_step = 1e3 * elapsed / args.steps
     mpix_s = world * W * H / (elapsed / args.steps) / 1e6
-    N = int(state["num_rendered"])
+    N = true_n
     ntiles = ((W + 15) // 16) * ((H + 15) // 16)
     alg = algorithmic_bytes(P, N, W, H, D, ntiles)
 
@@ -206,6 +219,7 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
                    "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N,
+                   "forward": "sync-free (ts2d_forward, device-side instance count)" if args.sync_free else "reference sequence (blocking read of num_rendered)",
                    "parallelism": f"image-parallel x{world}" + ((", RCCL all-reduce of 12 floats/triangle + all-gather of factored SH grads (3 floats/triangle/view)" if factored
                                        else ", RCCL all-reduce of dense per-triangle grads (60 floats/triangle)") if world > 1 else ""),
                    "algorithmic_bytes_per_step": alg["total"],

@@ -150,6 +150,19 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
                   const int32_t *radii, const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch,
                   size_t scratch_bytes, const ts2d_backward_out *out, void *stream);
 
+/* Sync-free forward (no counterpart in the reference, whose Rasterizer::forward blocks on a cudaMemcpy of num_rendered,
+ * R2D/src/rasterizer.cu:191): preprocess, depth order, instance count, emission, tile sort, ranges and blend are enqueued in ONE call
+ * and the host never waits.  The caller provides the capacity: `state->binning` must hold ts2d_binning_state_bytes(instance_capacity,
+ * W, H) bytes, and `instance_capacity` is what it later passes to ts2d_backward as num_rendered (the binning state is carved for it).
+ * The true instance count stays on the device; if it exceeds the capacity NOTHING is emitted (the image is the background, every
+ * statistic zero) and the state's status word is set -- read it with ts2d_forward_status (one blocking read, e.g. once per step
+ * after the optimizer has been queued) and re-run with a larger capacity.  Everything else as ts2d_forward_bin + ts2d_forward_render. */
+int ts2d_forward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state,
+                 int64_t instance_capacity, const ts2d_forward_out *out, void *stream);
+/* overflowed = 1 when the last ts2d_forward on this state exceeded its capacity; num_rendered = the true instance count. */
+int ts2d_forward_status(const ts2d_state *state, int32_t P, int32_t width, int32_t height, int32_t *overflowed, int64_t *num_rendered,
+                        void *stream);
+
 /* Multi-GPU gradient exchange helper (new capability, BASELINE.json north_star "image-parallel"; the reference has no
  * distributed path).  Each view's dL_dshs is basis(dir) x dL_dRGB per triangle (R2D/src/backward.cu:9-119), so ranks
  * exchange dL_dRGB (3 floats per triangle and view, from ts2d_backward with TS2D_FLAG_SH_FACTORED) plus the camera

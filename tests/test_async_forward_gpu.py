@@ -1,0 +1,49 @@
+"""Sync-free forward (include/ts2d.h: ts2d_forward; package switch set_instance_capacity): device-side instance count against a
+caller-provided capacity.  With enough capacity every output and gradient equals the synchronous path bit for bit (same kernels,
+same order; only atomics' summation order may differ); over capacity nothing is emitted and the status word says so."""
+import numpy as np
+import pytest
+
+import helpers
+import synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_async_forward_equals_synchronous_and_reports_overflow(variant):
+    import torch
+    import diff_triangle_rasterization_2D as pkg
+    s = synthetic.scene(20000, 320, 200, 2, seed=9)
+    ref = helpers.hip_forward_backward(s, True, variant=variant)
+    N = ref["num_rendered"]
+    try:
+        pkg.set_instance_capacity(lambda P, W, H: N + 1000)
+        got = helpers.hip_forward_backward(s, True, variant=variant)
+        assert got["num_rendered"] == N + 1000  # the capacity: only sizes the state for backward
+        for k in ("out_feature", "depth", "normal", "radii"):
+            assert np.array_equal(got[k], ref[k]), k
+        for k in ("contrib_sum", "contrib_max", "dL_dvertex", "dL_dcenter2D", "dL_dshs", "dL_dopacity"):
+            assert helpers.rel_l2(got[k], ref[k]) < 1e-6, k
+        # the tile ranges (and with them the instance list they index) are identical
+        assert np.array_equal(helpers.hip_state(got, s, "ranges"), helpers.hip_state(ref, s, "ranges"))
+        assert np.array_equal(helpers.hip_state(got, s, "vals")[:N], helpers.hip_state(ref, s, "vals"))
+        # status of a fitting and of an overflowing forward
+        from diff_triangle_rasterization_2D import TriangleRasterizer as R2
+        from diff_triangle_rasterization_3D import TriangleRasterizer as R3
+        rs = helpers.hip_settings(s, rich_info=True)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        R = R3 if variant == 3 else R2
+        args = (t(s["vertex"]).requires_grad_(True), torch.zeros((20000, 2), device="cuda", requires_grad=True), t(s["opacity"]))
+        out = R(rs)(*args, shs=t(s["shs"]))
+        assert pkg.forward_overflowed(out[0]) == (False, N)
+        pkg.set_instance_capacity(N - 1)
+        out = R(rs)(*args, shs=t(s["shs"]))
+        over, n_true = pkg.forward_overflowed(out[0])
+        assert over and n_true == N
+        bg = t(s["background"])[:, None, None].expand_as(out[0])
+        assert torch.equal(out[0], bg) and float(out[4].abs().sum()) == 0.0  # background only, no contributions
+        out[0].sum().backward()  # the backward of an overflowed forward is well defined: zero gradients
+        assert float(args[0].grad.abs().sum()) == 0.0
+    finally:
+        pkg.set_instance_capacity(None)

@@ -157,6 +157,7 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.legacy_blend = s_legacy;
     return r;
 }
+int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state, hipStream_t s);
 } // namespace
 
 extern "C" {
@@ -194,6 +195,100 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     if (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P))
         return fail(TS2D_ERR_CAPACITY, "geometry state buffer too small: %zu < %zu", state->geometry_bytes,
                     ts2d_geometry_state_bytes(P));
+    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s)) return rc;
+    GeometryStateView g;
+    ts_carve_geometry((char *)state->geometry, P, g);
+    unsigned long long n = 0;
+    TS_HIP(hipMemcpyAsync(&n, ts_instance_count_dev(g, P), sizeof(n), hipMemcpyDeviceToHost, s));
+    TS_HIP(hipStreamSynchronize(s)); // the reference's blocking cudaMemcpy, rasterizer.cu:191
+    if (n > 0x7fffffffull) // the reference's int num_rendered wraps here; instance slots are 32-bit
+        return fail(TS2D_ERR_CAPACITY, "%llu tile instances exceed the 2^31 - 1 the instance list can address", n);
+    *num_rendered = (int64_t)n;
+    return TS2D_OK;
+}
+
+} // extern "C" (reopened below, after the internal helpers)
+
+namespace
+{
+// Everything after the instance count is known -- on the host (n_dev == nullptr, N exact: the reference's sequence) or only on
+// the device (n_dev != nullptr, N = the capacity the binning state was carved for).
+int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t N, const unsigned long long *n_dev,
+                        const ts2d_state *state, const ts2d_forward_out *out, hipStream_t s)
+{
+    const bool rich = flags & TS2D_FLAG_RICH_INFO;
+    const int P = geom->P, W = cam->width, H = cam->height;
+    GeometryStateView g{};
+    BinningStateView b{};
+    ImageStateView im{};
+    if (P > 0) ts_carve_geometry((char *)state->geometry, P, g);
+    if (N > 0) ts_carve_binning((char *)state->binning, N, W, H, b);
+    ts_carve_image((char *)state->image, W, H, im);
+    const RenderArgs r = make_render(cam, geom, flags);
+    const int ntiles = r.grid_x * r.grid_y;
+    if (n_dev) n_dev = ts_instance_count_dev(g, P);
+
+    // tile ranges (rasterizer.cu:223) and the contribution statistics are cleared by the emission kernel, not by memsets
+    if (P > 0)
+    {
+        {
+            ProfScope ps("emit_keys", s);
+            ts_launch_emit_keys(P, r.grid_x, ntiles, g, b, im, rich ? out->contrib_sum : nullptr, rich ? out->contrib_max : nullptr,
+                                n_dev ? N : -1, im.status, s);
+        }
+        TS_CHECK(flags, s, "emit_keys");
+    }
+    else TS_HIP(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)ntiles, s));
+    if (N > 0)
+    {
+        {
+            ProfScope ps("tile_sort", s);
+            ts_sort_pairs(b, N, n_dev, ntiles, s); // tile bits only, see binning.hip
+        }
+        TS_CHECK(flags, s, "tile_sort");
+        {
+            ProfScope ps("tile_ranges", s);
+            ts_launch_tile_ranges(N, n_dev, b, im, s);
+        }
+        TS_CHECK(flags, s, "tile_ranges");
+    }
+    {
+        ProfScope ps("render_fwd", s);
+        if (flags & TS2D_FLAG_3D)
+            ts_launch_render3d_fwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
+                                   out->contrib_sum, out->contrib_max, s);
+        else if (r.legacy_blend)
+            ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+        else
+            ts_launch_render_fwd_group(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+    }
+    TS_CHECK(flags, s, "render_fwd");
+    return TS2D_OK;
+}
+
+int check_forward_args(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t N, const ts2d_state *state,
+                       const ts2d_forward_out *out)
+{
+    if (int rc = validate(cam, geom, flags)) return rc;
+    if (!state || !out || !out->out_feature) return fail(TS2D_ERR_INVALID, "null state/output");
+    const bool rich = flags & TS2D_FLAG_RICH_INFO;
+    if (rich && (!out->depth || !out->normal || (geom->P > 0 && (!out->contrib_sum || !out->contrib_max))))
+        return fail(TS2D_ERR_INVALID, "rich_info outputs are null");
+    const int P = geom->P, W = cam->width, H = cam->height;
+    if (N < 0) return fail(TS2D_ERR_INVALID, "num_rendered < 0");
+    if (N > 0x7fffffffll) return fail(TS2D_ERR_CAPACITY, "the instance list addresses at most 2^31 - 1 instances");
+    if (!state->image || state->image_bytes < ts2d_image_state_bytes(W, H)) return fail(TS2D_ERR_CAPACITY, "image state buffer too small");
+    if (N > 0 && (!state->binning || state->binning_bytes < ts2d_binning_state_bytes(N, W, H)))
+        return fail(TS2D_ERR_CAPACITY, "binning state buffer too small");
+    if (P > 0 && (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P)))
+        return fail(TS2D_ERR_CAPACITY, "geometry state buffer too small");
+    return TS2D_OK;
+}
+
+// preprocess + depth order + instance count on the device (no host read)
+int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state, hipStream_t s)
+{
+    const int P = geom->P;
     GeometryStateView g;
     ts_carve_geometry((char *)state->geometry, P, g);
     const PreprocessArgs a = make_pre(cam, geom, flags);
@@ -213,75 +308,50 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
         ts_scan_offsets(g, P, s);
     }
     TS_CHECK(flags, s, "scan");
-    unsigned long long n = 0;
-    TS_HIP(hipMemcpyAsync(&n, g.blocksum + (P + 1023) / 1024, sizeof(n), hipMemcpyDeviceToHost, s));
-    TS_HIP(hipStreamSynchronize(s)); // the reference's blocking cudaMemcpy, rasterizer.cu:191
-    if (n > 0x7fffffffull) // the reference's int num_rendered wraps here; instance slots are 32-bit
-        return fail(TS2D_ERR_CAPACITY, "%llu tile instances exceed the 2^31 - 1 the instance list can address", n);
-    *num_rendered = (int64_t)n;
     return TS2D_OK;
 }
+} // namespace
+
+extern "C" {
 
 int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t N,
                         const ts2d_state *state, const ts2d_forward_out *out, void *stream)
 {
-    if (int rc = validate(cam, geom, flags)) return rc;
-    if (!state || !out || !out->out_feature) return fail(TS2D_ERR_INVALID, "null state/output");
-    const bool rich = flags & TS2D_FLAG_RICH_INFO;
-    if (rich && (!out->depth || !out->normal || (geom->P > 0 && (!out->contrib_sum || !out->contrib_max))))
-        return fail(TS2D_ERR_INVALID, "rich_info outputs are null");
-    hipStream_t s = (hipStream_t)stream;
-    const int P = geom->P, W = cam->width, H = cam->height;
-    if (N < 0) return fail(TS2D_ERR_INVALID, "num_rendered < 0");
-    if (!state->image || state->image_bytes < ts2d_image_state_bytes(W, H))
-        return fail(TS2D_ERR_CAPACITY, "image state buffer too small");
-    if (N > 0 && (!state->binning || state->binning_bytes < ts2d_binning_state_bytes(N, W, H)))
-        return fail(TS2D_ERR_CAPACITY, "binning state buffer too small");
-    if (P > 0 && (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P)))
-        return fail(TS2D_ERR_CAPACITY, "geometry state buffer too small");
-    GeometryStateView g{};
-    BinningStateView b{};
-    ImageStateView im{};
-    if (P > 0) ts_carve_geometry((char *)state->geometry, P, g);
-    if (N > 0) ts_carve_binning((char *)state->binning, N, W, H, b);
-    ts_carve_image((char *)state->image, W, H, im);
-    const RenderArgs r = make_render(cam, geom, flags);
-    const int ntiles = r.grid_x * r.grid_y;
+    if (int rc = check_forward_args(cam, geom, flags, N, state, out)) return rc;
+    return forward_render_impl(cam, geom, flags, N, nullptr, state, out, (hipStream_t)stream);
+}
 
-    // tile ranges (rasterizer.cu:223) and the contribution statistics are cleared by the emission kernel, not by memsets
-    if (P > 0)
-    {
-        {
-            ProfScope ps("emit_keys", s);
-            ts_launch_emit_keys(P, r.grid_x, ntiles, g, b, im, rich ? out->contrib_sum : nullptr, rich ? out->contrib_max : nullptr, s);
-        }
-        TS_CHECK(flags, s, "emit_keys");
-    }
-    else TS_HIP(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)ntiles, s));
-    if (N > 0)
-    {
-        {
-            ProfScope ps("tile_sort", s);
-            ts_sort_pairs(b, N, ntiles, s); // tile bits only, see binning.hip
-        }
-        TS_CHECK(flags, s, "tile_sort");
-        {
-            ProfScope ps("tile_ranges", s);
-            ts_launch_tile_ranges(N, b, im, s);
-        }
-        TS_CHECK(flags, s, "tile_ranges");
-    }
-    {
-        ProfScope ps("render_fwd", s);
-        if (flags & TS2D_FLAG_3D)
-            ts_launch_render3d_fwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
-                                   out->contrib_sum, out->contrib_max, s);
-        else if (r.legacy_blend)
-            ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
-        else
-            ts_launch_render_fwd_group(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
-    }
-    TS_CHECK(flags, s, "render_fwd");
+int ts2d_forward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state,
+                 int64_t instance_capacity, const ts2d_forward_out *out, void *stream)
+{
+    if (int rc = check_forward_args(cam, geom, flags, instance_capacity, state, out)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (geom->P == 0) return forward_render_impl(cam, geom, flags, 0, nullptr, state, out, s);
+    if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
+    if (instance_capacity <= 0) return fail(TS2D_ERR_INVALID, "instance_capacity must be positive");
+    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s)) return rc;
+    static const unsigned long long on_device = 0; // any non-null marker: forward_render_impl resolves the real address
+    return forward_render_impl(cam, geom, flags, instance_capacity, &on_device, state, out, s);
+}
+
+int ts2d_forward_status(const ts2d_state *state, int32_t P, int32_t width, int32_t height, int32_t *overflowed, int64_t *num_rendered,
+                        void *stream)
+{
+    if (!state || !state->image || !overflowed || !num_rendered) return fail(TS2D_ERR_INVALID, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    *overflowed = 0;
+    *num_rendered = 0;
+    if (P <= 0) return TS2D_OK;
+    if (!state->geometry) return fail(TS2D_ERR_INVALID, "null geometry state");
+    GeometryStateView g{};
+    ImageStateView im{};
+    ts_carve_geometry((char *)state->geometry, P, g);
+    ts_carve_image((char *)state->image, width, height, im);
+    unsigned long long n = 0;
+    TS_HIP(hipMemcpyAsync(overflowed, im.status, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    TS_HIP(hipMemcpyAsync(&n, ts_instance_count_dev(g, P), sizeof(n), hipMemcpyDeviceToHost, s));
+    TS_HIP(hipStreamSynchronize(s));
+    *num_rendered = (int64_t)n;
     return TS2D_OK;
 }
 

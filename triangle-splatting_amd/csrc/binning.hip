@@ -70,13 +70,29 @@ __device__ __forceinline__ T peer_load(const T *p) { return __hip_atomic_load(p,
 template <typename T>
 __device__ __forceinline__ void peer_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// Sync-free forward (ts2d_forward): the pair count lives on the device.  `n_dev` (null on the synchronous path) points at the
+// 64-bit instance count the scan left behind; a count above `n` (the capacity the buffers were carved for) renders nothing and is
+// reported through the state's status word.  The launch covers the capacity; blocks past the actual count return at once.
+__device__ __forceinline__ bool resolve_count(const unsigned long long *n_dev, int64_t &n, RadixScratchView &r)
+{
+    if (n_dev)
+    {
+        const unsigned long long live = *n_dev;
+        n = (live <= (unsigned long long)n) ? (int64_t)live : 0;
+        r.chunks = (int)((n + CH - 1) / CH);
+        r.slabs = (r.chunks + 63) / 64;
+    }
+    return (int)blockIdx.x < r.chunks;
+}
+
 // Digit counts of every chunk, and -- by the blocks that arrive last -- their prefixes: the last block of a slab (64 chunks)
 // turns the slab's rows into exclusive column prefixes and its totals; the last slab to finish turns the slab totals into
 // their prefix over the slabs and forms the exclusive prefix of the 256 digit totals.  One launch, no spinning.
-__global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, int shift, uint32_t mask,
-                                                       RadixScratchView r)
+__global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, const unsigned long long *n_dev, int shift,
+                                                       uint32_t mask, RadixScratchView r)
 {
     __shared__ uint32_t bins[NB];
+    if (!resolve_count(n_dev, n, r)) return;
     const int t = threadIdx.x, chunk = blockIdx.x;
     bins[t] = 0u;
     __syncthreads();
@@ -144,10 +160,11 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
 //      per 4-byte store on this chip: measured 2x slower than rocPRIM; staged, the stores are coalesced runs).
 template <bool IDENTITY_VALUES>
 __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
-                                                          uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n, int shift,
-                                                          int nbits, RadixScratchView r)
+                                                          uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n,
+                                                          const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r)
 {
     constexpr int KB = CH / 256; // steps per wave
+    if (!resolve_count(n_dev, n, r)) return;
     __shared__ uint32_t stage_k[CH], stage_v[CH];
     __shared__ uint32_t wcnt[4][NB]; // per-wave digit counts, then the chunk-local start of the (wave, digit) run
     __shared__ int32_t gdelta[NB];   // global run start of the digit minus its chunk-local start
@@ -225,13 +242,13 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
     }
 }
 
-void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, int shift, int nbits,
-                const RadixScratchView &r, hipStream_t s)
+void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
+                int nbits, const RadixScratchView &r, hipStream_t s)
 {
     const dim3 grid((unsigned)r.chunks);
-    hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, s, kin, n, shift, (1u << nbits) - 1u, r);
-    if (vin) hipLaunchKernelGGL((rs_scatter_kernel<false>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits, r);
-    else hipLaunchKernelGGL((rs_scatter_kernel<true>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits, r);
+    hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, s, kin, n, n_dev, shift, (1u << nbits) - 1u, r);
+    if (vin) hipLaunchKernelGGL((rs_scatter_kernel<false>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r);
+    else hipLaunchKernelGGL((rs_scatter_kernel<true>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r);
 }
 
 // ---- step 2: tiles_sorted = tiles_touched[perm], 64-bit block sums, their prefix, N ---------------------------------------
@@ -298,7 +315,7 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
 constexpr uint32_t SMALL = 32;
 
 __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
-                                                         float *contrib_sum, float *contrib_max)
+                                                         float *contrib_sum, float *contrib_max, long long capacity, int32_t *status)
 {
     __shared__ uint32_t wtot[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -313,7 +330,14 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         contrib_max[i] = 0.0f;
     }
     const bool valid = i < P;
-    const uint32_t tiles = valid ? g.tiles_sorted[i] : 0u;
+    uint32_t tiles = valid ? g.tiles_sorted[i] : 0u;
+    if (capacity >= 0) // sync-free forward: the instance count is only known here; over capacity nothing is emitted
+    {
+        const unsigned long long live = g.blocksum[(P + SB - 1) / SB];
+        const bool over = live > (unsigned long long)capacity;
+        if (i == 0 && status) *status = over ? 1 : 0;
+        if (over) tiles = 0u;
+    }
     // inclusive prefix inside the block (wave64 DPP scan + the three preceding waves' totals) on top of the block's base;
     // scan blocks are 1024 triangles = four of these 256-lane blocks, so the three earlier quarters are summed here too
     const uint32_t inc = wave_inclusive_scan(tiles, lane);
@@ -374,9 +398,15 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     }
 }
 
-__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t N, const uint32_t *__restrict__ tile, uint2 *__restrict__ ranges)
+__global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t N, const unsigned long long *n_dev, const uint32_t *__restrict__ tile,
+                                                           uint2 *__restrict__ ranges)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (n_dev)
+    {
+        const unsigned long long live = *n_dev;
+        N = (live <= (unsigned long long)N) ? (int64_t)live : 0;
+    }
     if (i >= N) return;
     const uint32_t cur = tile[i];
     if (i == 0) ranges[cur].x = 0;
@@ -405,10 +435,10 @@ void ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
     if (P <= 0) return;
     const uint32_t *depth = (const uint32_t *)g.depth;
-    radix_pass(depth, nullptr, g.sk[0], g.sv[0], P, 0, 8, g.rs, s);
-    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, 8, 8, g.rs, s);
-    radix_pass(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, 16, 8, g.rs, s);
-    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, 24, 8, g.rs, s);
+    radix_pass(depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s);
+    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 8, 8, g.rs, s);
+    radix_pass(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, nullptr, 16, 8, g.rs, s);
+    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, s);
 }
 
 // Step 2: tiles_sorted = tiles_touched[perm], block sums -> exclusive prefix, blocksum[nblocks] = N.
@@ -420,15 +450,16 @@ void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 }
 
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
-                         float *contrib_sum, float *contrib_max, hipStream_t s)
+                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s)
 {
     if (P <= 0) return;
     hipLaunchKernelGGL(scan_emit_kernel, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges,
-                       contrib_sum, contrib_max);
+                       contrib_sum, contrib_max, (long long)capacity, status);
 }
+const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P) { return (const unsigned long long *)(g.blocksum + (P + SB - 1) / SB); }
 
 // Step 4: stable sort of the instances by tile id: ceil(bits / 8) passes, ping-pong from (k[0], v[0]).
-void ts_sort_pairs(const BinningStateView &b, int64_t N, int ntiles, hipStream_t s)
+void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s)
 {
     if (N <= 0) return;
     const int bits = ts_higher_msb((uint32_t)ntiles);
@@ -436,15 +467,15 @@ void ts_sort_pairs(const BinningStateView &b, int64_t N, int ntiles, hipStream_t
     for (int p = 0; p < b.passes; p++)
     {
         const int nbits = min(8, bits - 8 * p);
-        radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, 8 * p, nbits, b.rs, s);
+        radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, n_dev, 8 * p, nbits, b.rs, s);
         src ^= 1;
     }
 }
 
-void ts_launch_tile_ranges(int64_t N, const BinningStateView &b, const ImageStateView &im, hipStream_t s)
+void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s)
 {
     if (N <= 0) return;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, b.tile, im.ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, n_dev, b.tile, im.ranges);
 }
 
 // ---- rocPRIM comparators (tests/test_binning_gpu.py; never on the product path) --------------------------------------------------
@@ -497,7 +528,7 @@ int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
         int src = 0;
         for (int ps = 0; ps < b.passes; ps++)
         {
-            radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, 8 * ps, min(8, end_bit - 8 * ps), b.rs, s);
+            radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), b.rs, s);
             src ^= 1;
         }
         e = hipMemcpyAsync(keys_out, b.k[src], n * 4, hipMemcpyDeviceToDevice, s);

@@ -71,6 +71,7 @@ struct ImageStateView
     uint2 *ranges;       // T   [start, end) of each tile in the sorted list
     uint32_t *n_contrib; // W*H
     float *final_T;      // W*H
+    int32_t *status;     // 4   [0] sync-free forward: 1 = the instance count exceeded the capacity of the binning state
 };
 
 static inline size_t ts_align_up(size_t v) { return (v + TS_ALIGN - 1) & ~(size_t)(TS_ALIGN - 1); }
@@ -151,6 +152,7 @@ static inline size_t ts_carve_image(char *base, int32_t W, int32_t H, ImageState
     ts_carve(p, v.ranges, (size_t)gx * gy);
     ts_carve(p, v.n_contrib, (size_t)W * H);
     ts_carve(p, v.final_T, (size_t)W * H);
+    ts_carve(p, v.status, (size_t)4);
     return (size_t)(p - base) + TS_ALIGN;
 }
 
@@ -170,9 +172,10 @@ void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const Geo
 void ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s);                 // (depth bits, id) -> perm
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);                  // tiles_sorted, block sums, N
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
-                         float *contrib_sum, float *contrib_max, hipStream_t s);             // offsets + instances (+ output clears)
-void ts_sort_pairs(const BinningStateView &b, int64_t N, int ntiles, hipStream_t s);          // stable, tile bits only
-void ts_launch_tile_ranges(int64_t N, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
+                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path
+const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P);                        // where the scan leaves N
+void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s); // stable, tile bits only
+void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
 // rocPRIM comparators (tests only): same contracts as the hand-written steps, results into caller-provided device buffers
 int ts_compare_sort_pairs_rocprim(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
                                   int end_bit, hipStream_t s);

@@ -85,6 +85,11 @@ _lib.ts2d_forward_bin.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_
 _lib.ts2d_forward_render.restype = C.c_int
 _lib.ts2d_forward_render.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, C.c_int64,
                                      C.POINTER(_State), C.POINTER(_ForwardOut), _fp]
+_lib.ts2d_forward.restype = C.c_int
+_lib.ts2d_forward.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, _fp, C.POINTER(_State), C.c_int64,
+                              C.POINTER(_ForwardOut), _fp]
+_lib.ts2d_forward_status.restype = C.c_int
+_lib.ts2d_forward_status.argtypes = [C.POINTER(_State), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64), _fp]
 _lib.ts2d_backward.restype = C.c_int
 _lib.ts2d_backward.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, C.c_int64, _fp,
                                C.POINTER(_State), C.POINTER(_LossGrads), _fp, C.c_size_t, C.POINTER(_BackwardOut), _fp]
@@ -159,8 +164,12 @@ def _state(geometryBuffer, binningBuffer, imageBuffer) -> _State:
 
 def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma,
                         scale_modifier, background_depth, background, vertex, shs, feature, opacity, back_culling,
-                        rich_info, debug, *, variant=2):
-    """`variant=3` selects the 3D rasterizer (TS2D_FLAG_3D; used by the sibling package diff_triangle_rasterization_3D)."""
+                        rich_info, debug, *, variant=2, instance_capacity=None):
+    """`variant=3` selects the 3D rasterizer (TS2D_FLAG_3D; used by the sibling package diff_triangle_rasterization_3D).
+    `instance_capacity` (an int > 0) selects the SYNC-FREE forward (ts2d_forward): the binning state is sized for that many tile
+    instances, nothing is read back, and the returned `num_rendered` is the capacity (it only sizes the state for the backward
+    call); whether the true count fitted is reported by `forward_status`.  Default None = the reference's sequence with its one
+    blocking read of num_rendered."""
     P = vertex.size(0)
     H, W = int(image_height), int(image_width)
     use_shs = _use_shs(shs, feature)
@@ -218,6 +227,14 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
                              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
         geometryBuffer = torch.empty((_lib.ts2d_geometry_state_bytes(P),), **u8)
         imageBuffer = torch.empty((_lib.ts2d_image_state_bytes(W, H),), **u8)
+        if instance_capacity is not None:
+            cap = int(instance_capacity)
+            binningBuffer = torch.empty((_lib.ts2d_binning_state_bytes(cap, W, H),), **u8)
+            st = _state(geometryBuffer, binningBuffer, imageBuffer)
+            out = _ForwardOut(_ptr(out_feature), _ptr(depth), _ptr(normal), _ptr(contrib_sum), _ptr(contrib_max))
+            _check(_lib.ts2d_forward(C.byref(cam), C.byref(geom), flags, _ptr(radii), C.byref(st), cap, C.byref(out), stream),
+                   "rasterize_triangles")
+            return (cap, out_feature, radii, depth, normal, contrib_sum, contrib_max, geometryBuffer, binningBuffer, imageBuffer)
         binningBuffer = torch.empty((0,), **u8)
         st = _state(geometryBuffer, binningBuffer, imageBuffer)
         n = C.c_int64(0)
@@ -296,6 +313,16 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
                                   C.byref(loss), _ptr(scratch), scratch.numel(), C.byref(out), stream),
                "rasterize_triangles_backward")
     return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
+
+
+def forward_status(P, W, H, geometryBuffer, imageBuffer):
+    """(overflowed, num_rendered) of the last sync-free forward on these state buffers (ts2d_forward_status; one blocking read)."""
+    st = _State(_ptr(geometryBuffer), geometryBuffer.numel(), None, 0, _ptr(imageBuffer), imageBuffer.numel())
+    over, n = C.c_int32(0), C.c_int64(0)
+    with torch.cuda.device(imageBuffer.device):
+        _check(_lib.ts2d_forward_status(C.byref(st), int(P), int(W), int(H), C.byref(over), C.byref(n), torch.cuda.current_stream().cuda_stream),
+               "forward_status")
+    return bool(over.value), int(n.value)
 
 
 def sh_grad_expand(vertex, campos, dL_dcolor, sh_degree, M, out=None):

@@ -78,6 +78,38 @@ def _camera_and_geometry_args(rs: TriangleRasterizationSettings, background_dept
 # dL_dshs; they append (dL_dRGB (P,3), campos (3,)) to the sink and return no gradient for `shs` (parallel.py rebuilds the
 # sum over all ranks' views from the exchanged factors).
 _sh_grad_sink = None
+# Sync-free forward (include/ts2d.h: ts2d_forward): None = off (the reference's sequence, one blocking read of num_rendered per
+# forward); an int, or a callable (P, width, height) -> int, = the capacity in tile instances the binning state is sized for.
+# With it on, forward() never waits for the GPU; call `forward_overflowed(out_feature)` (one blocking read) once per step, e.g. after
+# the optimizer step has been queued, and re-render with a larger capacity when it reports True (the overflowing forward rendered
+# the background only).
+_instance_capacity = None
+
+
+def set_instance_capacity(capacity):
+    """Enables (int or callable (P, width, height) -> int) or disables (None) the sync-free forward for every later forward()."""
+    global _instance_capacity
+    _instance_capacity = capacity
+
+
+_last_sync_free_forward = None  # (P, width, height, geometryBuffer, imageBuffer) of the most recent sync-free forward
+
+
+def forward_overflowed(out_feature: torch.Tensor = None):
+    """(overflowed, true instance count) of the most recent sync-free forward -- or, given one of its outputs whose graph is still
+    alive, of the forward that produced `out_feature`.  One blocking read."""
+    if out_feature is not None and out_feature.grad_fn is not None:
+        try:
+            node = out_feature.grad_fn
+            saved = node.saved_tensors
+            rs = node.raster_settings
+            return _C.forward_status(saved[0].shape[0], rs.image_width, rs.image_height, saved[5], saved[7])
+        except RuntimeError:  # the graph was freed by backward(): fall back to the most recent forward
+            pass
+    if _last_sync_free_forward is None:
+        raise RuntimeError("no sync-free forward has run (set_instance_capacity)")
+    return _C.forward_status(*_last_sync_free_forward)
+
 # Set by parallel.GradBucket.capture(): while a bucket is installed, backward passes write dL_dvertex / dL_dopacity /
 # dL_dcenter2D (and the dense colour gradient when the bucket has a slot for it) straight into the bucket's views.
 _grad_bucket = None
@@ -100,8 +132,14 @@ class _RasterizeTriangles(torch.autograd.Function):
             vertex, shs, feature, opacity, rs.back_culling, rs.rich_info, rs.debug)
         with _snapshot_on_error("rasterize_triangles", native_args, rs.debug):
             (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max,
-             geometryBuffer, binningBuffer, imageBuffer) = _C.rasterize_triangles(*native_args, variant=ctx._forward_cls._variant)
+             geometryBuffer, binningBuffer, imageBuffer) = _C.rasterize_triangles(
+                *native_args, variant=ctx._forward_cls._variant,
+                instance_capacity=(_instance_capacity(vertex.shape[0], rs.image_width, rs.image_height) if callable(_instance_capacity)
+                                   else _instance_capacity) if vertex.shape[0] > 0 else None)
 
+        if _instance_capacity is not None and vertex.shape[0] > 0:
+            global _last_sync_free_forward
+            _last_sync_free_forward = (vertex.shape[0], rs.image_width, rs.image_height, geometryBuffer, imageBuffer)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.bg_depth = bg_depth
@@ -167,4 +205,4 @@ class TriangleRasterizer(nn.Module):
             opacity, self.raster_settings)
 
 
-__all__ = ["TriangleRasterizationSettings", "TriangleRasterizer"]
+__all__ = ["TriangleRasterizationSettings", "TriangleRasterizer", "set_instance_capacity", "forward_overflowed"]
