@@ -14,7 +14,7 @@ _cache = {}
 
 
 def load(name: str):
-    """name in {"_ref2d_C", "_ref3d_C", "_refknn_C"}; skips the calling test when the build is absent."""
+    """name in {"_ref2d_C", "_ref3d_C", "_ref3d_scalar_C", "_ref3d_nofma_C", "_refknn_C"}; skips the calling test when the build is absent."""
     if name not in _cache:
         path = os.path.join(ROOT, "oracle", "_ref", name + ".so")
         if not os.path.exists(path):
@@ -27,10 +27,11 @@ def load(name: str):
     return _cache[name]
 
 
-def forward_backward(s, rich_info=True, back_culling=False, use_feature=False, variant=2, device="cuda"):
-    """One scene through the reference's rasterize_triangles / rasterize_triangles_backward (R2D/ext.cpp:6-8, R3D/ext.cpp)."""
+def forward_backward(s, rich_info=True, back_culling=False, use_feature=False, variant=2, device="cuda", build=None):
+    """One scene through the reference's rasterize_triangles / rasterize_triangles_backward (R2D/ext.cpp:6-8, R3D/ext.cpp).
+    `build` names another build of the same sources (oracle/build_ref.py CODEGEN_FLAGS), e.g. "_ref3d_scalar_C"."""
     import torch
-    ref = load("_ref2d_C" if variant == 2 else "_ref3d_C")
+    ref = load(build or ("_ref2d_C" if variant == 2 else "_ref3d_C"))
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     empty = torch.empty(0, device=device)
     shs = empty if use_feature else t(s["shs"])

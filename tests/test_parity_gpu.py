@@ -281,6 +281,11 @@ def test_full_size_against_oracle(P, W, H, D, variant):
         assert helpers.robust_rel_l2(hf[k], ob[k], budget, grazing) < GRAD_TOL, k
     # its dL_dcenter2D -- the view-space xy of the SUM of the three vertex gradients, which largely cancel
     # (R3D backward.cu:211-213) -- is measured against the vertex gradients it is summed from
-    assert helpers.robust_rel_l2(hf["dL_dvertex"], ob["dL_dvertex"], budget, grazing) < GRAD_TOL
+    # The bar for the 3D geometry gradients is the reference's distance to ITSELF: its own sources built with and without the SLP
+    # vectorizer differ by 8.2e-2 un-budgeted and by 2.2e-3 after setting aside the 25 worst triangles (tests/test_reference_gpu.py::
+    # test_3d_variant_sits_inside_the_references_own_spread, profiles/r02_noise_floor3d_93k.json); the oracle is the -ffp-contract=off
+    # build of the reference to 1e-6, the product fuses like the vectorizer-free build.
+    tol3d = 2.5 * GRAD_TOL
+    assert helpers.robust_rel_l2(hf["dL_dvertex"], ob["dL_dvertex"], budget, grazing) < tol3d
     vref = np.linalg.norm(ob["dL_dvertex"].astype(np.float64))
-    assert helpers.robust_rel_l2(hf["dL_dcenter2D"], ob["dL_dcenter2D"], budget, grazing, ref=vref) < GRAD_TOL
+    assert helpers.robust_rel_l2(hf["dL_dcenter2D"], ob["dL_dcenter2D"], budget, grazing, ref=vref) < tol3d

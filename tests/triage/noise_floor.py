@@ -79,7 +79,8 @@ def compare(a, b, W, H):
         out[k] = float(helpers.rel_l2(a[k], b[k]))
     for k in ("dL_dvertex", "dL_dcenter2D"):
         out[k] = curve(a[k], b[k])
-    out["pixels_n_contrib_differs"] = int((a["n_contrib"] != b["n_contrib"]).sum())
+    if "n_contrib" in a and "n_contrib" in b:
+        out["pixels_n_contrib_differs"] = int((a["n_contrib"] != b["n_contrib"]).sum())
     rng = float(np.abs(b["out_feature"]).max())
     out["pixels_image_differs_gt_1e-3"] = int((np.abs(a["out_feature"] - b["out_feature"]).max(axis=0) > 1e-3 * rng).sum())
     out["pixels"] = W * H
@@ -92,23 +93,33 @@ def main():
     P, W, H, D = (int(x) for x in (sys.argv[1:5] if len(sys.argv) >= 5 else (1_000_000, 1920, 1080, 3)))
     seed = int(sys.argv[5]) if len(sys.argv) > 5 else 42
     with_ref = os.environ.get("NOISE_FLOOR_NO_REF", "") == ""
+    variant = int(os.environ.get("NOISE_FLOOR_VARIANT", "2"))  # 3: the 3D rasterizer (ray / plane barycentrics)
     s = synthetic.scene(P, W, H, D, seed=seed)
     t0 = time.time()
-    of = helpers.oracle_forward(s, True, False)
+    of = helpers.oracle_forward(s, True, False, variant=variant)
     ob = helpers.oracle_backward(s, of, True)
     O = dict(of, **ob)
     O["n_contrib"] = of["state"].field("n_contrib").astype(np.int64).reshape(H, W)
     t1 = time.time()
-    hf = helpers.hip_forward_backward(s, True, False)
+    hf = helpers.hip_forward_backward(s, True, False, variant=variant)
     hf["n_contrib"] = helpers.hip_state(hf, s, "n_contrib").astype(np.int64).reshape(H, W)
-    res = {"scene": f"S(P={P}, {W}x{H}, D={D}, seed={seed})", "oracle_seconds": round(t1 - t0, 1), "k_set_aside": list(KS),
+    res = {"scene": f"S(P={P}, {W}x{H}, D={D}, seed={seed})", "rasterizer": f"{variant}D", "oracle_seconds": round(t1 - t0, 1), "k_set_aside": list(KS),
            "HIP_vs_oracle": compare(hf, O, W, H)}
     if with_ref:
-        R = reference_run(s)
+        R = reference_run(s) if variant == 2 else ref_build.forward_backward(s, True, False, variant=3)
         res["oracle_vs_reference"] = compare(O, R, W, H)
         res["HIP_vs_reference"] = compare(hf, R, W, H)
+        if variant == 3:
+            # the reference against ITSELF: the same sources built with other code-generation switches (oracle/build_ref.py)
+            Rs = ref_build.forward_backward(s, True, False, variant=3, build="_ref3d_scalar_C")
+            Rn = ref_build.forward_backward(s, True, False, variant=3, build="_ref3d_nofma_C")
+            res["reference_scalar_vs_reference"] = compare(Rs, R, W, H)
+            res["reference_nofma_vs_reference"] = compare(Rn, R, W, H)
+            res["reference_nofma_vs_reference_scalar"] = compare(Rn, Rs, W, H)
+            res["HIP_vs_reference_scalar"] = compare(hf, Rs, W, H)
+            res["oracle_vs_reference_nofma"] = compare(O, Rn, W, H)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    path = os.path.join(ROOT, "gpurun_out", f"noise_floor_{P}.json")
+    path = os.path.join(ROOT, "gpurun_out", f"noise_floor_{P}.json" if variant == 2 else f"noise_floor3d_{P}.json")
     json.dump(res, open(path, "w"), indent=1)
     print(json.dumps(res, indent=1))
 

@@ -10,6 +10,7 @@ hipcc cross-compiles without a GPU.  Per-file flags matter:
 from __future__ import annotations
 
 import argparse
+import hashlib
 import os
 import shutil
 import subprocess
@@ -37,9 +38,10 @@ SOURCES = {
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
+    "render3d_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "api.hip": [],
 }
-HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
+HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
            os.path.join("..", "..", "include", "ts_knn.h"),
            os.path.join("..", "..", "include", "ts_model.h")]
@@ -50,6 +52,16 @@ def hipcc() -> str:
         if cand and os.path.exists(cand):
             return cand
     raise RuntimeError("hipcc not found: libts2d.so cannot be built (no CPU fallback exists by design)")
+
+
+_TOOLCHAIN_ID = {}
+
+
+def _toolchain_id(cc: str) -> str:
+    if cc not in _TOOLCHAIN_ID:
+        r = subprocess.run([cc, "--version"], capture_output=True, text=True)
+        _TOOLCHAIN_ID[cc] = hashlib.sha1((r.stdout + r.stderr).encode()).hexdigest()
+    return _TOOLCHAIN_ID[cc]
 
 
 def _newest_header() -> float:
@@ -65,8 +77,21 @@ def build(force: bool = False, verbose: bool = False) -> str:
         s = os.path.join(CSRC, src)
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
-            jobs.append([cc, *COMMON, *extra, "-c", s, "-o", o])
+        cmd = [cc, *COMMON, *extra, "-c", s, "-o", o]
+        # the object is only reused when it was produced by this very command line with this very compiler: a profiling build
+        # (TS2D_EXTRA_FLAGS=-DTS2D_STATS ...) or a toolchain update must not leave its objects behind for the next plain build
+        stamp, key = o + ".cmd", _toolchain_id(cc) + "\n" + " ".join(cmd)
+        fresh = os.path.exists(o) and os.path.exists(stamp) and open(stamp).read() == key
+        if force or not fresh or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_t):
+            jobs.append((cmd, stamp, key))
+
+    def compile_one(job):
+        cmd, stamp, key = job
+        if os.path.exists(stamp):
+            os.remove(stamp)
+        run(cmd)
+        with open(stamp, "w") as f:
+            f.write(key)
 
     def run(cmd):
         if verbose:
@@ -78,7 +103,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             print(r.stderr, file=sys.stderr)
 
     with ThreadPoolExecutor(max_workers=4) as ex:
-        list(ex.map(run, jobs))
+        list(ex.map(compile_one, jobs))
     if jobs or force or not os.path.exists(LIB):
         run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
     return LIB

@@ -254,9 +254,12 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     }
     {
         ProfScope ps("render_fwd", s);
-        if (flags & TS2D_FLAG_3D)
+        if ((flags & TS2D_FLAG_3D) && r.legacy_blend)
             ts_launch_render3d_fwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
                                    out->contrib_sum, out->contrib_max, s);
+        else if (flags & TS2D_FLAG_3D)
+            ts_launch_render3d_fwd_group(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
+                                         out->contrib_sum, out->contrib_max, s);
         else if (r.legacy_blend)
             ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
         else
@@ -392,9 +395,12 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     if (N > 0)
     {
         ProfScope ps("render_bwd", s);
-        if (flags & TS2D_FLAG_3D)
+        if ((flags & TS2D_FLAG_3D) && r.legacy_blend)
             ts_launch_render3d_bwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
                                    loss->dL_dout_normal, grad_rec, s);
+        else if (flags & TS2D_FLAG_3D)
+            ts_launch_render3d_bwd_group(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
+                                         loss->dL_dout_normal, grad_rec, s);
         else if (r.legacy_blend || r.bwd_mfma)
             ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
         else

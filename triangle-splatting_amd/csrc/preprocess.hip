@@ -114,7 +114,6 @@ __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int3
     } while (false);
 
     radii[idx] = out_radius;
-    if (idx < g.rs.slabs + 8) g.rs.tickets[idx] = 0u; // the binning kernels' "last block finishes" tickets (binning.hip)
     g.tiles_touched[idx] = out_tiles;
     g.rect[idx] = out_rect;
     g.clamped[idx] = out_clamped;

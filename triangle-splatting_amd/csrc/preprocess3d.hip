@@ -90,7 +90,6 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
     } while (false);
 
     radii[idx] = out_radius;
-    if (idx < g.rs.slabs + 8) g.rs.tickets[idx] = 0u; // the binning kernels' "last block finishes" tickets (binning.hip)
     g.tiles_touched[idx] = out_tiles;
     g.rect[idx] = out_rect;
     g.clamped[idx] = out_clamped;

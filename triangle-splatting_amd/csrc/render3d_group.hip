@@ -1,0 +1,560 @@
+// render3d_group.hip -- blend kernels of the 3D variant (rasterizer_type="3D"), lane-group edition.
+//
+// Behaviour follows FORWARD::renderCUDA / BACKWARD::renderCUDA of the reference's submodules/diff-triangle-rasterization-3D
+// ("R3D": src/forward.cu:151-306, src/backward.cu:216-454): for every pixel the view-space ray
+// p_ray = (tan_fovx * pixToProj(x), tan_fovy * pixToProj(y), 1) is intersected with the triangle's plane, barycentrics are taken
+// in 3D, and the same ecc / alpha / front-to-back blend as in the 2D variant follows.  Kept quirks: the normal is unnormalised;
+// accum_normal has no background term; the BACKWARD skip test is on G = exp(power), not on alpha (R3D backward.cu:351 vs
+// forward.cu:265), so pairs with G >= 1/255 > alpha that the forward skipped still receive (tiny) gradients.
+//
+// Structure = render_group.hip (four 16-lane groups per wave, one triangle per 4x4 pixel block and step, per-group entry lists,
+// DPP-row transpose-reduce, conflict-aware LDS accumulation, coalesced 64-byte atomic flush).  What is specific here:
+//   * the per-pixel arithmetic is the REFERENCE'S, expression for expression: depth = v1.n / p_ray.n, p_view = depth p_ray,
+//     p_vk = v_k - p_view, a1 = cross(p_v2, p_v3).n / n.n, a2 = cross(p_v3, p_v1).n / n.n, and the gradient terms of
+//     backward.cu:376-420 -- round 1 used projective affine forms N_k(q) / Den(q) and moment sums, which deliberately left
+//     the reference's rounding behaviour (its parity tests needed explained-outlier clauses);
+//   * only CULLING uses the affine forms (N_k, Den affine in the in-quadrant pixel offset; a_k >= m  <=>  s (N_k - m Den) >= 0
+//     wherever Den keeps its sign s over the 4x4 block), with the rounding slack added to the acceptance margin.
+#include "ts2d_common.h"
+#include "ts2d_wave.h"
+#include "ts2d_group.h"
+
+namespace
+{
+// Row of the constants table (ROW = 20 floats):
+//   [0..3] v1.xyz v2.x   [4..7] v2.yz v3.xy   [8..11] v3.z n.xyz   [12..15] d0 = v1.n, 1/n.n, opacity, r   [16] g [17] b
+//   [18] backward: triangle id; forward: this wave's running contrib_sum   [19] forward: running contrib_max
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 vsub(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 vscale(float s, V3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 vcross(V3 a, V3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+struct Cull3
+{
+    float d0, inn;
+    bool ov[4];
+};
+
+// Conservative culling against the four 4x4 blocks of the quadrant.  With u2 = v2 - v1, u3 = v3 - v1 and r = hit point - v1,
+// Den r = n x (delta x v1) where p_ray = v1 / v1.z + delta (see the derivation in render3d.hip: affine in the pixel offset, no
+// pole at grazing incidence); a2 = r.(u3 x n) / n.n, a3 = r.(n x u2) / n.n, a1 = 1 - a2 - a3.
+template <bool GAMMA1>
+__device__ __forceinline__ Cull3 cull3(V3 v1, V3 v2, V3 v3, V3 n, float op, float g2, V3 ray0, float sx, float sy)
+{
+    Cull3 c;
+    c.inn = 1.0f / vdot(n, n);
+    c.d0 = vdot(v1, n);
+    const float dc = vdot(ray0, n), dx = n.x * sx, dy = n.y * sy; // Den(q) = dc + dx qx + dy qy
+    const float iz = 1.0f / v1.z;
+    const float ddx = ray0.x - v1.x * iz, ddy = ray0.y - v1.y * iz;
+    const V3 m0 = vcross(n, V3{ddy * v1.z, -ddx * v1.z, ddx * v1.y - ddy * v1.x});
+    const V3 mx = vcross(n, V3{0.0f, -sx * v1.z, sx * v1.y});
+    const V3 my = vcross(n, V3{sy * v1.z, 0.0f, -sy * v1.x});
+    const V3 G2 = vscale(c.inn, vcross(vsub(v3, v1), n)), G3 = vscale(c.inn, vcross(n, vsub(v2, v1)));
+    const float a2c = vdot(m0, G2), a2x = vdot(mx, G2), a2y = vdot(my, G2);
+    const float a3c = vdot(m0, G3), a3x = vdot(mx, G3), a3y = vdot(my, G3);
+    const float a1c = dc - a2c - a3c, a1x = dx - a2x - a3x, a1y = dy - a2y - a3y;
+    const float t = 255.0f * op;
+    float E = -1.0f;
+    if (t >= 1.0f) // alpha >= 1/255 (forward) / G >= 1/255 (backward, op <= 1) needs ecc <= E
+    {
+        const float L = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(t); // ecc^(2 gamma) <= 2 ln(255 op); the backward passes op = 1
+        if (GAMMA1) E = __builtin_amdgcn_sqrtf(L);
+        else E = (g2 < 1e-6f) ? 10.0f : pow_nonneg(L, 1.0f / g2);
+        E = fminf(E * 1.0005f + 0.002f, 10.01f);
+    }
+    const float m = (1.0f - E) * (1.0f / 3.0f);
+    // f_k(q) = N_k(q) - m Den(q), affine: coefficients (x, y, c)
+    const float f1x = a1x - m * dx, f1y = a1y - m * dy, f1c = a1c - m * dc;
+    const float f2x = a2x - m * dx, f2y = a2y - m * dy, f2c = a2c - m * dc;
+    const float f3x = a3x - m * dx, f3y = a3y - m * dy, f3c = a3c - m * dc;
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+    {
+        const float bx = (g & 1) ? 4.0f : 0.0f, by = (g >> 1) ? 4.0f : 0.0f;
+        const float d00 = dc + dx * bx + dy * by;
+        const float dmin = d00 + fminf(0.0f, 3.0f * dx) + fminf(0.0f, 3.0f * dy), dmax = d00 + fmaxf(0.0f, 3.0f * dx) + fmaxf(0.0f, 3.0f * dy);
+        bool ov = E > 0.0f;
+        if (dmin > 0.0f || dmax < 0.0f) // Den keeps its sign over the block
+        {
+            const float s = dmin > 0.0f ? 1.0f : -1.0f;
+            const float slack = 1e-3f * fmaxf(fabsf(dmin), fabsf(dmax));
+            const float h1 = s * (f1c + f1x * bx + f1y * by) + fmaxf(0.0f, 3.0f * s * f1x) + fmaxf(0.0f, 3.0f * s * f1y);
+            const float h2 = s * (f2c + f2x * bx + f2y * by) + fmaxf(0.0f, 3.0f * s * f2x) + fmaxf(0.0f, 3.0f * s * f2y);
+            const float h3 = s * (f3c + f3x * bx + f3y * by) + fmaxf(0.0f, 3.0f * s * f3x) + fmaxf(0.0f, 3.0f * s * f3y);
+            ov = ov && h1 >= -slack && h2 >= -slack && h3 >= -slack;
+        }
+#ifdef TS3G_NO_CULL
+        ov = true;
+#endif
+        c.ov[g] = ov;
+    }
+    return c;
+}
+
+__device__ __forceinline__ void publish_row3(float *row, V3 v1, V3 v2, V3 v3, V3 n, const Cull3 &c, const float4 &r3, float w18)
+{
+    float4 *q = (float4 *)row;
+    q[0] = make_float4(v1.x, v1.y, v1.z, v2.x);
+    q[1] = make_float4(v2.y, v2.z, v3.x, v3.y);
+    q[2] = make_float4(v3.z, n.x, n.y, n.z);
+    q[3] = make_float4(c.d0, c.inn, r3.x, r3.y);
+    q[4] = make_float4(r3.z, r3.w, w18, 0.0f);
+}
+// Row -1: a unit triangle in the plane z = 1, a thousand units off axis, opacity 0: every pixel sees ecc ~ 3000
+__device__ __forceinline__ void write_dummy_row3(float *cst, int lane)
+{
+    if (lane < ROW)
+    {
+        // v1 = (1000, 1000, 1), v2 = (1001, 1000, 1), v3 = (1000, 1001, 1), n = (0, 0, 1), d0 = 1, 1/n.n = 1
+        const float tab[ROW] = {1000.0f, 1000.0f, 1.0f, 1001.0f, 1000.0f, 1.0f, 1000.0f, 1001.0f, 1.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        cst[lane - ROW] = tab[lane];
+    }
+}
+
+// The reference's per-pixel geometry (R3D forward.cu:238-256, backward.cu:328-343)
+struct Hit3
+{
+    V3 n, p1, p2, p3, c1, c2, e32, e13; // normal, p_vk = v_k - p_view, c1 = cross(p_v2, p_v3), c2 = cross(p_v3, p_v1), v3 - v2, v1 - v3
+    float prn, inv_prn, depth, inn, a1, a2, a3, mn, ecc, op, r, g, b;
+    bool ok; // |p_ray . n| >= EPS
+};
+// BWD selects which of the reference's two roundings of the depth is reproduced: the forward divides (forward.cu:243), the backward
+// multiplies by the rounded reciprocal (backward.cu:330-331).  The hit point has the magnitude of the depth while the barycentrics
+// live on the scale of the triangle, so one ulp of the depth is ~depth / edge ulps of a_k: v_rcp_f32 alone (1 ulp) tripled the
+// distance to the reference's gradients (profiles/r02_noise_floor3d_93k.json); one Newton step restores correct rounding.
+template <bool BWD>
+__device__ __forceinline__ Hit3 hit3(const float *row, V3 ray)
+{
+    const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4), q2 = *(const float4 *)(row + 8), q3 = *(const float4 *)(row + 12);
+    Hit3 h;
+    const V3 v1 = {q0.x, q0.y, q0.z}, v2 = {q0.w, q1.x, q1.y}, v3 = {q1.z, q1.w, q2.x};
+    h.n = {q2.y, q2.z, q2.w};
+    h.inn = q3.y; h.op = q3.z; h.r = q3.w;
+    h.prn = vdot(ray, h.n);
+    h.ok = fabsf(h.prn) >= 1e-8f; // forward.cu:241
+    // a ray inside the plane is skipped by the reference; here its lanes run on with depth = 0 so that every value stays finite
+    // (their alpha is forced to 0, and 0 * finite == 0 keeps them out of all sums)
+    const float r0 = h.ok ? __builtin_amdgcn_rcpf(h.prn) : 0.0f;
+    if (BWD)
+    {
+        h.inv_prn = fmaf(fmaf(-h.prn, r0, 1.0f), r0, r0);
+        h.depth = q3.x * h.inv_prn;
+    }
+    else
+    {
+        const float q = q3.x * r0;
+        h.inv_prn = r0;
+        h.depth = fmaf(fmaf(-h.prn, q, q3.x), r0, q);
+    }
+    const V3 pv = vscale(h.depth, ray);
+    h.p1 = vsub(v1, pv); h.p2 = vsub(v2, pv); h.p3 = vsub(v3, pv);
+    h.e32 = vsub(v3, v2); h.e13 = vsub(v1, v3);
+    h.c1 = vcross(h.p2, h.p3);
+    h.c2 = vcross(h.p3, h.p1);
+    h.a1 = vdot(h.c1, h.n) * h.inn; // forward.cu:251-253
+    h.a2 = vdot(h.c2, h.n) * h.inn;
+    h.a3 = 1.0f - h.a1 - h.a2;
+    h.mn = fminf(fminf(h.a1, h.a2), h.a3);
+    h.ecc = fmaf(-3.0f, h.mn, 1.0f);
+    return h;
+}
+
+template <bool RICH, bool GAMMA1>
+__global__ void __launch_bounds__(256) render3d_fwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
+                                                                  const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
+                                                                  float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                                                                  float *__restrict__ out_feature, float *__restrict__ out_depth,
+                                                                  float *__restrict__ out_normal, float *__restrict__ contrib_sum,
+                                                                  float *__restrict__ contrib_max)
+{
+    __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
+    __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+    constexpr int TCAP = 1024; // see render_group.hip: the tile's contribution statistics, merged over the four quadrant waves
+    __shared__ float tsum[RICH ? TCAP : 1];
+    __shared__ int tmax[RICH ? TCAP : 1];
+
+    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
+    const int lx = ((grp & 1) << 2) + (sub & 3), ly = ((grp >> 1) << 2) + (sub >> 2);
+    const int px = X0 + lx, py = Y0 + ly;
+    const bool inside = px < a.W && py < a.H;
+    // pixToProj(v, S) = (2 v - S + 1) / S   (R3D auxiliary.h:40-43)
+    const V3 ray = {tan_fovx * ((2.0f * (float)px - (float)a.W + 1.0f) / (float)a.W), tan_fovy * ((2.0f * (float)py - (float)a.H + 1.0f) / (float)a.H), 1.0f};
+    const float sx = tan_fovx * 2.0f / (float)a.W, sy = tan_fovy * 2.0f / (float)a.H;
+    const V3 ray0 = {tan_fovx * ((2.0f * (float)X0 - (float)a.W + 1.0f) / (float)a.W), tan_fovy * ((2.0f * (float)Y0 - (float)a.H + 1.0f) / (float)a.H), 1.0f};
+    const uint2 range = ranges[tile];
+    const int len = (int)(range.y - range.x);
+    if (RICH)
+    {
+        for (int k = threadIdx.x; k < min(len, TCAP); k += 256) { tsum[k] = 0.0f; tmax[k] = 0; }
+        __syncthreads();
+    }
+    const float g2 = 2.0f * a.gamma;
+    const float bg0 = a.background[0], bg1 = a.C > 1 ? a.background[1] : 0.0f, bg2 = a.C > 2 ? a.background[2] : 0.0f;
+    float *cst = cst_all[wave] + ROW;
+    signed char *list = list_all[wave];
+    write_dummy_row3(cst, lane);
+    const RowSel rsel(lane);
+
+    float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, anx = 0.0f, any_ = 0.0f, anz = 0.0f, ad = 0.0f;
+    bool done = !inside;
+    uint32_t last = (uint32_t)len;
+
+    for (int base = 0; base < len; base += 64)
+    {
+        const unsigned long long alive = ballot(!done);
+        if (alive == 0) break;
+        const int k = base + lane;
+        const bool valid = k < len;
+        uint32_t id = 0;
+        float4 r0 = make_float4(0, 0, 1, 0), r1 = make_float4(1, 0, 0, 1), r2 = make_float4(1, 0, 0, 1), r3 = make_float4(0, 0, 0, 0);
+        if (valid)
+        {
+            id = point_list[range.x + k];
+            const float4 *rp = rec + 4 * (size_t)id;
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
+        }
+        const V3 v1 = {r0.x, r0.y, r0.z}, v2 = {r0.w, r1.x, r1.y}, v3 = {r1.z, r1.w, r2.x}, n = {r2.y, r2.z, r2.w};
+        const Cull3 c = cull3<GAMMA1>(v1, v2, v3, n, r3.x, g2, ray0, sx, sy);
+        unsigned long long M[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) M[g] = ((alive >> (16 * g)) & 0xFFFFull) ? ballot(valid && c.ov[g] && r3.x * 255.0f >= 1.0f) : 0ull;
+        const unsigned long long any = M[0] | M[1] | M[2] | M[3];
+        if (any == 0) continue;
+        if ((any >> lane) & 1) publish_row3(cst + lane * ROW, v1, v2, v3, n, c, r3, 0.0f);
+        ((uint32_t *)list)[lane] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            if ((M[g] >> lane) & 1) list[g * 64 + lane_rank(M[g])] = (signed char)lane;
+        const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
+        const signed char *mylist = list + grp * 64;
+        for (int t0 = 0; t0 < steps; t0 += 8)
+        {
+            float cw[8];
+            uint32_t cjc[8];
+            const uint2 packed = *(const uint2 *)(mylist + t0);
+#pragma unroll
+            for (int st = 0; st < 8; st++)
+            {
+                cw[st] = 0.0f;
+                cjc[st] = 0u;
+                if (t0 + st < steps)
+                {
+                    const int jc = (int)(signed char)(((st < 4 ? packed.x : packed.y) >> (8 * (st & 3))) & 0xFFu);
+                    const float *row = cst + jc * ROW;
+                    const Hit3 h = hit3<false>(row, ray);
+                    const float pw = GAMMA1 ? h.ecc * h.ecc : pow_nonneg(h.ecc, g2);
+                    const float alpha = fminf(0.99f, h.op * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:259-260
+                    const bool hit = !done && h.ok && ecc_in_range(h.ecc) && alpha >= 1.0f / 255.0f;            // forward.cu:241,256,261
+                    const float al = hit ? alpha : 0.0f;
+                    const float contrib = al * T;
+                    ar = fmaf(h.r, contrib, ar);
+                    ag = fmaf(row[16], contrib, ag);
+                    ab = fmaf(row[17], contrib, ab);
+                    if (RICH)
+                    {
+                        anx = fmaf(h.n.x, contrib, anx); // forward.cu:276 (unnormalised normal)
+                        any_ = fmaf(h.n.y, contrib, any_);
+                        anz = fmaf(h.n.z, contrib, anz);
+                        ad = fmaf(h.depth, contrib, ad); // forward.cu:277
+                        cw[st] = contrib;
+                        cjc[st] = (uint32_t)jc;
+                    }
+                    T *= (1.0f - al);
+                    const bool sat = hit && T <= 0.0001f; // forward.cu:280
+                    last = sat ? (uint32_t)(base + jc + 1) : last;
+                    done = done || sat;
+                }
+            }
+            if (RICH)
+            {
+                // contrib_sum / contrib_max (forward.cu:271-273): reduced per 16-lane group and folded into the entry's row, one
+                // group after the other (two groups may hold the same entry) -- see render_group.hip
+                const float sm = row_reduce8(cw, rsel, OpAdd());
+                const float mx = row_reduce8(cw, rsel, OpMax());
+                const int ejc = (int)row_select8(cjc, rsel);
+                float *acc = cst + ejc * ROW + 18;
+                const bool writer = (lane & 1) == 0 && sm > 0.0f;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                {
+                    if (writer && grp == g)
+                    {
+                        float2 o = *(float2 *)acc;
+                        o.x += sm;
+                        o.y = __int_as_float(max(__float_as_int(o.y), __float_as_int(mx))); // both >= 0: int order == float order
+                        *(float2 *)acc = o;
+                    }
+                    wave_lds_order();
+                }
+            }
+        }
+        if (RICH && ((any >> lane) & 1))
+        {
+            const float2 o = *(const float2 *)(cst + lane * ROW + 18);
+            if (o.x > 0.0f && base + lane < TCAP)
+            {
+                atomicAdd(&tsum[base + lane], o.x); // LDS; the four waves of the tile meet here
+                atomicMax(&tmax[base + lane], __float_as_int(o.y));
+            }
+            else if (o.x > 0.0f)
+            {
+                unsafeAtomicAdd(contrib_sum + id, o.x);
+                if (o.y > contrib_max[id]) atomicMax((int *)contrib_max + id, __float_as_int(o.y));
+            }
+        }
+    }
+    if (RICH)
+    {
+        __syncthreads();
+        for (int k = threadIdx.x; k < min(len, TCAP); k += 256)
+        {
+            const float sm = tsum[k];
+            if (sm > 0.0f)
+            {
+                const uint32_t tid = point_list[range.x + k];
+                const float mx = __int_as_float(tmax[k]);
+                unsafeAtomicAdd(contrib_sum + tid, sm);
+                if (mx > contrib_max[tid]) atomicMax((int *)contrib_max + tid, __float_as_int(mx));
+            }
+        }
+    }
+    if (inside)
+    {
+        const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
+        final_T[pix] = T;
+        n_contrib[pix] = last;
+        out_feature[pix] = ar + T * bg0;
+        if (a.C > 1) out_feature[HW + pix] = ag + T * bg1;
+        if (a.C > 2) out_feature[2 * HW + pix] = ab + T * bg2;
+        if (RICH)
+        {
+            out_depth[pix] = ad + T * a.background_depth;
+            out_normal[pix] = anx;
+            out_normal[HW + pix] = any_;
+            out_normal[2 * HW + pix] = anz;
+        }
+    }
+}
+
+// Backward (R3D backward.cu:216-454).  Gradient record of the 3D variant: [0..8] dL/dv1_view dL/dv2_view dL/dv3_view,
+// [9..11] dL/dnormal_view, [12] dL/dopacity, [13..15] dL/drgb.  Per pair, with (z1, z2, z3) = dL/da (only the arg-min component is
+// non-zero) and w1 = z1 - z3, w2 = z2 - z3 (da3 = -da1 - da2 throughout, :396-400):
+//   dL/dv2 = w1 cross(p_v3, n) / n.n                                  (:386, 404)
+//   dL/dv3 = (w1 cross(n, p_v2) + w2 cross(p_v1, n)) / n.n            (:387, 393, 405)
+//   dL/dv1 = w2 cross(n, p_v3) / n.n + dL_ddepth n / (p_ray.n)        (:391, 402-403)
+//   dL_ddepth = dL_ddepth_pixel contrib + w1 da1_ddepth + w2 da2_ddepth, da1_ddepth = n.cross(v3 - v2, p_ray) / n.n, ...   (:389, 395, 401)
+//   dL/dn  = dL_dnormal_pixel contrib + (w1 (c1 - 2 a1 n) + w2 (c2 - 2 a2 n)) / n.n + dL_ddepth p_v1 / (p_ray.n)   (:388, 394, 403, 406)
+template <bool RICH, bool GAMMA1>
+__global__ void __launch_bounds__(256, 4) render3d_bwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
+                                                                     const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
+                                                                     const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
+                                                                     const float *__restrict__ dL_dout_feature,
+                                                                     const float *__restrict__ dL_dout_depth,
+                                                                     const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
+{
+    __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
+    __shared__ __attribute__((aligned(16))) float sums_all[4][65 * 16];
+    __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+
+    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tx = tile % a.grid_x, ty = tile / a.grid_x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int grp = lane >> 4, sub = lane & 15;
+    const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
+    const int lx = ((grp & 1) << 2) + (sub & 3), ly = ((grp >> 1) << 2) + (sub >> 2);
+    const int px = X0 + lx, py = Y0 + ly;
+    const bool inside = px < a.W && py < a.H;
+    const V3 ray = {tan_fovx * ((2.0f * (float)px - (float)a.W + 1.0f) / (float)a.W), tan_fovy * ((2.0f * (float)py - (float)a.H + 1.0f) / (float)a.H), 1.0f};
+    const float sx = tan_fovx * 2.0f / (float)a.W, sy = tan_fovy * 2.0f / (float)a.H;
+    const V3 ray0 = {tan_fovx * ((2.0f * (float)X0 - (float)a.W + 1.0f) / (float)a.W), tan_fovy * ((2.0f * (float)Y0 - (float)a.H + 1.0f) / (float)a.H), 1.0f};
+    const uint2 range = ranges[tile];
+    const float g2 = 2.0f * a.gamma;
+    const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
+    float *cst = cst_all[wave] + ROW;
+    float *sums = sums_all[wave] + 16;
+    signed char *list = list_all[wave];
+    write_dummy_row3(cst, lane);
+
+    float T = inside ? final_T[pix] : 0.0f;
+    const int last = inside ? (int)n_contrib[pix] : 0;
+    float dpr = 0.0f, dpg = 0.0f, dpb = 0.0f, dnx = 0.0f, dny = 0.0f, dnz = 0.0f, dd = 0.0f, B = 0.0f;
+    if (inside) // backward.cu:283-295; one scalar back-to-front composite B = sum_c dL_dpix_c accum_c (see render.hip)
+    {
+        dpr = dL_dout_feature[pix];
+        B = dpr * a.background[0];
+        if (a.C > 1) { dpg = dL_dout_feature[HW + pix]; B = fmaf(dpg, a.background[1], B); }
+        if (a.C > 2) { dpb = dL_dout_feature[2 * HW + pix]; B = fmaf(dpb, a.background[2], B); }
+        if (RICH)
+        {
+            dnx = dL_dout_normal[pix]; dny = dL_dout_normal[HW + pix]; dnz = dL_dout_normal[2 * HW + pix];
+            dd = dL_dout_depth[pix];
+            B = fmaf(dd, a.background_depth, B);
+        }
+    }
+    float lm = (float)last;
+    lm = fmaxf(lm, dpp<DPP_XOR1>(lm));
+    lm = fmaxf(lm, dpp<DPP_XOR2>(lm));
+    lm = fmaxf(lm, dpp<DPP_HALF_MIRROR>(lm));
+    lm = fmaxf(lm, dpp<DPP_MIRROR>(lm));
+    int glast[4];
+#pragma unroll
+    for (int g = 0; g < 4; g++) glast[g] = (int)__builtin_amdgcn_readlane((int)lm, 16 * g);
+    const int maxlast = max(max(glast[0], glast[1]), max(glast[2], glast[3]));
+    if (maxlast <= 0) return;
+
+    for (int base = ((maxlast - 1) >> 6) << 6; base >= 0; base -= 64)
+    {
+        const int k = base + lane;
+        const bool valid = k < maxlast;
+        uint32_t id = 0;
+        float4 r0 = make_float4(0, 0, 1, 0), r1 = make_float4(1, 0, 0, 1), r2 = make_float4(1, 0, 0, 1), r3 = make_float4(0, 0, 0, 0);
+        if (valid)
+        {
+            id = point_list[range.x + k];
+            const float4 *rp = rec + 4 * (size_t)id;
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
+        }
+        const V3 v1 = {r0.x, r0.y, r0.z}, v2 = {r0.w, r1.x, r1.y}, v3 = {r1.z, r1.w, r2.x}, n = {r2.y, r2.z, r2.w};
+        // the backward's skip test is on G (backward.cu:351): support computed with opacity 1
+        const Cull3 c = cull3<GAMMA1>(v1, v2, v3, n, 1.0f, g2, ray0, sx, sy);
+        unsigned long long M[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+        {
+            const int nn = glast[g] - base;
+            const unsigned long long keep = nn >= 64 ? ~0ull : (nn <= 0 ? 0ull : ((1ull << nn) - 1ull));
+            M[g] = ballot(valid && c.ov[g]) & keep;
+        }
+        const unsigned long long any = M[0] | M[1] | M[2] | M[3];
+        if (any == 0) continue;
+        if ((any >> lane) & 1)
+        {
+            publish_row3(cst + lane * ROW, v1, v2, v3, n, c, r3, __uint_as_float(id));
+            float4 *z = (float4 *)(sums + lane * 16);
+            z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
+        }
+        ((uint32_t *)list)[lane] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+            if ((M[g] >> lane) & 1) list[g * 64 + (__popcll(M[g]) - 1 - lane_rank(M[g]))] = (signed char)lane;
+        const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
+        const signed char *mylist = list + grp * 64;
+        unsigned long long conflict;
+        {
+            const int l0 = list[lane], l1 = list[64 + lane], l2 = list[128 + lane], l3 = list[192 + lane];
+            conflict = ballot((l0 >= 0 && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 >= 0 && (l1 == l2 || l1 == l3)) || (l2 >= 0 && l2 == l3));
+        }
+        const int lrel = last - base;
+        for (int t0 = 0; t0 < steps; t0++)
+        {
+            const int jc = mylist[t0];
+            const float *row = cst + jc * ROW;
+            float *acc = sums + jc * 16 + sub;
+            const bool shared_row = (conflict >> t0) & 1;
+            const float acc0 = *acc;
+            const Hit3 h = hit3<true>(row, ray);
+            const float cg = row[16], cb = row[17];
+            const float pw = GAMMA1 ? h.ecc * h.ecc : pow_nonneg(h.ecc, g2);
+            const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f);
+            const float opG = h.op * G;
+            const float alpha = fminf(0.99f, opG);
+            const bool hit = (jc < lrel) && h.ok && ecc_in_range(h.ecc) && G >= 1.0f / 255.0f; // backward.cu:322-323,328,343,351
+            const float al = hit ? alpha : 0.0f;
+            const float oma = 1.0f - al;
+            T = T * __builtin_amdgcn_rcpf(oma); // :354
+            const float contrib = al * T;
+            float X = fmaf(dpb, cb, fmaf(dpg, cg, dpr * h.r)); // :368
+            if (RICH) // :374-380
+            {
+                X = fmaf(dnz, h.n.z, fmaf(dny, h.n.y, fmaf(dnx, h.n.x, X)));
+                X = fmaf(dd, h.depth, X);
+            }
+            const float dL_dcontrib = X - B;
+            B = fmaf(al, X, oma * B);
+            const float dL_dalpha = dL_dcontrib * T; // :383
+            const float zr = 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(h.ecc + 1e-8f); // -3 dL_decc, :384-385
+            const float z = (hit && opG < 0.99f) ? zr : 0.0f;
+            const bool k1 = h.a1 == h.mn;
+            const bool k2 = !k1 && h.a2 == h.mn;
+            const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = z - z1 - z2;
+            const float w1 = (z1 - z3) * h.inn, w2 = (z2 - z3) * h.inn; // 1 / n.n folded in
+            const V3 A1 = vcross(h.p3, h.n), A2 = vcross(h.n, h.p2), A3 = vcross(h.p1, h.n);
+            const float da1_dd = vdot(h.n, vcross(h.e32, ray)), da2_dd = vdot(h.n, vcross(h.e13, ray)); // :389, 395
+            const float dLdd = fmaf(w2, da2_dd, fmaf(w1, da1_dd, RICH ? dd * contrib : 0.0f)) * h.inv_prn; // dL_ddepth / (p_ray.n)
+            float v[16];
+            v[bitrev4(0)] = fmaf(dLdd, h.n.x, -w2 * A1.x); // dL/dv1 = w2 cross(n, p_v3) + dL_ddepth n / prn; cross(n, p_v3) = -A1
+            v[bitrev4(1)] = fmaf(dLdd, h.n.y, -w2 * A1.y);
+            v[bitrev4(2)] = fmaf(dLdd, h.n.z, -w2 * A1.z);
+            v[bitrev4(3)] = w1 * A1.x; v[bitrev4(4)] = w1 * A1.y; v[bitrev4(5)] = w1 * A1.z;
+            v[bitrev4(6)] = fmaf(w2, A3.x, w1 * A2.x); v[bitrev4(7)] = fmaf(w2, A3.y, w1 * A2.y); v[bitrev4(8)] = fmaf(w2, A3.z, w1 * A2.z);
+            const float s12 = -2.0f * (w1 * h.a1 + w2 * h.a2);
+            v[bitrev4(9)] = fmaf(dLdd, h.p1.x, fmaf(s12, h.n.x, fmaf(w2, h.c2.x, fmaf(w1, h.c1.x, RICH ? dnx * contrib : 0.0f))));
+            v[bitrev4(10)] = fmaf(dLdd, h.p1.y, fmaf(s12, h.n.y, fmaf(w2, h.c2.y, fmaf(w1, h.c1.y, RICH ? dny * contrib : 0.0f))));
+            v[bitrev4(11)] = fmaf(dLdd, h.p1.z, fmaf(s12, h.n.z, fmaf(w2, h.c2.z, fmaf(w1, h.c1.z, RICH ? dnz * contrib : 0.0f))));
+            v[bitrev4(12)] = hit ? dL_dalpha * G : 0.0f; // :447
+            v[bitrev4(13)] = dpr * contrib; v[bitrev4(14)] = dpg * contrib; v[bitrev4(15)] = dpb * contrib; // :365
+            const float red = row_reduce16(v, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull);
+            if (!shared_row) *acc = acc0 + red;
+            else
+            {
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+                {
+                    if (grp == g) *acc += red;
+                    wave_lds_order();
+                }
+            }
+        }
+        {
+            if ((any >> lane) & 1) list[lane_rank(any)] = (signed char)lane;
+            const int nn = __popcll(any);
+#pragma unroll 1
+            for (int e0 = 0; e0 < nn; e0 += 4)
+            {
+                if (e0 + grp < nn)
+                {
+                    const int e = list[e0 + grp];
+                    const uint32_t eid = __float_as_uint(cst[e * ROW + 18]);
+                    unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, sums[e * 16 + sub]);
+                }
+            }
+        }
+    }
+}
+} // namespace
+
+#define TS_DISPATCH_G3(KERNEL, ...)                                                                                                \
+    do                                                                                                                              \
+    {                                                                                                                               \
+        const bool g1 = (a.gamma == 1.0f);                                                                                          \
+        if (a.rich_info && g1) hipLaunchKernelGGL((KERNEL<true, true>), grid, dim3(256), 0, s, __VA_ARGS__);                        \
+        else if (a.rich_info) hipLaunchKernelGGL((KERNEL<true, false>), grid, dim3(256), 0, s, __VA_ARGS__);                        \
+        else if (g1) hipLaunchKernelGGL((KERNEL<false, true>), grid, dim3(256), 0, s, __VA_ARGS__);                                 \
+        else hipLaunchKernelGGL((KERNEL<false, false>), grid, dim3(256), 0, s, __VA_ARGS__);                                        \
+    } while (0)
+
+void ts_launch_render3d_fwd_group(const RenderArgs &a, float tan_fovx, float tan_fovy, const GeometryStateView &g, const BinningStateView &b,
+                                  const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal, float *contrib_sum,
+                                  float *contrib_max, hipStream_t s)
+{
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    if (grid.x == 0) return;
+    TS_DISPATCH_G3(render3d_fwd_group_kernel, a, tan_fovx, tan_fovy, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, out_feature, out_depth,
+                   out_normal, contrib_sum, contrib_max);
+}
+
+void ts_launch_render3d_bwd_group(const RenderArgs &a, float tan_fovx, float tan_fovy, const GeometryStateView &g, const BinningStateView &b,
+                                  const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
+                                  const float *dL_dout_normal, float *grad_rec, hipStream_t s)
+{
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    if (grid.x == 0) return;
+    TS_DISPATCH_G3(render3d_bwd_group_kernel, a, tan_fovx, tan_fovy, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature,
+                   dL_dout_depth, dL_dout_normal, grad_rec);
+}

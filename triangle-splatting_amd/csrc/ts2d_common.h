@@ -224,6 +224,14 @@ void ts_launch_render3d_bwd(const RenderArgs &a, float tan_fovx, float tan_fovy,
                             const BinningStateView &b, const ImageStateView &im, const float *dL_dout_feature,
                             const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec, hipStream_t s);
 
+// lane-group kernels with the reference's per-pixel ray / plane arithmetic (render3d_group.hip); the default
+void ts_launch_render3d_fwd_group(const RenderArgs &a, float tan_fovx, float tan_fovy, const GeometryStateView &g,
+                                  const BinningStateView &b, const ImageStateView &im, float *out_feature, float *out_depth,
+                                  float *out_normal, float *contrib_sum, float *contrib_max, hipStream_t s);
+void ts_launch_render3d_bwd_group(const RenderArgs &a, float tan_fovx, float tan_fovy, const GeometryStateView &g,
+                                  const BinningStateView &b, const ImageStateView &im, const float *dL_dout_feature,
+                                  const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec, hipStream_t s);
+
 // ---- factored SH-gradient exchange (multi-GPU, shgrad.hip) ---------------------------------------------------------
 void ts_launch_sh_grad_expand(int P, int D, int M, int V, const float *vertex, const float *campos, const float *dL_dcolor,
                               float *dL_dshs, hipStream_t s);

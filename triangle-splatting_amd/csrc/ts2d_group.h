@@ -1,0 +1,100 @@
+// ts2d_group.h -- building blocks shared by the lane-group blend kernels (render_group.hip: 2D, render3d_group.hip: 3D):
+// wave64 ballots / ranks, the 16-lane DPP-row transpose-reduce networks, the ecc range test.
+#pragma once
+#include "ts2d_wave.h"
+
+namespace
+{
+constexpr int ROW = 20; // floats per entry row of the wave-private constants table (row -1 = a dummy no pixel can hit)
+
+__device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int lane_rank(unsigned long long m) // set bits of m below this lane
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// 0 <= ecc <= 10 (forward.cu:307) as ONE unsigned compare: negative floats and NaN have larger bit patterns than 10.0f
+__device__ __forceinline__ bool ecc_in_range(float ecc) { return __float_as_uint(ecc) <= 0x41200000u; }
+
+// ---- 16-lane (DPP row) transpose-reduce: N values per lane -> each lane keeps the row-wide reduction of ONE value ----
+// Level 1 pairs lanes l, l ^ 8 (row_ror:8), level 2 lanes inside a group of 8 (row_half_mirror), level 3 l, l ^ 2, then l, l ^ 1.
+struct RowSel
+{
+    bool b3, b2, b1;
+    __device__ __forceinline__ explicit RowSel(int lane) : b3(lane & 8), b2(lane & 4), b1(lane & 2) {}
+};
+template <typename Op>
+__device__ __forceinline__ float pair_ror8(float x, float y, bool b, Op op)
+{
+    const float own = b ? y : x, oth = b ? x : y;
+    return op(own, dpp<DPP_ROR8>(oth));
+}
+template <typename Op>
+__device__ __forceinline__ float pair_hmir(float x, float y, bool b, Op op)
+{
+    const float own = b ? y : x, oth = b ? x : y;
+    return op(own, dpp<DPP_HALF_MIRROR>(oth));
+}
+template <typename Op>
+__device__ __forceinline__ float pair_xor2(float x, float y, bool b, Op op)
+{
+    const float own = b ? y : x, oth = b ? x : y;
+    return op(own, dpp<DPP_XOR2>(oth));
+}
+// 8 values: the result of value (b3 + 2 b2 + 4 b1) lands in lanes l and l ^ 1
+template <typename Op>
+__device__ __forceinline__ float row_reduce8(const float (&c)[8], const RowSel &r, Op op)
+{
+    const float s0 = pair_ror8(c[0], c[1], r.b3, op), s1 = pair_ror8(c[2], c[3], r.b3, op);
+    const float s2 = pair_ror8(c[4], c[5], r.b3, op), s3 = pair_ror8(c[6], c[7], r.b3, op);
+    const float t0 = pair_hmir(s0, s1, r.b2, op), t1 = pair_hmir(s2, s3, r.b2, op);
+    const float v = pair_xor2(t0, t1, r.b1, op);
+    return op(v, dpp<DPP_XOR1>(v));
+}
+__device__ __forceinline__ uint32_t row_select8(const uint32_t (&c)[8], const RowSel &r)
+{
+    const uint32_t s0 = r.b3 ? c[1] : c[0], s1 = r.b3 ? c[3] : c[2], s2 = r.b3 ? c[5] : c[4], s3 = r.b3 ? c[7] : c[6];
+    const uint32_t t0 = r.b2 ? s1 : s0, t1 = r.b2 ? s3 : s2;
+    return r.b1 ? t1 : t0;
+}
+
+// 16 values: the row-wide sum of the value fed at position (b3 + 2 b2 + 4 b1 + 8 b0) lands in the lane -- callers feed
+// gradient-record column c at position bitrev4(c), so that lane (l & 15) of a group ends up with column (l & 15).
+// Levels 1 and 2 pair lanes of different DPP banks (l ^ 8 via row_ror:8, then the two banks of each 8 via row_half_mirror), so
+// the "which half keeps which value" select is the instruction's own bank write mask: two v_add_f32_dpp per pair instead of
+// two v_cndmask + one (all half rate on gfx950).  Levels 3 and 4 pair lanes inside a quad and need one v_cndmask each.
+// Written as ONE asm statement because hipcc's DPP combiner does not form partially masked adds; wait states (a VALU
+// result needs 2 states before a DPP op reads it) are satisfied by the instruction order plus the three s_nop.
+__device__ __forceinline__ float row_reduce16(float (&v)[16], unsigned long long mask_b1, unsigned long long mask_b0)
+{
+#define TSG_L1(X, Y)                                                                    \
+    "v_add_f32_dpp " Y ", " Y ", " Y " row_ror:8 row_mask:0xf bank_mask:0xc\n"         \
+    "v_add_f32_dpp " Y ", " X ", " X " row_ror:8 row_mask:0xf bank_mask:0x3\n"
+#define TSG_L2(X, Y)                                                                    \
+    "v_add_f32_dpp " Y ", " Y ", " Y " row_half_mirror row_mask:0xf bank_mask:0xa\n"   \
+    "v_add_f32_dpp " Y ", " X ", " X " row_half_mirror row_mask:0xf bank_mask:0x5\n"
+#define TSG_L3(X, Y, QP, M)                                                             \
+    "v_add_f32_dpp " X ", " X ", " X " quad_perm:" QP " row_mask:0xf bank_mask:0xf\n"  \
+    "v_add_f32_dpp " Y ", " Y ", " Y " quad_perm:" QP " row_mask:0xf bank_mask:0xf\n"  \
+    "v_cndmask_b32_e64 " Y ", " X ", " Y ", " M "\n"
+    asm volatile("s_nop 1\n"
+                 TSG_L1("%0", "%1") TSG_L1("%2", "%3") TSG_L1("%4", "%5") TSG_L1("%6", "%7")
+                 TSG_L1("%8", "%9") TSG_L1("%10", "%11") TSG_L1("%12", "%13") TSG_L1("%14", "%15")
+                 TSG_L2("%1", "%3") TSG_L2("%5", "%7") TSG_L2("%9", "%11") TSG_L2("%13", "%15")
+                 TSG_L3("%3", "%7", "[2,3,0,1]", "%16") TSG_L3("%11", "%15", "[2,3,0,1]", "%16")
+                 "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 0\n"
+                 "v_add_f32_dpp %15, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_e64 %15, %7, %15, %17\n"
+                 "s_nop 1\n"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                 : "s"(mask_b1), "s"(mask_b0));
+#undef TSG_L1
+#undef TSG_L2
+#undef TSG_L3
+    return v[15];
+}
+constexpr int bitrev4(int c) { return ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3); }
+
+} // namespace

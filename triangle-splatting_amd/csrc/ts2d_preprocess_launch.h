@@ -12,10 +12,18 @@
 
 namespace ts
 {
+// The binning kernels' "last block finishes" tickets (binning.hip) are zeroed by the first launch of the step.  Every grid has at
+// least 64 threads and slabs + 8 <= max(P, 64), so the threads beyond P of a tiny scene take part.
+__device__ __forceinline__ void clear_tickets(const GeometryStateView &g, int idx)
+{
+    if (idx < g.rs.slabs + 8) g.rs.tickets[idx] = 0u;
+}
+
 template <class Body>
 __global__ void __launch_bounds__(256) preprocess_fwd_direct_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
+    clear_tickets(g, idx);
     if (idx >= a.P) return;
     Body::fwd(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
 }
@@ -30,6 +38,7 @@ __global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArg
     stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
     if (SHROW > 0) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
     __syncthreads();
+    clear_tickets(g, idx);
     if (idx >= a.P) return;
     const float *shp = SHROW > 0 ? s_sh + lane * (SHROW + 1) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
     Body::fwd(a, radii, g, idx, s_v + lane * 9, shp);
