@@ -19,7 +19,7 @@ for rich in (True, False):
     _C.profile_enable(False)
     print(f"rich={rich}: " + "  ".join(f"{n} {v:.3f}" for n, v in rows.items() if n.startswith("render")))
 if hasattr(_C._lib, "ts2d_stats_read_group"):
-    buf = (ctypes.c_ulonglong * 8)()
+    buf = (ctypes.c_ulonglong * 12)()
     _C._lib.ts2d_stats_read_group(buf, 1)
     hf = helpers.hip_forward_backward(s, backward=False)
     torch.cuda.synchronize()
@@ -27,6 +27,7 @@ if hasattr(_C._lib, "ts2d_stats_read_group"):
     v = list(buf); N = hf["num_rendered"]
     print(f"N {N}; visits {v[0]}; (entry,block) survivors {v[1]}; (entry,quadrant) survivors {v[7]}; steps {v[2]}; windows {v[3]}; "
           f"pairs {v[4]}; waves {v[5]}; batches {v[6]}")
+    print(f"steps with a row shared by two groups {v[8]} ({v[8]/max(v[2],1):.3f} of steps); passes {v[9]}, second passes {v[10]}")
     import json
     json.dump({"scene": f"S(P={P}, {W}x{H}, D={D}, seed=42)", "num_rendered": N, "list_entries_visited_per_quadrant_wave_total": v[0],
                "entry_block_survivors": v[1], "entry_quadrant_survivors": v[7], "wave_steps": v[2], "windows": v[3],

@@ -43,8 +43,8 @@ template <bool GAMMA1>
 __device__ __forceinline__ Cull3 cull3(V3 v1, V3 v2, V3 v3, V3 n, float op, float g2, V3 ray0, float sx, float sy)
 {
     Cull3 c;
-    c.inn = 1.0f / vdot(n, n);
-    c.d0 = vdot(v1, n);
+    c.inn = 1.0f / vdot(n, n); // forward.cu:250
+    c.d0 = vdot(v1, n);        // forward.cu:243
     const float dc = vdot(ray0, n), dx = n.x * sx, dy = n.y * sy; // Den(q) = dc + dx qx + dy qy
     const float iz = 1.0f / v1.z;
     const float ddx = ray0.x - v1.x * iz, ddy = ray0.y - v1.y * iz;
@@ -101,6 +101,19 @@ __device__ __forceinline__ void publish_row3(float *row, V3 v1, V3 v2, V3 v3, V3
     q[2] = make_float4(v3.z, n.x, n.y, n.z);
     q[3] = make_float4(c.d0, c.inn, r3.x, r3.y);
     q[4] = make_float4(r3.z, r3.w, w18, 0.0f);
+}
+// Second pass of a batch with more than NR surviving entries (rare): the lane gathers its entry's record again (see render_group.hip)
+__device__ __forceinline__ void republish_row3(float *row, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, uint32_t pos,
+                                               bool with_id)
+{
+    const uint32_t id = point_list[pos];
+    const float4 *rp = rec + 4 * (size_t)id;
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+    const V3 v1 = {r0.x, r0.y, r0.z}, v2 = {r0.w, r1.x, r1.y}, v3 = {r1.z, r1.w, r2.x}, n = {r2.y, r2.z, r2.w};
+    Cull3 c;
+    c.inn = 1.0f / vdot(n, n);
+    c.d0 = vdot(v1, n);
+    publish_row3(row, v1, v2, v3, n, c, r3, with_id ? __uint_as_float(id) : 0.0f);
 }
 // Row -1: a unit triangle in the plane z = 1, a thousand units off axis, opacity 0: every pixel sees ecc ~ 3000
 __device__ __forceinline__ void write_dummy_row3(float *cst, int lane)
@@ -162,17 +175,17 @@ __device__ __forceinline__ Hit3 hit3(const float *row, V3 ray)
 }
 
 template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256) render3d_fwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
+__global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
                                                                   const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                   float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                                   float *__restrict__ out_feature, float *__restrict__ out_depth,
                                                                   float *__restrict__ out_normal, float *__restrict__ contrib_sum,
                                                                   float *__restrict__ contrib_max)
 {
-    __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
-    __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+    __shared__ __attribute__((aligned(16))) float cst_all[4][(NR + 1) * ROW];
+    __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2]; // per group: NR entries of (row | batch position << 8)
     constexpr int TCAP = 1024; // see render_group.hip: the tile's contribution statistics, merged over the four quadrant waves
-    __shared__ float tsum[RICH ? TCAP : 1];
+    __shared__ unsigned long long tsum[RICH ? TCAP : 1]; // 16.48 fixed point (ts2d_group.h)
     __shared__ int tmax[RICH ? TCAP : 1];
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
@@ -191,13 +204,13 @@ __global__ void __launch_bounds__(256) render3d_fwd_group_kernel(RenderArgs a, f
     const int len = (int)(range.y - range.x);
     if (RICH)
     {
-        for (int k = threadIdx.x; k < min(len, TCAP); k += 256) { tsum[k] = 0.0f; tmax[k] = 0; }
+        for (int k = threadIdx.x; k < min(len, TCAP); k += 256) { tsum[k] = 0ull; tmax[k] = 0; }
         __syncthreads();
     }
     const float g2 = 2.0f * a.gamma;
     const float bg0 = a.background[0], bg1 = a.C > 1 ? a.background[1] : 0.0f, bg2 = a.C > 2 ? a.background[2] : 0.0f;
     float *cst = cst_all[wave] + ROW;
-    signed char *list = list_all[wave];
+    uint32_t *list = list_all[wave];
     write_dummy_row3(cst, lane);
     const RowSel rsel(lane);
 
@@ -226,87 +239,78 @@ __global__ void __launch_bounds__(256) render3d_fwd_group_kernel(RenderArgs a, f
         for (int g = 0; g < 4; g++) M[g] = ((alive >> (16 * g)) & 0xFFFFull) ? ballot(valid && c.ov[g] && r3.x * 255.0f >= 1.0f) : 0ull;
         const unsigned long long any = M[0] | M[1] | M[2] | M[3];
         if (any == 0) continue;
-        if ((any >> lane) & 1) publish_row3(cst + lane * ROW, v1, v2, v3, n, c, r3, 0.0f);
-        ((uint32_t *)list)[lane] = 0xFFFFFFFFu;
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            if ((M[g] >> lane) & 1) list[g * 64 + lane_rank(M[g])] = (signed char)lane;
-        const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
-        const signed char *mylist = list + grp * 64;
-        for (int t0 = 0; t0 < steps; t0 += 8)
+        // compacted table rows, at most NR per pass (render_group.hip)
+        const bool anybit = (any >> lane) & 1;
+        const int rank = lane_rank(any), nact = __popcll(any);
+        const int r = rank & (NR - 1);
+        bool mine = anybit && rank < NR;
+        if (mine) publish_row3(cst + r * ROW, v1, v2, v3, n, c, r3, 0.0f);
+        for (int h = 0;;)
         {
-            float cw[8];
-            uint32_t cjc[8];
-            const uint2 packed = *(const uint2 *)(mylist + t0);
+            const unsigned long long mm = nact <= NR ? any : ballot(mine);
+            list[lane] = 0xFFFFFFFFu;
+            int steps = 0;
 #pragma unroll
-            for (int st = 0; st < 8; st++)
+            for (int g = 0; g < 4; g++)
             {
-                cw[st] = 0.0f;
-                cjc[st] = 0u;
-                if (t0 + st < steps)
+                const unsigned long long Mh = M[g] & mm;
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + lane_rank(Mh)] = (unsigned short)(r | (lane << 8));
+                steps = max(steps, __popcll(Mh));
+            }
+            const uint32_t *mylist = list + grp * (NR / 2);
+            for (int t0 = 0; t0 < steps; t0 += 8)
+            {
+                float cw[8];
+                uint32_t cjc[8];
+                const uint4 packed = *(const uint4 *)(mylist + (t0 >> 1));
+#pragma unroll
+                for (int st = 0; st < 8; st++)
                 {
-                    const int jc = (int)(signed char)(((st < 4 ? packed.x : packed.y) >> (8 * (st & 3))) & 0xFFu);
-                    const float *row = cst + jc * ROW;
-                    const Hit3 h = hit3<false>(row, ray);
-                    const float pw = GAMMA1 ? h.ecc * h.ecc : pow_nonneg(h.ecc, g2);
-                    const float alpha = fminf(0.99f, h.op * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:259-260
-                    const bool hit = !done && h.ok && ecc_in_range(h.ecc) && alpha >= 1.0f / 255.0f;            // forward.cu:241,256,261
-                    const float al = hit ? alpha : 0.0f;
-                    const float contrib = al * T;
-                    ar = fmaf(h.r, contrib, ar);
-                    ag = fmaf(row[16], contrib, ag);
-                    ab = fmaf(row[17], contrib, ab);
-                    if (RICH)
+                    cw[st] = 0.0f;
+                    cjc[st] = 0u;
+                    if (t0 + st < steps)
                     {
-                        anx = fmaf(h.n.x, contrib, anx); // forward.cu:276 (unnormalised normal)
-                        any_ = fmaf(h.n.y, contrib, any_);
-                        anz = fmaf(h.n.z, contrib, anz);
-                        ad = fmaf(h.depth, contrib, ad); // forward.cu:277
-                        cw[st] = contrib;
-                        cjc[st] = (uint32_t)jc;
+                        const uint32_t word = st < 2 ? packed.x : (st < 4 ? packed.y : (st < 6 ? packed.z : packed.w));
+                        const uint32_t e16 = (word >> (16 * (st & 1))) & 0xFFFFu;
+                        const int jc = (int)(signed char)(e16 & 0xFFu), jpos = (int)(e16 >> 8); // table row, position in the batch
+                        const float *row = cst + jc * ROW;
+                        const Hit3 h = hit3<false>(row, ray);
+                        const float pw = GAMMA1 ? h.ecc * h.ecc : pow_nonneg(h.ecc, g2);
+                        const float alpha = fminf(0.99f, h.op * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:259-260
+                        const bool hit = !done && h.ok && ecc_in_range(h.ecc) && alpha >= 1.0f / 255.0f;            // forward.cu:241,256,261
+                        const float al = hit ? alpha : 0.0f;
+                        const float contrib = al * T;
+                        ar = fmaf(h.r, contrib, ar);
+                        ag = fmaf(row[16], contrib, ag);
+                        ab = fmaf(row[17], contrib, ab);
+                        if (RICH)
+                        {
+                            anx = fmaf(h.n.x, contrib, anx); // forward.cu:276 (unnormalised normal)
+                            any_ = fmaf(h.n.y, contrib, any_);
+                            anz = fmaf(h.n.z, contrib, anz);
+                            ad = fmaf(h.depth, contrib, ad); // forward.cu:277
+                            cw[st] = contrib;
+                            cjc[st] = (uint32_t)jpos;
+                        }
+                        T *= (1.0f - al);
+                        const bool sat = hit && T <= 0.0001f; // forward.cu:280
+                        last = sat ? (uint32_t)(base + jpos + 1) : last;
+                        done = done || sat;
                     }
-                    T *= (1.0f - al);
-                    const bool sat = hit && T <= 0.0001f; // forward.cu:280
-                    last = sat ? (uint32_t)(base + jc + 1) : last;
-                    done = done || sat;
+                }
+                if (RICH)
+                {
+                    // contrib_sum / contrib_max (forward.cu:271-273): reduced per 16-lane group, added to the tile's statistics in LDS
+                    // with integer atomics (ts2d_group.h)
+                    const float sm = row_reduce8(cw, rsel, OpAdd());
+                    const float mx = row_reduce8(cw, rsel, OpMax());
+                    const int k = base + (int)row_select8(cjc, rsel);
+                    if ((lane & 1) == 0 && sm > 0.0f) tile_stats_add<TCAP>(tsum, tmax, k, sm, mx, point_list + range.x, contrib_sum, contrib_max);
                 }
             }
-            if (RICH)
-            {
-                // contrib_sum / contrib_max (forward.cu:271-273): reduced per 16-lane group and folded into the entry's row, one
-                // group after the other (two groups may hold the same entry) -- see render_group.hip
-                const float sm = row_reduce8(cw, rsel, OpAdd());
-                const float mx = row_reduce8(cw, rsel, OpMax());
-                const int ejc = (int)row_select8(cjc, rsel);
-                float *acc = cst + ejc * ROW + 18;
-                const bool writer = (lane & 1) == 0 && sm > 0.0f;
-#pragma unroll
-                for (int g = 0; g < 4; g++)
-                {
-                    if (writer && grp == g)
-                    {
-                        float2 o = *(float2 *)acc;
-                        o.x += sm;
-                        o.y = __int_as_float(max(__float_as_int(o.y), __float_as_int(mx))); // both >= 0: int order == float order
-                        *(float2 *)acc = o;
-                    }
-                    wave_lds_order();
-                }
-            }
-        }
-        if (RICH && ((any >> lane) & 1))
-        {
-            const float2 o = *(const float2 *)(cst + lane * ROW + 18);
-            if (o.x > 0.0f && base + lane < TCAP)
-            {
-                atomicAdd(&tsum[base + lane], o.x); // LDS; the four waves of the tile meet here
-                atomicMax(&tmax[base + lane], __float_as_int(o.y));
-            }
-            else if (o.x > 0.0f)
-            {
-                unsafeAtomicAdd(contrib_sum + id, o.x);
-                if (o.y > contrib_max[id]) atomicMax((int *)contrib_max + id, __float_as_int(o.y));
-            }
+            if (++h * NR >= nact) break;
+            mine = anybit && rank >= NR;
+            if (mine) republish_row3(cst + r * ROW, point_list, rec, range.x + base + lane, false);
         }
     }
     if (RICH)
@@ -314,14 +318,8 @@ __global__ void __launch_bounds__(256) render3d_fwd_group_kernel(RenderArgs a, f
         __syncthreads();
         for (int k = threadIdx.x; k < min(len, TCAP); k += 256)
         {
-            const float sm = tsum[k];
-            if (sm > 0.0f)
-            {
-                const uint32_t tid = point_list[range.x + k];
-                const float mx = __int_as_float(tmax[k]);
-                unsafeAtomicAdd(contrib_sum + tid, sm);
-                if (mx > contrib_max[tid]) atomicMax((int *)contrib_max + tid, __float_as_int(mx));
-            }
+            const unsigned long long fx48 = tsum[k];
+            if (fx48 != 0ull) tile_stats_flush(fx48, tmax[k], point_list[range.x + k], contrib_sum, contrib_max);
         }
     }
     if (inside)
@@ -351,16 +349,16 @@ __global__ void __launch_bounds__(256) render3d_fwd_group_kernel(RenderArgs a, f
 //   dL_ddepth = dL_ddepth_pixel contrib + w1 da1_ddepth + w2 da2_ddepth, da1_ddepth = n.cross(v3 - v2, p_ray) / n.n, ...   (:389, 395, 401)
 //   dL/dn  = dL_dnormal_pixel contrib + (w1 (c1 - 2 a1 n) + w2 (c2 - 2 a2 n)) / n.n + dL_ddepth p_v1 / (p_ray.n)   (:388, 394, 403, 406)
 template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256, 4) render3d_bwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
+__global__ void __launch_bounds__(256, 6) render3d_bwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
                                                                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                      const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                                      const float *__restrict__ dL_dout_feature,
                                                                      const float *__restrict__ dL_dout_depth,
                                                                      const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
-    __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
-    __shared__ __attribute__((aligned(16))) float sums_all[4][65 * 16];
-    __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+    __shared__ __attribute__((aligned(16))) float cst_all[4][(NR + 1) * ROW];
+    __shared__ __attribute__((aligned(16))) float sums_all[4][(NR + 1) * 16];
+    __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2];
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -378,7 +376,7 @@ __global__ void __launch_bounds__(256, 4) render3d_bwd_group_kernel(RenderArgs a
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
     float *cst = cst_all[wave] + ROW;
     float *sums = sums_all[wave] + 16;
-    signed char *list = list_all[wave];
+    uint32_t *list = list_all[wave];
     write_dummy_row3(cst, lane);
 
     float T = inside ? final_T[pix] : 0.0f;
@@ -433,97 +431,115 @@ __global__ void __launch_bounds__(256, 4) render3d_bwd_group_kernel(RenderArgs a
         }
         const unsigned long long any = M[0] | M[1] | M[2] | M[3];
         if (any == 0) continue;
-        if ((any >> lane) & 1)
-        {
-            publish_row3(cst + lane * ROW, v1, v2, v3, n, c, r3, __uint_as_float(id));
-            float4 *z = (float4 *)(sums + lane * 16);
-            z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
-        }
-        ((uint32_t *)list)[lane] = 0xFFFFFFFFu;
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-            if ((M[g] >> lane) & 1) list[g * 64 + (__popcll(M[g]) - 1 - lane_rank(M[g]))] = (signed char)lane;
-        const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
-        const signed char *mylist = list + grp * 64;
-        unsigned long long conflict;
-        {
-            const int l0 = list[lane], l1 = list[64 + lane], l2 = list[128 + lane], l3 = list[192 + lane];
-            conflict = ballot((l0 >= 0 && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 >= 0 && (l1 == l2 || l1 == l3)) || (l2 >= 0 && l2 == l3));
-        }
+        const bool anybit = (any >> lane) & 1;
+        const int rank = lane_rank(any), nact = __popcll(any);
         const int lrel = last - base;
-        for (int t0 = 0; t0 < steps; t0++)
+        const int r = rank & (NR - 1);
+        bool mine = anybit && (rank / NR) == (nact - 1) / NR;
+        if (mine) publish_row3(cst + r * ROW, v1, v2, v3, n, c, r3, __uint_as_float(id));
+        for (int h = (nact - 1) / NR;;)
         {
-            const int jc = mylist[t0];
-            const float *row = cst + jc * ROW;
-            float *acc = sums + jc * 16 + sub;
-            const bool shared_row = (conflict >> t0) & 1;
-            const float acc0 = *acc;
-            const Hit3 h = hit3<true>(row, ray);
-            const float cg = row[16], cb = row[17];
-            const float pw = GAMMA1 ? h.ecc * h.ecc : pow_nonneg(h.ecc, g2);
-            const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f);
-            const float opG = h.op * G;
-            const float alpha = fminf(0.99f, opG);
-            const bool hit = (jc < lrel) && h.ok && ecc_in_range(h.ecc) && G >= 1.0f / 255.0f; // backward.cu:322-323,328,343,351
-            const float al = hit ? alpha : 0.0f;
-            const float oma = 1.0f - al;
-            T = T * __builtin_amdgcn_rcpf(oma); // :354
-            const float contrib = al * T;
-            float X = fmaf(dpb, cb, fmaf(dpg, cg, dpr * h.r)); // :368
-            if (RICH) // :374-380
+            const unsigned long long mm = nact <= NR ? any : ballot(mine);
+            if (mine)
             {
-                X = fmaf(dnz, h.n.z, fmaf(dny, h.n.y, fmaf(dnx, h.n.x, X)));
-                X = fmaf(dd, h.depth, X);
+                float4 *z = (float4 *)(sums + r * 16);
+                z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
             }
-            const float dL_dcontrib = X - B;
-            B = fmaf(al, X, oma * B);
-            const float dL_dalpha = dL_dcontrib * T; // :383
-            const float zr = 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(h.ecc + 1e-8f); // -3 dL_decc, :384-385
-            const float z = (hit && opG < 0.99f) ? zr : 0.0f;
-            const bool k1 = h.a1 == h.mn;
-            const bool k2 = !k1 && h.a2 == h.mn;
-            const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = z - z1 - z2;
-            const float w1 = (z1 - z3) * h.inn, w2 = (z2 - z3) * h.inn; // 1 / n.n folded in
-            const V3 A1 = vcross(h.p3, h.n), A2 = vcross(h.n, h.p2), A3 = vcross(h.p1, h.n);
-            const float da1_dd = vdot(h.n, vcross(h.e32, ray)), da2_dd = vdot(h.n, vcross(h.e13, ray)); // :389, 395
-            const float dLdd = fmaf(w2, da2_dd, fmaf(w1, da1_dd, RICH ? dd * contrib : 0.0f)) * h.inv_prn; // dL_ddepth / (p_ray.n)
-            float v[16];
-            v[bitrev4(0)] = fmaf(dLdd, h.n.x, -w2 * A1.x); // dL/dv1 = w2 cross(n, p_v3) + dL_ddepth n / prn; cross(n, p_v3) = -A1
-            v[bitrev4(1)] = fmaf(dLdd, h.n.y, -w2 * A1.y);
-            v[bitrev4(2)] = fmaf(dLdd, h.n.z, -w2 * A1.z);
-            v[bitrev4(3)] = w1 * A1.x; v[bitrev4(4)] = w1 * A1.y; v[bitrev4(5)] = w1 * A1.z;
-            v[bitrev4(6)] = fmaf(w2, A3.x, w1 * A2.x); v[bitrev4(7)] = fmaf(w2, A3.y, w1 * A2.y); v[bitrev4(8)] = fmaf(w2, A3.z, w1 * A2.z);
-            const float s12 = -2.0f * (w1 * h.a1 + w2 * h.a2);
-            v[bitrev4(9)] = fmaf(dLdd, h.p1.x, fmaf(s12, h.n.x, fmaf(w2, h.c2.x, fmaf(w1, h.c1.x, RICH ? dnx * contrib : 0.0f))));
-            v[bitrev4(10)] = fmaf(dLdd, h.p1.y, fmaf(s12, h.n.y, fmaf(w2, h.c2.y, fmaf(w1, h.c1.y, RICH ? dny * contrib : 0.0f))));
-            v[bitrev4(11)] = fmaf(dLdd, h.p1.z, fmaf(s12, h.n.z, fmaf(w2, h.c2.z, fmaf(w1, h.c1.z, RICH ? dnz * contrib : 0.0f))));
-            v[bitrev4(12)] = hit ? dL_dalpha * G : 0.0f; // :447
-            v[bitrev4(13)] = dpr * contrib; v[bitrev4(14)] = dpg * contrib; v[bitrev4(15)] = dpb * contrib; // :365
-            const float red = row_reduce16(v, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull);
-            if (!shared_row) *acc = acc0 + red;
-            else
-            {
+            list[lane] = 0xFFFFFFFFu;
+            int steps = 0;
 #pragma unroll
-                for (int g = 0; g < 4; g++)
-                {
-                    if (grp == g) *acc += red;
-                    wave_lds_order();
-                }
-            }
-        }
-        {
-            if ((any >> lane) & 1) list[lane_rank(any)] = (signed char)lane;
-            const int nn = __popcll(any);
-#pragma unroll 1
-            for (int e0 = 0; e0 < nn; e0 += 4)
+            for (int g = 0; g < 4; g++)
             {
-                if (e0 + grp < nn)
+                const unsigned long long Mh = M[g] & mm;
+                const int nn = __popcll(Mh);
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (nn - 1 - lane_rank(Mh))] = (unsigned short)(r | (lane << 8));
+                steps = max(steps, nn);
+            }
+            const u16a *mylist = (const u16a *)list + grp * NR;
+            unsigned long long conflict;
+            {
+                const u16a *l16 = (const u16a *)list + (lane & (NR - 1));
+                const int l0 = l16[0] & 0xFF, l1 = l16[NR] & 0xFF, l2 = l16[2 * NR] & 0xFF, l3 = l16[3 * NR] & 0xFF;
+                conflict = ballot(lane < NR && ((l0 != 0xFF && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != 0xFF && (l1 == l2 || l1 == l3)) ||
+                                                (l2 != 0xFF && l2 == l3)));
+            }
+            for (int t0 = 0; t0 < steps; t0++)
+            {
+                const uint32_t e16 = mylist[t0];
+                const int jc = (int)(signed char)(e16 & 0xFFu), jpos = (int)(e16 >> 8);
+                const float *row = cst + jc * ROW;
+                float *acc = sums + jc * 16 + sub;
+                const bool shared_row = (conflict >> t0) & 1;
+                const float acc0 = *acc;
+                const Hit3 h = hit3<true>(row, ray);
+                const float cg = row[16], cb = row[17];
+                const float pw = GAMMA1 ? h.ecc * h.ecc : pow_nonneg(h.ecc, g2);
+                const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f);
+                const float opG = h.op * G;
+                const float alpha = fminf(0.99f, opG);
+                const bool hit = (jpos < lrel) && h.ok && ecc_in_range(h.ecc) && G >= 1.0f / 255.0f; // backward.cu:322-323,328,343,351
+                const float al = hit ? alpha : 0.0f;
+                const float oma = 1.0f - al;
+                T = T * __builtin_amdgcn_rcpf(oma); // :354
+                const float contrib = al * T;
+                float X = fmaf(dpb, cb, fmaf(dpg, cg, dpr * h.r)); // :368
+                if (RICH) // :374-380
                 {
-                    const int e = list[e0 + grp];
-                    const uint32_t eid = __float_as_uint(cst[e * ROW + 18]);
-                    unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, sums[e * 16 + sub]);
+                    X = fmaf(dnz, h.n.z, fmaf(dny, h.n.y, fmaf(dnx, h.n.x, X)));
+                    X = fmaf(dd, h.depth, X);
+                }
+                const float dL_dcontrib = X - B;
+                B = fmaf(al, X, oma * B);
+                const float dL_dalpha = dL_dcontrib * T; // :383
+                const float zr = 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(h.ecc + 1e-8f); // -3 dL_decc, :384-385
+                const float z = (hit && opG < 0.99f) ? zr : 0.0f;
+                const bool k1 = h.a1 == h.mn;
+                const bool k2 = !k1 && h.a2 == h.mn;
+                const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = z - z1 - z2;
+                const float w1 = (z1 - z3) * h.inn, w2 = (z2 - z3) * h.inn; // 1 / n.n folded in
+                const V3 A1 = vcross(h.p3, h.n), A2 = vcross(h.n, h.p2), A3 = vcross(h.p1, h.n);
+                const float da1_dd = vdot(h.n, vcross(h.e32, ray)), da2_dd = vdot(h.n, vcross(h.e13, ray)); // :389, 395
+                const float dLdd = fmaf(w2, da2_dd, fmaf(w1, da1_dd, RICH ? dd * contrib : 0.0f)) * h.inv_prn; // dL_ddepth / (p_ray.n)
+                float v[16];
+                v[bitrev4(0)] = fmaf(dLdd, h.n.x, -w2 * A1.x); // dL/dv1 = w2 cross(n, p_v3) + dL_ddepth n / prn; cross(n, p_v3) = -A1
+                v[bitrev4(1)] = fmaf(dLdd, h.n.y, -w2 * A1.y);
+                v[bitrev4(2)] = fmaf(dLdd, h.n.z, -w2 * A1.z);
+                v[bitrev4(3)] = w1 * A1.x; v[bitrev4(4)] = w1 * A1.y; v[bitrev4(5)] = w1 * A1.z;
+                v[bitrev4(6)] = fmaf(w2, A3.x, w1 * A2.x); v[bitrev4(7)] = fmaf(w2, A3.y, w1 * A2.y); v[bitrev4(8)] = fmaf(w2, A3.z, w1 * A2.z);
+                const float s12 = -2.0f * (w1 * h.a1 + w2 * h.a2);
+                v[bitrev4(9)] = fmaf(dLdd, h.p1.x, fmaf(s12, h.n.x, fmaf(w2, h.c2.x, fmaf(w1, h.c1.x, RICH ? dnx * contrib : 0.0f))));
+                v[bitrev4(10)] = fmaf(dLdd, h.p1.y, fmaf(s12, h.n.y, fmaf(w2, h.c2.y, fmaf(w1, h.c1.y, RICH ? dny * contrib : 0.0f))));
+                v[bitrev4(11)] = fmaf(dLdd, h.p1.z, fmaf(s12, h.n.z, fmaf(w2, h.c2.z, fmaf(w1, h.c1.z, RICH ? dnz * contrib : 0.0f))));
+                v[bitrev4(12)] = hit ? dL_dalpha * G : 0.0f; // :447
+                v[bitrev4(13)] = dpr * contrib; v[bitrev4(14)] = dpg * contrib; v[bitrev4(15)] = dpb * contrib; // :365
+                const float red = row_reduce16(v, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull);
+                if (!shared_row) *acc = acc0 + red;
+                else
+                {
+#pragma unroll
+                    for (int g = 0; g < 4; g++)
+                    {
+                        if (grp == g) *acc += red;
+                        wave_lds_order();
+                    }
                 }
             }
+            {
+                const int nn = __popcll(mm);
+#pragma unroll 1
+                for (int e0 = 0; e0 < nn; e0 += 4)
+                {
+                    const int e = e0 + grp;
+                    if (e < nn)
+                    {
+                        const uint32_t eid = __float_as_uint(cst[e * ROW + 18]);
+                        unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, sums[e * 16 + sub]);
+                    }
+                }
+            }
+            if (--h < 0) break;
+            mine = anybit && rank < NR;
+            if (mine) republish_row3(cst + r * ROW, point_list, rec, range.x + base + lane, true);
         }
     }
 }

@@ -39,7 +39,6 @@ namespace
 {
 // ROW (ts2d_group.h) = 20 floats per entry row of the constants table:
 //   [0..3] u1x u1y u2x u2y   [4..7] u3x u3y 1/area2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [17] id
-//   [18] [19] forward: the wave's running contrib_sum / contrib_max of the entry
 // (u_k = screen vertex k relative to the quadrant origin); row -1 is a dummy that fails every pixel's ecc test.
 
 struct BlockCull
@@ -47,6 +46,40 @@ struct BlockCull
     float u1x, u1y, u2x, u2y, u3x, u3y, ia;
     bool ov[4]; // the triangle's support (alpha >= 1/255 and ecc <= 10) can reach block g = (by >> 2) * 2 + (bx >> 2)
 };
+
+__device__ __forceinline__ void publish_row(float *row, const BlockCull &s, uint32_t id, const float4 &r1, const float4 &r2, const float4 &r3)
+{
+    float4 *q = (float4 *)row;
+    q[0] = make_float4(s.u1x, s.u1y, s.u2x, s.u2y);
+    q[1] = make_float4(s.u3x, s.u3y, s.ia, r1.z);
+    q[2] = make_float4(r1.w, r2.x, r2.y, r2.z);
+    q[3] = make_float4(r2.w, r3.x, r3.y, r3.z);
+    q[4] = make_float4(r3.w, __uint_as_float(id), 0.0f, 0.0f);
+}
+
+// The part of the setup that ends up in the entry's table row: vertices relative to the quadrant origin, 1 / area2.
+__device__ __forceinline__ void entry_geometry(BlockCull &s, float v1x, float v1y, float v2x, float v2y, float v3x, float v3y, float OX, float OY)
+{
+    // area2 exactly as preprocess evaluates (and the reference stores) it: cross(v2 - v1, v3 - v1) without contraction
+    const float area2 = __fsub_rn(__fmul_rn(v2x - v1x, v3y - v1y), __fmul_rn(v2y - v1y, v3x - v1x)); // forward.cu:137
+    s.ia = __builtin_amdgcn_rcpf(area2); // the reference divides by area2 per pixel; a 1-ulp reciprocal moves a_k by <= 2 ulp
+    s.u1x = v1x - OX; s.u1y = v1y - OY; s.u2x = v2x - OX; s.u2y = v2y - OY; s.u3x = v3x - OX; s.u3y = v3y - OY;
+}
+
+// Second pass of a batch with more than NR surviving entries (rare): the lane gathers its entry's record again -- keeping the
+// first gather's registers alive across the first pass would cost the occupancy the compaction buys.
+template <bool RICH>
+__device__ __forceinline__ uint32_t republish_row(float *row, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, uint32_t pos,
+                                                  float OX, float OY)
+{
+    const uint32_t id = point_list[pos];
+    const float4 *rp = rec + 4 * (size_t)id;
+    const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = RICH ? rp[3] : make_float4(0, 0, 0, 0);
+    BlockCull s;
+    entry_geometry(s, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, OX, OY);
+    publish_row(row, s, id, r1, r2, r3);
+    return id;
+}
 
 // Conservative culling of one triangle against the four 4x4 sample blocks of the quadrant whose origin is (OX, OY).
 // The affine forms a_k(q) = A_k qx + B_k qy + C_k are used ONLY here; their rounding error (up to ~(|C| + 7|A| + 7|B|) ulp
@@ -56,10 +89,7 @@ __device__ __forceinline__ BlockCull block_cull(float v1x, float v1y, float v2x,
                                                 float OX, float OY)
 {
     BlockCull s;
-    // area2 exactly as preprocess evaluates (and the reference stores) it: cross(v2 - v1, v3 - v1) without contraction
-    const float area2 = __fsub_rn(__fmul_rn(v2x - v1x, v3y - v1y), __fmul_rn(v2y - v1y, v3x - v1x)); // forward.cu:137
-    s.ia = __builtin_amdgcn_rcpf(area2); // the reference divides by area2 per pixel; a 1-ulp reciprocal moves a_k by <= 2 ulp
-    s.u1x = v1x - OX; s.u1y = v1y - OY; s.u2x = v2x - OX; s.u2y = v2y - OY; s.u3x = v3x - OX; s.u3y = v3y - OY;
+    entry_geometry(s, v1x, v1y, v2x, v2y, v3x, v3y, OX, OY);
     const float C1 = (s.u2x * s.u3y - s.u2y * s.u3x) * s.ia, A1 = (v2y - v3y) * s.ia, B1 = (v3x - v2x) * s.ia;
     const float C2 = (s.u3x * s.u1y - s.u3y * s.u1x) * s.ia, A2 = (v3y - v1y) * s.ia, B2 = (v1x - v3x) * s.ia;
     const float A3 = -A1 - A2, B3 = -B1 - B2, C3 = 1.0f - C1 - C2;
@@ -96,16 +126,6 @@ __device__ __forceinline__ BlockCull block_cull(float v1x, float v1y, float v2x,
     return s;
 }
 
-__device__ __forceinline__ void publish_row(float *row, const BlockCull &s, uint32_t id, const float4 &r1, const float4 &r2, const float4 &r3)
-{
-    float4 *q = (float4 *)row;
-    q[0] = make_float4(s.u1x, s.u1y, s.u2x, s.u2y);
-    q[1] = make_float4(s.u3x, s.u3y, s.ia, r1.z);
-    q[2] = make_float4(r1.w, r2.x, r2.y, r2.z);
-    q[3] = make_float4(r2.w, r3.x, r3.y, r3.z);
-    q[4] = make_float4(r3.w, __uint_as_float(id), 0.0f, 0.0f); // [18] [19]: this wave's contrib_sum / contrib_max of the entry
-}
-
 // Row -1: a unit triangle a thousand pixels away with opacity 0 -> every pixel of the quadrant sees ecc ~ 3000 and alpha 0.
 __device__ __forceinline__ void write_dummy_row(float *cst, int lane)
 {
@@ -138,27 +158,31 @@ __device__ __forceinline__ Bary barycentrics(const float4 &q0, const float4 &q1,
 // Profiling builds only (-DTS2D_STATS), read with ts2d_stats_read_group():
 // [0] list entries visited (per quadrant wave)  [1] (entry, block) pairs surviving the cull  [2] wave steps  [3] windows
 // [4] (pixel, entry) pairs blended  [5] quadrant waves  [6] batches with work  [7] (entry, quadrant) pairs surviving
-__device__ unsigned long long g_stats_group[8];
+__device__ unsigned long long g_stats_group[12];
 #define TSG_STAT(i, v) stat_acc[i] += (unsigned long long)(v)
 #else
 #define TSG_STAT(i, v)
 #endif
 
 template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+__global__ void __launch_bounds__(256, 6) render_fwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                                 const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                 float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                                 float *__restrict__ out_feature, float *__restrict__ out_depth,
                                                                 float *__restrict__ out_normal, float *__restrict__ contrib_sum,
                                                                 float *__restrict__ contrib_max)
 {
-    __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
-    __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+    __shared__ __attribute__((aligned(16))) float cst_all[4][(NR + 1) * ROW];
+    __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2]; // per group: NR entries of (row | batch position << 8)
     // contrib_sum / contrib_max of the tile's first TCAP list entries, merged over the four quadrant waves before they leave
     // as global atomics (one L2 line operation per (tile, triangle) instead of one per (quadrant, triangle))
     constexpr int TCAP = 1024;
-    __shared__ float tsum[RICH ? TCAP : 1];
+    __shared__ unsigned long long tsum[RICH ? TCAP : 1]; // 16.48 fixed point
     __shared__ int tmax[RICH ? TCAP : 1];
+#ifdef TSG_PAD_LDS // occupancy experiment: extra LDS bytes per workgroup
+    __shared__ int pad_lds[TSG_PAD_LDS / 4];
+    if (a.W < 0) pad_lds[threadIdx.x] = 1, atomicAdd(&tmax[0], pad_lds[255 - threadIdx.x]);
+#endif
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -173,13 +197,13 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
     const int len = (int)(range.y - range.x);
     if (RICH)
     {
-        for (int k = threadIdx.x; k < min(len, TCAP); k += 256) { tsum[k] = 0.0f; tmax[k] = 0; }
+        for (int k = threadIdx.x; k < min(len, TCAP); k += 256) { tsum[k] = 0ull; tmax[k] = 0; }
         __syncthreads();
     }
     const float g2 = 2.0f * a.gamma;
     const float bg0 = a.background[0], bg1 = a.C > 1 ? a.background[1] : 0.0f, bg2 = a.C > 2 ? a.background[2] : 0.0f;
     float *cst = cst_all[wave] + ROW;
-    signed char *list = list_all[wave];
+    uint32_t *list = list_all[wave];
     write_dummy_row(cst, lane);
     const RowSel rsel(lane);
     const int my_slot = (lane >> 3 & 1) + ((lane >> 2 & 1) << 1) + ((lane >> 1 & 1) << 2); // which of a window's 8 steps this lane reports
@@ -189,7 +213,7 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
     uint32_t last = (uint32_t)len; // a pixel that never saturates examines the whole list (forward.cu:296-297)
 
 #ifdef TS2D_STATS
-    unsigned long long stat_acc[8] = {0, 0, 0, 0, 0, 1, 0, 0};
+    unsigned long long stat_acc[12] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
 #endif
     for (int base = 0; base < len; base += 64)
     {
@@ -217,135 +241,124 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
         TSG_STAT(1, __popcll(M[0]) + __popcll(M[1]) + __popcll(M[2]) + __popcll(M[3]));
         TSG_STAT(6, 1);
         TSG_STAT(7, __popcll(any));
-        if ((any >> lane) & 1) publish_row(cst + lane * ROW, s, id, r1, r2, r3);
-        ((uint32_t *)list)[lane] = 0xFFFFFFFFu; // four lists x 64 entries of -1
+        // The entries with work are COMPACTED into at most NR table rows per pass (a batch with more survivors takes two passes):
+        // half the LDS of a row per list entry, hence 7 instead of 5 resident waves per SIMD -- the blend kernels are latency
+        // bound (3 instead of 5 waves: +27 %, profiles/r02_notes.md).
+        const bool anybit = (any >> lane) & 1;
+        const int rank = lane_rank(any), nact = __popcll(any);
+        const int r = rank & (NR - 1);
+        bool mine = anybit && rank < NR;
+        if (mine) publish_row(cst + r * ROW, s, id, r1, r2, r3);
+        for (int h = 0;;)
+        {
+            const unsigned long long mm = nact <= NR ? any : ballot(mine);
+            list[lane] = 0xFFFFFFFFu; // four lists x NR entries of (row -1, position 255)
+            int steps = 0;
 #pragma unroll
-        for (int g = 0; g < 4; g++)
-            if ((M[g] >> lane) & 1) list[g * 64 + lane_rank(M[g])] = (signed char)lane;
-        const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
-        const signed char *mylist = list + grp * 64;
-        TSG_STAT(2, steps);
-        TSG_STAT(3, (steps + 7) / 8);
+            for (int g = 0; g < 4; g++)
+            {
+                const unsigned long long Mh = M[g] & mm;
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + lane_rank(Mh)] = (unsigned short)(r | (lane << 8));
+                steps = max(steps, __popcll(Mh));
+            }
+            const uint32_t *mylist = list + grp * (NR / 2);
+            TSG_STAT(2, steps);
+            TSG_STAT(3, (steps + 7) / 8);
+#ifdef TS2D_STATS
+            {   // [8] steps at which two groups hold the same entry (what the backward must serialise)  [9] passes  [10] second passes
+                const u16a *l16 = (const u16a *)list + (lane & (NR - 1));
+                const int l0 = l16[0] & 0xFF, l1 = l16[NR] & 0xFF, l2 = l16[2 * NR] & 0xFF, l3 = l16[3 * NR] & 0xFF;
+                TSG_STAT(8, __popcll(ballot(lane < NR && ((l0 != 0xFF && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != 0xFF && (l1 == l2 || l1 == l3)) ||
+                                                          (l2 != 0xFF && l2 == l3)))));
+                TSG_STAT(9, 1);
+                TSG_STAT(10, h > 0 ? 1 : 0);
+            }
+#endif
 
-        for (int t0 = 0; t0 < steps; t0 += 8)
-        {
-            float c[8];
-            uint32_t cjc[8];
-            const uint2 packed = *(const uint2 *)(mylist + t0); // this group's next 8 entry indices
-#pragma unroll
-            for (int st = 0; st < 8; st++)
+            for (int t0 = 0; t0 < steps; t0 += 8)
             {
-                c[st] = 0.0f;
-                cjc[st] = 0u;
-                if (t0 + st < steps)
+                float c[8];
+                uint32_t cjc[8];
+                const uint4 packed = *(const uint4 *)(mylist + (t0 >> 1)); // this group's next 8 entries
+#pragma unroll
+                for (int st = 0; st < 8; st++)
                 {
-                    const int jc = (int)(signed char)(((st < 4 ? packed.x : packed.y) >> (8 * (st & 3))) & 0xFFu);
-                    const float *row = cst + jc * ROW;
-                    const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
-                    const Bary b = barycentrics(q0, q1, fx, fy);
-                    const float4 q2 = *(const float4 *)(row + 8);
-                    float4 q3 = make_float4(0, 0, 0, 0);
-                    float vd3 = 0.0f;
-                    if (RICH)
+                    c[st] = 0.0f;
+                    cjc[st] = 0u;
+                    if (t0 + st < steps)
                     {
-                        q3 = *(const float4 *)(row + 12);
-                        vd3 = row[16];
-                        cjc[st] = (uint32_t)jc;
+                        const uint32_t word = st < 2 ? packed.x : (st < 4 ? packed.y : (st < 6 ? packed.z : packed.w));
+                        const uint32_t e16 = (word >> (16 * (st & 1))) & 0xFFFFu;
+                        const int jc = (int)(signed char)(e16 & 0xFFu), jpos = (int)(e16 >> 8); // table row, position in the batch
+                        const float *row = cst + jc * ROW;
+                        const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
+                        const Bary b = barycentrics(q0, q1, fx, fy);
+                        const float4 q2 = *(const float4 *)(row + 8);
+                        float4 q3 = make_float4(0, 0, 0, 0);
+                        float vd3 = 0.0f;
+                        if (RICH)
+                        {
+                            q3 = *(const float4 *)(row + 12);
+                            vd3 = row[16];
+                            cjc[st] = (uint32_t)jpos;
+                        }
+                        const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
+                        const float alpha = fminf(0.99f, q1.w * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:311-312
+                        const bool hit = !done && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f;                     // forward.cu:307,313
+                        // branch-free blend: a lane that does not hit runs with alpha = 0 (x + c*0 == x, T*1 == T bit for bit)
+                        const float al = hit ? alpha : 0.0f;
+                        TSG_STAT(4, __popcll(ballot(hit)));
+                        const float contrib = al * T;
+                        ar = fmaf(q2.x, contrib, ar);
+                        ag = fmaf(q2.y, contrib, ag);
+                        ab = fmaf(q2.z, contrib, ab);
+                        if (RICH)
+                        {
+                            anx = fmaf(q2.w, contrib, anx);
+                            any_ = fmaf(q3.x, contrib, any_);
+                            anz = fmaf(q3.y, contrib, anz);
+                            const float d = q3.z * b.a1 + q3.w * b.a2 + vd3 * b.a3; // forward.cu:328
+                            ad = fmaf(d, contrib, ad);
+                            c[st] = contrib;
+                        }
+                        T *= (1.0f - al);
+                        const bool sat = hit && T <= 0.0001f; // forward.cu:333
+                        last = sat ? (uint32_t)(base + jpos + 1) : last;
+                        done = done || sat;
                     }
-                    const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
-                    const float alpha = fminf(0.99f, q1.w * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:311-312
-                    const bool hit = !done && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f;                     // forward.cu:307,313
-                    // branch-free blend: a lane that does not hit runs with alpha = 0 (x + c*0 == x, T*1 == T bit for bit)
-                    const float al = hit ? alpha : 0.0f;
-                    TSG_STAT(4, __popcll(ballot(hit)));
-                    const float contrib = al * T;
-                    ar = fmaf(q2.x, contrib, ar);
-                    ag = fmaf(q2.y, contrib, ag);
-                    ab = fmaf(q2.z, contrib, ab);
-                    if (RICH)
-                    {
-                        anx = fmaf(q2.w, contrib, anx);
-                        any_ = fmaf(q3.x, contrib, any_);
-                        anz = fmaf(q3.y, contrib, anz);
-                        const float d = q3.z * b.a1 + q3.w * b.a2 + vd3 * b.a3; // forward.cu:328
-                        ad = fmaf(d, contrib, ad);
-                        c[st] = contrib;
-                    }
-                    T *= (1.0f - al);
-                    const bool sat = hit && T <= 0.0001f; // forward.cu:333
-                    last = sat ? (uint32_t)(base + jc + 1) : last;
-                    done = done || sat;
                 }
-            }
 #if TSG_PROBE != 2
-            if (RICH)
-            {
-                // contrib_sum / contrib_max (forward.cu:323-324; the reference issues two global atomics per (pixel, triangle)):
-                // the window's 8 x 64 contributions are reduced inside each 16-lane group, lane pairs (l, l ^ 1) end up with
-                // (sum, max, entry) of step `b3 + 2 b2 + 4 b1` of their group, and the even lanes fold them into the entry's
-                // row of the wave's table -- one group after the other, because two groups may hold the same entry.
-                const float sm = row_reduce8(c, rsel, OpAdd());
-                const float mx = row_reduce8(c, rsel, OpMax());
-                const int ejc = (int)row_select8(cjc, rsel);
-                float *acc = cst + ejc * ROW + 18;
-                const bool writer = (lane & 1) == 0 && sm > 0.0f;
-#pragma unroll
-                for (int g = 0; g < 4; g++)
+                if (RICH)
                 {
-                    if (writer && grp == g)
-                    {
-                        float2 o = *(float2 *)acc;
-                        o.x += sm;
-                        o.y = __int_as_float(max(__float_as_int(o.y), __float_as_int(mx))); // both >= 0: int order == float order
-                        *(float2 *)acc = o;
-                    }
-                    wave_lds_order();
+                    // contrib_sum / contrib_max (forward.cu:323-324; the reference issues two global atomics per (pixel, triangle)):
+                    // the window's 8 x 64 contributions are reduced inside each 16-lane group, lane pairs (l, l ^ 1) end up with
+                    // (sum, max, batch position) of step `b3 + 2 b2 + 4 b1` of their group, and the even lanes add them to the TILE's
+                    // statistics in LDS with INTEGER atomics (ts2d_group.h: ds_add_u64 / ds_max_i32 cost 5-7 cycles per wave
+                    // instruction, ds_add_f32 193) -- no ordering between groups or waves is needed.
+                    const float sm = row_reduce8(c, rsel, OpAdd());
+                    const float mx = row_reduce8(c, rsel, OpMax());
+                    const int k = base + (int)row_select8(cjc, rsel);
+                    if ((lane & 1) == 0 && sm > 0.0f) tile_stats_add<TCAP>(tsum, tmax, k, sm, mx, point_list + range.x, contrib_sum, contrib_max);
                 }
-            }
 #endif
-        }
-#if TSG_PROBE == 0
-        if (RICH && ((any >> lane) & 1))
-        {
-            const float2 o = *(const float2 *)(cst + lane * ROW + 18);
-            if (o.x > 0.0f && base + lane < TCAP)
-            {
-                atomicAdd(&tsum[base + lane], o.x);                  // LDS; the four waves of the tile meet here
-                atomicMax(&tmax[base + lane], __float_as_int(o.y)); // both >= 0: int order == float order
             }
-            else if (o.x > 0.0f)
-            {
-                // Scattered global atomics cost one L2 line operation each (~20 G/s chip-wide, tools/atomic_scope_bench.hip): at two
-                // per (entry, quadrant) the forward was bound by them, not by its arithmetic.  A running maximum only grows, so a
-                // (possibly stale, hence smaller) plain read that already exceeds this wave's value proves the atomic redundant:
-                // ~60 % of the max operations disappear.
-                unsafeAtomicAdd(contrib_sum + id, o.x);
-                if (o.y > contrib_max[id]) atomicMax((int *)contrib_max + id, __float_as_int(o.y));
-            }
+            if (++h * NR >= nact) break;
+            mine = anybit && rank >= NR;
+            if (mine) republish_row<RICH>(cst + r * ROW, point_list, rec, range.x + base + lane, OX, OY);
         }
-#endif
     }
 
 #ifdef TS2D_STATS
     if (lane == 0)
-        for (int i = 0; i < 8; i++) atomicAdd(&g_stats_group[i], stat_acc[i]);
+        for (int i = 0; i < 12; i++) atomicAdd(&g_stats_group[i], stat_acc[i]);
 #endif
     if (RICH)
     {
         __syncthreads(); // the only rendezvous of the four quadrant waves: the tile's merged contribution statistics leave
         for (int k = threadIdx.x; k < min(len, TCAP); k += 256)
         {
-            const float sm = tsum[k];
-            if (sm > 0.0f)
-            {
-                const uint32_t tid = point_list[range.x + k];
-                const float mx = __int_as_float(tmax[k]);
-                // scattered global atomics cost one L2 line operation each (~20 G/s chip-wide, tools/atomic_scope_bench.hip): at two
-                // per (entry, quadrant) the forward was bound by them, not by its arithmetic.  A running maximum only grows, so a
-                // (possibly stale, hence smaller) plain read that already exceeds this tile's value proves the atomic redundant.
-                unsafeAtomicAdd(contrib_sum + tid, sm);
-                if (mx > contrib_max[tid]) atomicMax((int *)contrib_max + tid, __float_as_int(mx));
-            }
+            const unsigned long long fx48 = tsum[k];
+            if (fx48 != 0ull) tile_stats_flush(fx48, tmax[k], point_list[range.x + k], contrib_sum, contrib_max);
         }
     }
     if (inside)
@@ -376,16 +389,20 @@ __global__ void __launch_bounds__(256) render_fwd_group_kernel(RenderArgs a, con
 // wave-private LDS table (one group after the other: two groups may be working on the same entry); once per batch the rows
 // leave as coalesced 64-byte atomic adds, one gradient record per 16 lanes.
 template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+__global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                                    const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                                    const float *__restrict__ dL_dout_feature,
                                                                    const float *__restrict__ dL_dout_depth,
                                                                    const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
-    __shared__ __attribute__((aligned(16))) float cst_all[4][65 * ROW];
-    __shared__ __attribute__((aligned(16))) float sums_all[4][65 * 16]; // row -1 absorbs the adds of idle groups
-    __shared__ __attribute__((aligned(16))) signed char list_all[4][4 * 64];
+    __shared__ __attribute__((aligned(16))) float cst_all[4][(NR + 1) * ROW];
+    __shared__ __attribute__((aligned(16))) float sums_all[4][(NR + 1) * 16]; // row -1 absorbs the adds of idle groups
+    __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2];  // per group: NR entries of (row | batch position << 8)
+#ifdef TSG_PAD_LDS
+    __shared__ int pad_lds_b[TSG_PAD_LDS / 4];
+    if (a.W < 0) pad_lds_b[threadIdx.x] = 1, list_all[0][0] = (signed char)pad_lds_b[255 - threadIdx.x];
+#endif
 
     const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
@@ -401,7 +418,7 @@ __global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, 
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
     float *cst = cst_all[wave] + ROW;
     float *sums = sums_all[wave] + 16;
-    signed char *list = list_all[wave];
+    uint32_t *list = list_all[wave];
     write_dummy_row(cst, lane);
 
     float T = inside ? final_T[pix] : 0.0f;            // backward.cu:318
@@ -456,121 +473,138 @@ __global__ void __launch_bounds__(256, 4) render_bwd_group_kernel(RenderArgs a, 
         }
         const unsigned long long any = M[0] | M[1] | M[2] | M[3];
         if (any == 0) continue;
-        if ((any >> lane) & 1)
-        {
-            publish_row(cst + lane * ROW, s, id, r1, r2, r3);
-            float4 *z = (float4 *)(sums + lane * 16);
-            z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
-        }
-        ((uint32_t *)list)[lane] = 0xFFFFFFFFu;
-#pragma unroll
-        for (int g = 0; g < 4; g++) // back to front: the entry with the highest list position first
-            if ((M[g] >> lane) & 1) list[g * 64 + (__popcll(M[g]) - 1 - lane_rank(M[g]))] = (signed char)lane;
-        const int steps = max(max(__popcll(M[0]), __popcll(M[1])), max(__popcll(M[2]), __popcll(M[3])));
-        const signed char *mylist = list + grp * 64;
-
-        // steps at which two groups work on the SAME entry (their sums must then be added to its row one after the other)
-        unsigned long long conflict;
-        {
-            const int l0 = list[lane], l1 = list[64 + lane], l2 = list[128 + lane], l3 = list[192 + lane];
-            conflict = ballot((l0 >= 0 && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 >= 0 && (l1 == l2 || l1 == l3)) || (l2 >= 0 && l2 == l3));
-        }
+        // compacted table rows, at most NR per pass (see the forward); back to front: the upper half of a full batch first
+        const bool anybit = (any >> lane) & 1;
+        const int rank = lane_rank(any), nact = __popcll(any);
         const int lrel = last - base; // entries [0, lrel) of this batch are in front of the pixel's last contributor
-        for (int t0 = 0; t0 < steps; t0++)
+        const int r = rank & (NR - 1);
+        bool mine = anybit && (rank / NR) == (nact - 1) / NR;
+        if (mine) publish_row(cst + r * ROW, s, id, r1, r2, r3);
+        for (int h = (nact - 1) / NR;;)
         {
+            const unsigned long long mm = nact <= NR ? any : ballot(mine);
+            if (mine)
             {
-                constexpr int st = 0;
-                const int jc = mylist[t0]; // this group's next entry; past the end of its list: -1 = the dummy row
-                const float *row = cst + jc * ROW;
-                float *acc = sums + jc * 16 + sub;
-                const bool shared_row = (conflict >> (t0 + st)) & 1; // wave-uniform
-                const float q0acc = *acc;                              // fetched early; only used when no other group adds to this row now
-                const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
-                const Bary b = barycentrics(q0, q1, fx, fy);
-                const float4 q2 = *(const float4 *)(row + 8);
-                float4 q3 = make_float4(0, 0, 0, 0);
-                float vd3 = 0.0f;
-                if (RICH)
-                {
-                    q3 = *(const float4 *)(row + 12);
-                    vd3 = row[16];
-                }
-                const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
-                const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f); // exp(-0.5 pw)
-                const float opG = q1.w * G;
-                const float alpha = fminf(0.99f, opG);
-                const bool hit = (jc < lrel) && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f; // backward.cu:378,393,400
-                // branch-free from here on: a lane that does not hit runs with alpha = 0, so T and B stay bit-unchanged and every
-                // value it feeds into the reduction is an exact 0
-                const float al = hit ? alpha : 0.0f;
-                const float oma = 1.0f - al;
-                T = T * __builtin_amdgcn_rcpf(oma); // backward.cu:403
-                const float contrib = al * T;
-                float X = fmaf(dpb, q2.z, fmaf(dpg, q2.y, dpr * q2.x)); // backward.cu:415
-                float w = 0.0f;
-                if (RICH) // backward.cu:419-437
-                {
-                    X = fmaf(dnz, q3.y, fmaf(dny, q3.x, fmaf(dnx, q2.w, X)));
-                    const float depth = fmaf(vd3, b.a3, fmaf(q3.w, b.a2, q3.z * b.a1));
-                    X = fmaf(dd, depth, X);
-                    w = dd * contrib; // dL_ddepth
-                }
-                const float dL_dcontrib = X - B;
-                B = fmaf(al, X, oma * B);
-                const float dL_dalpha = dL_dcontrib * T;
-                // backward.cu:443-447: dL_decc = dL_dpower * 2 gamma * power / (ecc + 1e-8) with power = -0.5 pw and
-                // dL_dpower = dL_dalpha * alpha unless the 0.99 clamp was active; z = -3 dL_decc goes to the arg-min barycentric
-                const float zr = 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(b.ecc + 1e-8f);
-                const float z = (hit && opG < 0.99f) ? zr : 0.0f; // the select sits last: a lane that does not hit may hold inf / NaN in pw
-                const bool k1 = b.a1 == b.mn;        // backward.cu:449-461: a1 <= a2 && a1 <= a3, then a2 <= a1 && a2 <= a3, else a3
-                const bool k2 = !k1 && b.a2 == b.mn;
-                const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = z - z1 - z2;
-                const float da1 = fmaf(w, q3.z, z1), da2 = fmaf(w, q3.w, z2), da3 = fmaf(w, vd3, z3); // backward.cu:433,462
-                const float sdot = fmaf(da3, b.a3, fmaf(da2, b.a2, da1 * b.a1));
-                const float e1 = da1 - sdot, e2 = da2 - sdot, e3 = da3 - sdot;
-                float v[16];
-                v[bitrev4(0)] = e3 * b.p2y - e2 * b.p3y;  // perp(t_1).x =  t_1.y
-                v[bitrev4(1)] = e2 * b.p3x - e3 * b.p2x;  // perp(t_1).y = -t_1.x
-                v[bitrev4(2)] = e1 * b.p3y - e3 * b.p1y;
-                v[bitrev4(3)] = e3 * b.p1x - e1 * b.p3x;
-                v[bitrev4(4)] = e2 * b.p1y - e1 * b.p2y;
-                v[bitrev4(5)] = e1 * b.p2x - e2 * b.p1x;
-                v[bitrev4(6)] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
-                v[bitrev4(7)] = dpr * contrib; v[bitrev4(8)] = dpg * contrib; v[bitrev4(9)] = dpb * contrib; // backward.cu:412
-                v[bitrev4(10)] = dnx * contrib; v[bitrev4(11)] = dny * contrib; v[bitrev4(12)] = dnz * contrib; // backward.cu:421-423
-                v[bitrev4(13)] = w * b.a1; v[bitrev4(14)] = w * b.a2; v[bitrev4(15)] = w * b.a3;             // backward.cu:429-431
-                const float red = row_reduce16(v, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull); // lane (l & 15): column (l & 15) of its group's entry
-                if (!shared_row) *acc = q0acc + red;
-                else
-                {
+                float4 *z = (float4 *)(sums + r * 16);
+                z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
+            }
+            list[lane] = 0xFFFFFFFFu;
+            int steps = 0;
 #pragma unroll
-                    for (int g = 0; g < 4; g++)
+            for (int g = 0; g < 4; g++) // back to front: the entry with the highest list position first
+            {
+                const unsigned long long Mh = M[g] & mm;
+                const int n = __popcll(Mh);
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (n - 1 - lane_rank(Mh))] = (unsigned short)(r | (lane << 8));
+                steps = max(steps, n);
+            }
+            const u16a *mylist = (const u16a *)list + grp * NR;
+
+            // steps at which two groups work on the SAME entry (their sums must then be added to its row one after the other)
+            unsigned long long conflict;
+            {
+                const u16a *l16 = (const u16a *)list + (lane & (NR - 1));
+                const int l0 = l16[0] & 0xFF, l1 = l16[NR] & 0xFF, l2 = l16[2 * NR] & 0xFF, l3 = l16[3 * NR] & 0xFF;
+                conflict = ballot(lane < NR && ((l0 != 0xFF && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != 0xFF && (l1 == l2 || l1 == l3)) ||
+                                                (l2 != 0xFF && l2 == l3)));
+            }
+            for (int t0 = 0; t0 < steps; t0++)
+            {
+                {
+                    const uint32_t e16 = mylist[t0]; // this group's next entry; past the end of its list: row -1 = the dummy
+                    const int jc = (int)(signed char)(e16 & 0xFFu), jpos = (int)(e16 >> 8);
+                    const float *row = cst + jc * ROW;
+                    float *acc = sums + jc * 16 + sub;
+                    const bool shared_row = TSG_PROBE == 3 ? false : (bool)((conflict >> t0) & 1); // wave-uniform
+                    const float q0acc = *acc;                              // fetched early; only used when no other group adds to this row now
+                    const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
+                    const Bary b = barycentrics(q0, q1, fx, fy);
+                    const float4 q2 = *(const float4 *)(row + 8);
+                    float4 q3 = make_float4(0, 0, 0, 0);
+                    float vd3 = 0.0f;
+                    if (RICH)
                     {
-                        if (grp == g) *acc += red;
-                        wave_lds_order();
+                        q3 = *(const float4 *)(row + 12);
+                        vd3 = row[16];
+                    }
+                    const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
+                    const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f); // exp(-0.5 pw)
+                    const float opG = q1.w * G;
+                    const float alpha = fminf(0.99f, opG);
+                    const bool hit = (jpos < lrel) && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f; // backward.cu:378,393,400
+                    // branch-free from here on: a lane that does not hit runs with alpha = 0, so T and B stay bit-unchanged and every
+                    // value it feeds into the reduction is an exact 0
+                    const float al = hit ? alpha : 0.0f;
+                    const float oma = 1.0f - al;
+                    T = T * __builtin_amdgcn_rcpf(oma); // backward.cu:403
+                    const float contrib = al * T;
+                    float X = fmaf(dpb, q2.z, fmaf(dpg, q2.y, dpr * q2.x)); // backward.cu:415
+                    float w = 0.0f;
+                    if (RICH) // backward.cu:419-437
+                    {
+                        X = fmaf(dnz, q3.y, fmaf(dny, q3.x, fmaf(dnx, q2.w, X)));
+                        const float depth = fmaf(vd3, b.a3, fmaf(q3.w, b.a2, q3.z * b.a1));
+                        X = fmaf(dd, depth, X);
+                        w = dd * contrib; // dL_ddepth
+                    }
+                    const float dL_dcontrib = X - B;
+                    B = fmaf(al, X, oma * B);
+                    const float dL_dalpha = dL_dcontrib * T;
+                    // backward.cu:443-447: dL_decc = dL_dpower * 2 gamma * power / (ecc + 1e-8) with power = -0.5 pw and
+                    // dL_dpower = dL_dalpha * alpha unless the 0.99 clamp was active; z = -3 dL_decc goes to the arg-min barycentric
+                    const float zr = 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(b.ecc + 1e-8f);
+                    const float z = (hit && opG < 0.99f) ? zr : 0.0f; // the select sits last: a lane that does not hit may hold inf / NaN in pw
+                    const bool k1 = b.a1 == b.mn;        // backward.cu:449-461: a1 <= a2 && a1 <= a3, then a2 <= a1 && a2 <= a3, else a3
+                    const bool k2 = !k1 && b.a2 == b.mn;
+                    const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = z - z1 - z2;
+                    const float da1 = fmaf(w, q3.z, z1), da2 = fmaf(w, q3.w, z2), da3 = fmaf(w, vd3, z3); // backward.cu:433,462
+                    const float sdot = fmaf(da3, b.a3, fmaf(da2, b.a2, da1 * b.a1));
+                    const float e1 = da1 - sdot, e2 = da2 - sdot, e3 = da3 - sdot;
+                    float v[16];
+                    v[bitrev4(0)] = e3 * b.p2y - e2 * b.p3y;  // perp(t_1).x =  t_1.y
+                    v[bitrev4(1)] = e2 * b.p3x - e3 * b.p2x;  // perp(t_1).y = -t_1.x
+                    v[bitrev4(2)] = e1 * b.p3y - e3 * b.p1y;
+                    v[bitrev4(3)] = e3 * b.p1x - e1 * b.p3x;
+                    v[bitrev4(4)] = e2 * b.p1y - e1 * b.p2y;
+                    v[bitrev4(5)] = e1 * b.p2x - e2 * b.p1x;
+                    v[bitrev4(6)] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
+                    v[bitrev4(7)] = dpr * contrib; v[bitrev4(8)] = dpg * contrib; v[bitrev4(9)] = dpb * contrib; // backward.cu:412
+                    v[bitrev4(10)] = dnx * contrib; v[bitrev4(11)] = dny * contrib; v[bitrev4(12)] = dnz * contrib; // backward.cu:421-423
+                    v[bitrev4(13)] = w * b.a1; v[bitrev4(14)] = w * b.a2; v[bitrev4(15)] = w * b.a3;             // backward.cu:429-431
+                    const float red = row_reduce16(v, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull); // lane (l & 15): column (l & 15) of its group's entry
+                    if (!shared_row) *acc = q0acc + red;
+                    else
+                    {
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+                        {
+                            if (grp == g) *acc += red;
+                            wave_lds_order();
+                        }
                     }
                 }
             }
-        }
 
-        // Batch flush: 16 consecutive lanes add the 16 floats (one 64-byte line) of one triangle's gradient record, four
-        // entries per instruction (the entries with work, compacted through group 0's list); the vertex columns get their
-        // 1 / area2 here.
-        {
-            if ((any >> lane) & 1) list[lane_rank(any)] = (signed char)lane;
-            const int n = __popcll(any);
-#pragma unroll 1
-            for (int e0 = 0; e0 < n; e0 += 4)
+            // Pass flush: 16 consecutive lanes add the 16 floats (one 64-byte line) of one triangle's gradient record, four
+            // rows per instruction; the vertex columns get their 1 / area2 here.
             {
-                if (e0 + grp < n)
+                const int n = __popcll(mm);
+#pragma unroll 1
+                for (int e0 = 0; e0 < n; e0 += 4)
                 {
-                    const int e = list[e0 + grp];
-                    const uint32_t eid = __float_as_uint(cst[e * ROW + 17]);
-                    float val = sums[e * 16 + sub];
-                    if (sub < 6) val *= cst[e * ROW + 6];
-                    if (RICH || sub < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, val);
+                    const int e = e0 + grp;
+                    if (e < n)
+                    {
+                        const uint32_t eid = __float_as_uint(cst[e * ROW + 17]);
+                        float val = sums[e * 16 + sub];
+                        if (sub < 6) val *= cst[e * ROW + 6];
+                        if (RICH || sub < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, val);
+                    }
                 }
             }
+            if (--h < 0) break;
+            mine = anybit && rank < NR;
+            if (mine) republish_row<RICH>(cst + r * ROW, point_list, rec, range.x + base + lane, OX, OY);
         }
     }
 }
@@ -599,10 +633,10 @@ void ts_launch_render_fwd_group(const RenderArgs &a, const GeometryStateView &g,
 #ifdef TS2D_STATS
 extern "C" int ts2d_stats_read_group(unsigned long long *out, int reset)
 {
-    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats_group), sizeof(unsigned long long) * 8);
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats_group), sizeof(unsigned long long) * 12);
     if (e == hipSuccess && reset)
     {
-        unsigned long long z[8] = {0};
+        unsigned long long z[12] = {0};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_stats_group), z, sizeof(z));
     }
     return e == hipSuccess ? 0 : 2;

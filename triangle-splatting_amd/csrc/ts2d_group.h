@@ -5,6 +5,8 @@
 
 namespace
 {
+constexpr int NR = 32;  // table rows per pass: the entries of a 64-entry batch that have work, compacted (more than NR: two passes)
+typedef unsigned short __attribute__((may_alias)) u16a;
 constexpr int ROW = 20; // floats per entry row of the wave-private constants table (row -1 = a dummy no pixel can hit)
 
 __device__ __forceinline__ unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -97,4 +99,40 @@ __device__ __forceinline__ float row_reduce16(float (&v)[16], unsigned long long
 }
 constexpr int bitrev4(int c) { return ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3); }
 
+
+// ---- contrib_sum / contrib_max of a tile (forward, rich_info) ---------------------------------------------------------------
+// The four quadrant waves of a tile and the four lane groups of each wave meet in two LDS arrays indexed by list position.
+// LDS atomics on gfx950 (tools/lds_atomic_bench2.hip): ds_add_f32 193 cycles per wave instruction, ds_add_u32 4.9, ds_add_u64 7.0,
+// ds_max_i32 4.8 -- so the sums are kept in 16.48 FIXED POINT (a (group, entry) sum is <= 16, a tile's <= 256; the smallest
+// possible contribution, 1/255 * 1e-4, still carries 27 significant bits: the fixed-point sum is closer to the exact one than any
+// fp32 summation order) and the maxima as the bit patterns of non-negative floats (int order == float order).
+__device__ __forceinline__ unsigned long long to_fixed48(float x) // x in [0, 2^15): floor(x * 2^48), exact for x >= 2^-25
+{
+    const float y = x * 0x1p48f;                          // exact
+    const uint32_t hi = (uint32_t)(y * 0x1p-32f);         // truncates
+    const float rem = fmaf(-(float)hi, 0x1p32f, y);       // exact: in [0, 2^32)
+    return ((unsigned long long)hi << 32) | (unsigned long long)(uint32_t)rem;
+}
+// Scattered global atomics cost one L2 line operation each (~20 G/s chip-wide, tools/atomic_scope_bench.hip).  A running maximum
+// only grows, so a (possibly stale, hence smaller) plain read that already exceeds the new value proves the atomic redundant.
+__device__ __forceinline__ void global_stats_add(uint32_t tid, float sm, float mx, float *contrib_sum, float *contrib_max)
+{
+    unsafeAtomicAdd(contrib_sum + tid, sm);
+    if (mx > contrib_max[tid]) atomicMax((int *)contrib_max + tid, __float_as_int(mx));
+}
+template <int TCAP>
+__device__ __forceinline__ void tile_stats_add(unsigned long long *tsum, int *tmax, int k, float sm, float mx, const uint32_t *tile_list,
+                                               float *contrib_sum, float *contrib_max)
+{
+    if (k < TCAP)
+    {
+        __hip_atomic_fetch_add(tsum + k, to_fixed48(sm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_max(tmax + k, __float_as_int(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    else global_stats_add(tile_list[k], sm, mx, contrib_sum, contrib_max); // list positions beyond the LDS arrays (a very long tile list)
+}
+__device__ __forceinline__ void tile_stats_flush(unsigned long long fx48, int mxbits, uint32_t tid, float *contrib_sum, float *contrib_max)
+{
+    global_stats_add(tid, (float)((double)fx48 * 0x1p-48), __int_as_float(mxbits), contrib_sum, contrib_max);
+}
 } // namespace
