@@ -263,6 +263,9 @@ USEFUL_FLOP_PER_PAIR = {"render_fwd": 60, "render_bwd": 175}  # fp32 operations 
 FP32_VECTOR_PEAK = 157.3e12                                   # MI355X_MICROARCH.md
 
 
+MIX_CYCLES_PER_VALU_INST = {"render_bwd": 3.3, "render_fwd": 3.0}
+
+
 def compute_side(kernel, avg_ms, headline):
     """The roofline the blend kernels actually sit on (they are VALU-bound), from the committed SQ-counter pass
     of the same workload (profiles/blend_pmc.json, tools/collect_blend_pmc.sh) and the lane-group statistics
@@ -276,6 +279,13 @@ def compute_side(kernel, avg_ms, headline):
             out.update(valu_insts_per_launch=v["SQ_INSTS_VALU"], valu_issue_slot_frac=v["valu_issue_frac_at_2cyc"],
                        transcendental_insts_per_launch=v.get("SQ_INSTS_VALU_TRANS_F32"), lds_busy_frac=v.get("lds_busy_frac"),
                        avg_waves_per_simd=v.get("avg_waves_per_simd"), wave_cycle_split=v.get("wave_cycle_split"))
+            # the same count priced with the MEASURED per-class issue costs (tools/valu_bench2.hip: 2.5 cycles full rate, 4.3 for
+            # compare / select / min / every DPP form, 8.3 transcendental) at the static instruction mix of the kernel's step
+            # loop: an estimate of how much of the VALU issue capacity the launch consumes
+            mix = MIX_CYCLES_PER_VALU_INST.get(kernel)
+            if mix and v.get("kernel_cycles"):
+                out.update(valu_cycles_per_inst_at_measured_mix=mix,
+                           valu_busy_frac_est=round(v["SQ_INSTS_VALU"] * mix / (1024.0 * v["kernel_cycles"]), 4))
     except Exception:
         pass
     try:
