@@ -289,3 +289,28 @@ def test_full_size_against_oracle(P, W, H, D, variant):
     assert helpers.robust_rel_l2(hf["dL_dvertex"], ob["dL_dvertex"], budget, grazing) < tol3d
     vref = np.linalg.norm(ob["dL_dvertex"].astype(np.float64))
     assert helpers.robust_rel_l2(hf["dL_dcenter2D"], ob["dL_dcenter2D"], budget, grazing, ref=vref) < tol3d
+
+
+def test_backward_when_the_loss_ignores_the_rich_outputs():
+    """A loss that touches only the image (or only depth / normal): autograd hands the Function `None` for the other outputs
+    (no zero tensors are materialised any more); the result must be what explicit zero upstream gradients give."""
+    import torch
+    from diff_triangle_rasterization_2D import TriangleRasterizer
+    s = synthetic.scene(3000, 96, 64, 2, seed=5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    full = dict(s)
+    full["dL_dout_depth"] = np.zeros_like(s["dL_dout_depth"])
+    full["dL_dout_normal"] = np.zeros_like(s["dL_dout_normal"])
+    want = helpers.hip_forward_backward(full, True, False)
+    vertex, shs, opacity = (t(s[k]).requires_grad_(True) for k in ("vertex", "shs", "opacity"))
+    center2D = torch.zeros((3000, 2), device="cuda", requires_grad=True)
+    out = TriangleRasterizer(helpers.hip_settings(s, True))(vertex, center2D, opacity, shs=shs)
+    (out[0] * t(s["dL_dout_feature"])).sum().backward()
+    for got, k in ((vertex.grad, "dL_dvertex"), (shs.grad, "dL_dshs"), (opacity.grad, "dL_dopacity"), (center2D.grad, "dL_dcenter2D")):
+        assert helpers.rel_l2(got.cpu().numpy().reshape(want[k].shape), want[k]) < 1e-5, k
+    # only the depth map: the image's upstream gradient is the missing one
+    vertex.grad = shs.grad = opacity.grad = None
+    out = TriangleRasterizer(helpers.hip_settings(s, True))(vertex, torch.zeros((3000, 2), device="cuda", requires_grad=True), opacity, shs=shs)
+    out[2].sum().backward()
+    assert torch.isfinite(vertex.grad).all() and float(vertex.grad.abs().sum()) > 0.0
+    assert float(shs.grad.abs().sum()) == 0.0  # the colours do not influence the depth map

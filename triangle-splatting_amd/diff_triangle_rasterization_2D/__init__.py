@@ -140,9 +140,13 @@ class _RasterizeTriangles(torch.autograd.Function):
         if _instance_capacity is not None and vertex.shape[0] > 0:
             global _last_sync_free_forward
             _last_sync_free_forward = (vertex.shape[0], rs.image_width, rs.image_height, geometryBuffer, imageBuffer)
+        # autograd would otherwise materialise a zero tensor for every output without an incoming gradient (radii, contrib_sum,
+        # contrib_max: three fill kernels per step that nothing reads); backward() makes its own zeros where it needs them
+        ctx.set_materialize_grads(False)
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.bg_depth = bg_depth
+        ctx.num_channels = int(out_feature.shape[0])
         ctx.save_for_backward(vertex, shs, feature, opacity, radii, geometryBuffer, binningBuffer, imageBuffer)
         if rs.rich_info:
             ctx.mark_non_differentiable(radii, contrib_sum, contrib_max)
@@ -154,9 +158,12 @@ class _RasterizeTriangles(torch.autograd.Function):
     def backward(ctx, *grads_out):
         rs = ctx.raster_settings
         vertex, shs, feature, opacity, radii, geometryBuffer, binningBuffer, imageBuffer = ctx.saved_tensors
-        g_feature = grads_out[0]
+        H, W = rs.image_height, rs.image_width
+        zeros = lambda *shape: torch.zeros(shape, device=vertex.device, dtype=vertex.dtype)
+        g_feature = grads_out[0] if grads_out[0] is not None else zeros(ctx.num_channels, H, W)
         if rs.rich_info:
-            g_depth, g_normal = grads_out[2], grads_out[3]
+            g_depth = grads_out[2] if grads_out[2] is not None else zeros(H, W)
+            g_normal = grads_out[3] if grads_out[3] is not None else zeros(3, H, W)
         else:  # FIX of the reference's unbound names
             g_depth = g_normal = torch.empty((0,), device=vertex.device, dtype=vertex.dtype)
         native_args = _camera_and_geometry_args(rs, ctx.bg_depth) + (
