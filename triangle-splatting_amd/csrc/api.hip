@@ -10,6 +10,7 @@
 #include "../../include/ts_knn.h"
 #include "../../include/ts_model.h"
 #include "ts2d_common.h"
+#include <atomic>
 
 #include <cstdarg>
 #include <cstdio>
@@ -157,7 +158,30 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.legacy_blend = s_legacy;
     return r;
 }
-int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state, hipStream_t s);
+// Early read-back of the instance count (binning.hip, count_instances_kernel): a pinned host word + an event per call in flight
+struct EarlyCount
+{
+    unsigned long long *host = nullptr;
+    hipEvent_t ev = nullptr;
+};
+int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state, hipStream_t s,
+                     EarlyCount *early);
+bool acquire_early_count(EarlyCount &e)
+{
+    constexpr int SLOTS = 64; // calls that may be between their copy and their wait at the same time (streams x threads)
+    static unsigned long long *ring = [] {
+        void *p = nullptr;
+        return hipHostMalloc(&p, SLOTS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess ? (unsigned long long *)p : nullptr;
+    }();
+    static hipEvent_t events[SLOTS] = {};
+    static std::atomic<unsigned> next{0};
+    if (!ring) return false;
+    const unsigned i = next.fetch_add(1) % SLOTS;
+    if (!events[i] && hipEventCreateWithFlags(&events[i], hipEventDisableTiming) != hipSuccess) return false;
+    e.host = ring + i;
+    e.ev = events[i];
+    return true;
+}
 } // namespace
 
 extern "C" {
@@ -195,12 +219,24 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     if (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P))
         return fail(TS2D_ERR_CAPACITY, "geometry state buffer too small: %zu < %zu", state->geometry_bytes,
                     ts2d_geometry_state_bytes(P));
-    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s)) return rc;
-    GeometryStateView g;
-    ts_carve_geometry((char *)state->geometry, P, g);
+    // The count is summed and copied right after preprocess; the depth sort and the scan are queued behind the copy, and the host
+    // waits for the COPY only (the reference's blocking cudaMemcpy, rasterizer.cu:191, sits after its scan)
+    EarlyCount early;
+    const bool have_early = acquire_early_count(early);
+    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, have_early ? &early : nullptr)) return rc;
     unsigned long long n = 0;
-    TS_HIP(hipMemcpyAsync(&n, ts_instance_count_dev(g, P), sizeof(n), hipMemcpyDeviceToHost, s));
-    TS_HIP(hipStreamSynchronize(s)); // the reference's blocking cudaMemcpy, rasterizer.cu:191
+    if (have_early)
+    {
+        TS_HIP(hipEventSynchronize(early.ev));
+        n = *early.host;
+    }
+    else
+    {
+        GeometryStateView g;
+        ts_carve_geometry((char *)state->geometry, P, g);
+        TS_HIP(hipMemcpyAsync(&n, ts_instance_count_dev(g, P), sizeof(n), hipMemcpyDeviceToHost, s));
+        TS_HIP(hipStreamSynchronize(s));
+    }
     if (n > 0x7fffffffull) // the reference's int num_rendered wraps here; instance slots are 32-bit
         return fail(TS2D_ERR_CAPACITY, "%llu tile instances exceed the 2^31 - 1 the instance list can address", n);
     *num_rendered = (int64_t)n;
@@ -289,7 +325,8 @@ int check_forward_args(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
 }
 
 // preprocess + depth order + instance count on the device (no host read)
-int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state, hipStream_t s)
+int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state, hipStream_t s,
+                     EarlyCount *early)
 {
     const int P = geom->P;
     GeometryStateView g;
@@ -301,6 +338,14 @@ int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
         else ts_launch_preprocess_fwd(a, radii, g, s);
     }
     TS_CHECK(flags, s, "preprocess_fwd");
+    if (early)
+    {
+        {
+            ProfScope ps("count", s);
+            ts_launch_count_instances(g, P, early->host, s); // writes the pinned host word itself
+        }
+        TS_HIP(hipEventRecord(early->ev, s));
+    }
     {
         ProfScope ps("depth_sort", s);
         ts_sort_by_depth(g, P, s);
@@ -332,7 +377,7 @@ int ts2d_forward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fla
     if (geom->P == 0) return forward_render_impl(cam, geom, flags, 0, nullptr, state, out, s);
     if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
     if (instance_capacity <= 0) return fail(TS2D_ERR_INVALID, "instance_capacity must be positive");
-    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s)) return rc;
+    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, nullptr)) return rc;
     static const unsigned long long on_device = 0; // any non-null marker: forward_render_impl resolves the real address
     return forward_render_impl(cam, geom, flags, instance_capacity, &on_device, state, out, s);
 }

@@ -251,6 +251,45 @@ void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32
     else hipLaunchKernelGGL((rs_scatter_kernel<true>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r);
 }
 
+// ---- early instance count: N = sum(tiles_touched), known as soon as preprocess is done ------------------------------------------
+// The reference's interface hands num_rendered to the host (rasterizer.cu:189-191), which sizes the binning buffer from it.  N does not
+// depend on the depth order, so it is summed right after preprocess and copied to the host WHILE the depth sort runs: the host
+// round trip (blocking read, buffer allocation, next launches: ~55 us of idle GPU in round 2's timeline) hides behind 0.15 ms of
+// queued kernels.  Partial sums go through blocksum[] (rewritten later by gather_blocksum_kernel), the total lands where that
+// kernel will put the same number again.
+constexpr int CB = 2048; // triangles per block
+__global__ void __launch_bounds__(256) count_instances_kernel(int P, GeometryStateView g, uint32_t *ticket, int nblocks_scan,
+                                                              unsigned long long *host_out)
+{
+    __shared__ unsigned long long wsum[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    unsigned long long sum = 0;
+#pragma unroll
+    for (int k = 0; k < CB / 256; k++)
+    {
+        const int i = blockIdx.x * CB + 256 * k + t;
+        if (i < P) sum += g.tiles_touched[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) wsum[wave] = sum;
+    __syncthreads();
+    if (t == 0) peer_store((unsigned long long *)g.blocksum + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+    if (!last_arrival(ticket, gridDim.x)) return;
+    sum = 0;
+    for (int b = t; b < (int)gridDim.x; b += 256) sum += peer_load((const unsigned long long *)g.blocksum + b);
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    __syncthreads();
+    if (lane == 0) wsum[wave] = sum;
+    __syncthreads();
+    if (t == 0)
+    {
+        const unsigned long long n = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        ((unsigned long long *)g.blocksum)[nblocks_scan] = n;
+        // pinned, device-visible host word: the host reads it after the event recorded behind this kernel (no copy kernel in between)
+        if (host_out) __hip_atomic_store(host_out, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- step 2: tiles_sorted = tiles_touched[perm], 64-bit block sums, their prefix, N ---------------------------------------
 constexpr int SB = 1024; // triangles per scan block (256 threads x 4)
 
@@ -447,6 +486,13 @@ void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
     if (P <= 0) return;
     const int nblocks = (P + SB - 1) / SB;
     hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, g.rs.tickets + 1);
+}
+
+void ts_launch_count_instances(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(count_instances_kernel, dim3((unsigned)((P + CB - 1) / CB)), dim3(256), 0, s, P, g, g.rs.tickets + 2 + g.rs.slabs,
+                       (P + SB - 1) / SB, host_out);
 }
 
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,

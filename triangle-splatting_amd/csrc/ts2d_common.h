@@ -173,6 +173,7 @@ void ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s);    
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);                  // tiles_sorted, block sums, N
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                          float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path
+void ts_launch_count_instances(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s);
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P);                        // where the scan leaves N
 void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s); // stable, tile bits only
 void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
