@@ -8,6 +8,8 @@
                           prune_points / densification / opacity_pruning / opacity_clipping / scale_pruning / scale_clipping /
                           opacity_reset / contribution_pruning with their Adam-state surgery on native row operators
                           (reference: src/diff_recon/models/VanillaTS_model.py:194-201, 214-345, 347-537)
+    raw_triangle.py       RawTriangle with loadPLY / savePLY / saveGLB / loadGLB: the on-disk formats of a triangle model, numpy only
+                          (reference: src/diff_recon/models/raw_triangle.py:12-33, 124-223)
     model_forward.py      render_view = the argument construction of VanillaTSModel.forward
                           (reference: src/diff_recon/models/VanillaTS_model.py:585-694)
 
@@ -18,3 +20,4 @@ from .triangle_renderer import TriangleRenderer  # noqa: F401
 from .model_forward import gamma_rescale_ratio, rescale_triangles, ste_opacity, render_view  # noqa: F401
 from .model_update import (DensificationStats, prune_points, densification, opacity_pruning, opacity_clipping, scale_pruning,  # noqa: F401
                            scale_clipping, opacity_reset, contribution_pruning)
+from .raw_triangle import RawTriangle  # noqa: F401
