@@ -137,7 +137,7 @@ __device__ __forceinline__ void project_vec_approx_bwd(f3 p, f3 v, float tx, flo
 
 // One triangle.  `vp` / `shp`: its vertex and SH rows (global or LDS); `ov` (9 floats) and `osh` (3 M floats, may be null):
 // where dL_dvertex / dL_dshs of this triangle go (global or LDS rows that the caller flushes).
-__device__ __forceinline__ void preprocess_bwd_one(const PreprocessArgs &a, const int32_t *__restrict__ radii,
+__device__ __forceinline__ f3 preprocess_bwd_one(const PreprocessArgs &a, const int32_t *__restrict__ radii,
                                                    const GeometryStateView &g, const float *__restrict__ grad_rec, int idx,
                                                    const float *vp, const float *shp, float *ov, float *osh,
                                                    float *__restrict__ dL_dcenter2D, float *__restrict__ dL_dfeature,
@@ -152,8 +152,12 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreprocessArgs &a, cons
         dL_dopacity[idx] = 0.0f;
         for (int c = 0; c < a.C; c++) dL_dfeature[(size_t)idx * a.C + c] = 0.0f;
         if (a.use_shs && osh)
-            for (int k = 0; k < a.M * 3; k++) osh[k] = 0.0f;
-        return;
+        {
+#pragma unroll
+            for (int k = 0; k < 48; k++) // constant indices: the row may live in registers (M <= 16, validate())
+                if (k < a.M * 3) osh[k] = 0.0f;
+        }
+        return {0.0f, 0.0f, 0.0f};
     }
 
     const float4 *gr = (const float4 *)(grad_rec + TS_GRAD_FLOATS * (size_t)idx);
@@ -223,6 +227,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreprocessArgs &a, cons
     const f3 dL_dr2 = xform_vec_4x3_T(dL_dr2_view, a.viewmatrix);
     const f3 dL_dr3 = xform_vec_4x3_T(dL_dr3_view, a.viewmatrix);
 
+    f3 masked = {0.0f, 0.0f, 0.0f}; // the clamp-masked colour gradient: returned, for callers that expand dL_dshs themselves
     if (a.use_shs)
     {
         const uint8_t cl = g.clamped[idx];
@@ -233,6 +238,7 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreprocessArgs &a, cons
         const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
         // when osh aliases shp (LDS row, staged kernel) the coefficients must be consumed before the gradients are written
         const f3 dsh = sh_backward(a.D, a.M, shp, center, cp, dL_dRGB, nullptr);
+        masked = dL_dRGB;
         if (osh) sh_grad_store(a.D, a.M, center, cp, dL_dRGB, osh);
         if (!osh) dL_drgb = dL_dRGB; // factored exchange (TS2D_FLAG_SH_FACTORED): hand out the clamp-masked colour gradient
         dL_dcenter = add(dL_dcenter, dsh);
@@ -251,12 +257,13 @@ __device__ __forceinline__ void preprocess_bwd_one(const PreprocessArgs &a, cons
     if (a.C > 0) of[0] = dL_drgb.x;
     if (a.C > 1) of[1] = dL_drgb.y;
     if (a.C > 2) of[2] = dL_drgb.z;
+    return masked;
 }
 
 struct Raster2D
 {
     template <class... T> static __device__ __forceinline__ void fwd(T... t) { preprocess_fwd_one(t...); }
-    template <class... T> static __device__ __forceinline__ void bwd(T... t) { preprocess_bwd_one(t...); }
+    template <class... T> static __device__ __forceinline__ f3 bwd(T... t) { return preprocess_bwd_one(t...); }
 };
 } // namespace
 

@@ -102,7 +102,7 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
 }
 
 // One triangle; `ov` (9 floats) / `osh` (3 M floats, may be null) receive dL_dvertex / dL_dshs (global memory or LDS rows).
-__device__ __forceinline__ void preprocess3d_bwd_one(const PreprocessArgs &a, const int32_t *__restrict__ radii,
+__device__ __forceinline__ f3 preprocess3d_bwd_one(const PreprocessArgs &a, const int32_t *__restrict__ radii,
                                                      const GeometryStateView &g, const float *__restrict__ grad_rec, int idx,
                                                      const float *vp, const float *shp, float *ov, float *osh,
                                                      float *__restrict__ dL_dcenter2D, float *__restrict__ dL_dfeature,
@@ -117,8 +117,12 @@ __device__ __forceinline__ void preprocess3d_bwd_one(const PreprocessArgs &a, co
         dL_dopacity[idx] = 0.0f;
         for (int c = 0; c < a.C; c++) dL_dfeature[(size_t)idx * a.C + c] = 0.0f;
         if (a.use_shs && osh)
-            for (int k = 0; k < a.M * 3; k++) osh[k] = 0.0f;
-        return;
+        {
+#pragma unroll
+            for (int k = 0; k < 48; k++) // constant indices: the row may live in registers (M <= 16, validate())
+                if (k < a.M * 3) osh[k] = 0.0f;
+        }
+        return {0.0f, 0.0f, 0.0f};
     }
     const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]}; // before ov (may alias vp) is written
     const float4 *rp = g.rec + 4 * (size_t)idx;
@@ -137,6 +141,7 @@ __device__ __forceinline__ void preprocess3d_bwd_one(const PreprocessArgs &a, co
     gv3 = add(gv3, cross(sub(v1_view, v2_view), gn));
     f3 dL_dv1 = xform_vec_4x3_T(gv1, a.viewmatrix), dL_dv2 = xform_vec_4x3_T(gv2, a.viewmatrix),
        dL_dv3 = xform_vec_4x3_T(gv3, a.viewmatrix);
+    f3 masked = {0.0f, 0.0f, 0.0f}; // the clamp-masked colour gradient: returned, for callers that expand dL_dshs themselves
     if (a.use_shs)
     {
         const f3 center = divf(add(add(v1, v2), v3), 3.0f);
@@ -148,6 +153,7 @@ __device__ __forceinline__ void preprocess3d_bwd_one(const PreprocessArgs &a, co
         const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
         // when osh aliases shp (LDS row) the coefficients must be consumed before the gradients are written
         const f3 dsh = sh_backward(a.D, a.M, shp, center, cp, dL_dRGB, nullptr);
+        masked = dL_dRGB;
         if (osh) sh_grad_store(a.D, a.M, center, cp, dL_dRGB, osh);
         if (!osh) grgb_out = dL_dRGB; // factored exchange (TS2D_FLAG_SH_FACTORED)
         const f3 third = divf(dsh, 3.0f); // R3D backward.cu:196-198
@@ -163,11 +169,12 @@ __device__ __forceinline__ void preprocess3d_bwd_one(const PreprocessArgs &a, co
     if (a.C > 0) of[0] = grgb_out.x;
     if (a.C > 1) of[1] = grgb_out.y;
     if (a.C > 2) of[2] = grgb_out.z;
+    return masked;
 }
 struct Raster3D
 {
     template <class... T> static __device__ __forceinline__ void fwd(T... t) { preprocess3d_fwd_one(t...); }
-    template <class... T> static __device__ __forceinline__ void bwd(T... t) { preprocess3d_bwd_one(t...); }
+    template <class... T> static __device__ __forceinline__ f3 bwd(T... t) { return preprocess3d_bwd_one(t...); }
 };
 } // namespace
 

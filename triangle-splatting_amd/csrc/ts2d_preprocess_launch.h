@@ -9,7 +9,12 @@
 #pragma once
 #include "ts2d_common.h"
 #include "ts2d_stage.h"
+#include "ts2d_math.h"
+#include "ts2d_sh.h"
 
+#ifndef TS_PRE_OUT_REGS
+#define TS_PRE_OUT_REGS 0
+#endif
 namespace ts
 {
 // The binning kernels' "last block finishes" tickets (binning.hip) are zeroed by the first launch of the step.  Every grid has at
@@ -28,19 +33,29 @@ __global__ void __launch_bounds__(256) preprocess_fwd_direct_kernel(PreprocessAr
     Body::fwd(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
 }
 
-// vertex rows always staged; SH rows staged when SHROW = 3 M > 0
-template <class Body, int SHROW>
+// vertex rows always staged; SH rows (SHROW = 3 M > 0 floats) travel either through LDS as well (SH_REGS = false) or straight into
+// the lane's registers with SHROW / 4 dwordx4 loads (SH_REGS = true).  Both read the rows at the same rate in isolation
+// (tools/sh_stage_bench.hip: 5.5-5.7 TB/s), but 12.5 KB of LDS per single-wave workgroup held the kernel at 2 waves per SIMD with
+// 73 % of the wave cycles spent waiting (profiles/r02_notes.md); without it the registers are the only limit.
+template <class Body, int SHROW, bool SH_REGS>
 __global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
 {
     __shared__ float s_v[64 * 9];
-    __shared__ float s_sh[SHROW > 0 ? 64 * (SHROW + 1) : 1];
+    __shared__ float s_sh[(SHROW > 0 && !SH_REGS) ? 64 * (SHROW + 1) : 1];
     const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
+    float shr[(SHROW > 0 && SH_REGS) ? SHROW : 4];
+    if (SHROW > 0 && SH_REGS && idx < a.P)
+    {
+        const float4 *rowp = (const float4 *)(a.shs + (size_t)idx * SHROW);
+#pragma unroll
+        for (int c = 0; c < SHROW / 4; c++) *(float4 *)(shr + 4 * c) = rowp[c];
+    }
     stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
-    if (SHROW > 0) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
+    if (SHROW > 0 && !SH_REGS) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
     __syncthreads();
     clear_tickets(g, idx);
     if (idx >= a.P) return;
-    const float *shp = SHROW > 0 ? s_sh + lane * (SHROW + 1) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
+    const float *shp = SHROW > 0 ? (SH_REGS ? shr : s_sh + lane * (SHROW + 1)) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
     Body::fwd(a, radii, g, idx, s_v + lane * 9, shp);
 }
 
@@ -60,7 +75,7 @@ __global__ void __launch_bounds__(256) preprocess_bwd_direct_kernel(PreprocessAr
 
 // SHROW = 3 M > 0: LDS rows carry the SH coefficients in (SH_IN) and / or the dL_dshs rows out (WRITE_SH); the vertex rows
 // carry the vertices in and dL_dvertex out.  A lane only ever touches its own rows between the two cooperative phases.
-template <class Body, int SHROW, bool SH_IN, bool WRITE_SH>
+template <class Body, int SHROW, bool SH_IN, bool WRITE_SH, bool SH_REGS>
 __global__ void __launch_bounds__(64) preprocess_bwd_staged_kernel(PreprocessArgs a, const int32_t *__restrict__ radii,
                                                                     GeometryStateView g, const float *__restrict__ grad_rec,
                                                                     float *__restrict__ dL_dvertex, float *__restrict__ dL_dcenter2D,
@@ -68,21 +83,48 @@ __global__ void __launch_bounds__(64) preprocess_bwd_staged_kernel(PreprocessArg
                                                                     float *__restrict__ dL_dopacity)
 {
     __shared__ float s_v[64 * 9];
-    __shared__ float s_sh[SHROW > 0 ? 64 * (SHROW + 1) : 1];
+    constexpr bool OUT_REGS = SH_REGS && TS_PRE_OUT_REGS; // gradient rows leave from registers (strided dwordx4 stores) or through LDS (coalesced)
+    __shared__ float s_sh[(SHROW > 0 && (!SH_REGS || (WRITE_SH && !OUT_REGS))) ? 64 * (SHROW + 1) : 1];
     const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
+    // SH_REGS (rows of whole 16-byte pieces): the coefficient row comes straight into registers and the gradient row leaves from
+    // registers, SHROW / 4 dwordx4 each -- see preprocess_fwd_staged_kernel
+    float shr[(SHROW > 0 && SH_REGS && SH_IN) ? SHROW : 4], osr[(SHROW > 0 && OUT_REGS && WRITE_SH) ? SHROW : 4];
+    if (SHROW > 0 && SH_REGS && SH_IN && idx < a.P)
+    {
+        const float4 *rowp = (const float4 *)(a.shs + (size_t)idx * SHROW);
+#pragma unroll
+        for (int c = 0; c < SHROW / 4; c++) *(float4 *)(shr + 4 * c) = rowp[c];
+    }
     stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
-    if (SHROW > 0 && SH_IN) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
+    if (SHROW > 0 && SH_IN && !SH_REGS) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
     __syncthreads();
     if (idx < a.P)
     {
-        float *row = SHROW > 0 ? s_sh + lane * (SHROW + 1) : nullptr;
-        const float *shp = (SHROW > 0 && SH_IN) ? row : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
-        Body::bwd(a, radii, g, grad_rec, idx, s_v + lane * 9, shp, s_v + lane * 9, WRITE_SH ? row : nullptr, dL_dcenter2D,
-                  dL_dfeature, dL_dopacity);
+        const float *vp = s_v + lane * 9;
+        const float *shp = (SHROW > 0 && SH_IN) ? (SH_REGS ? shr : s_sh + lane * (SHROW + 1)) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
+        if (SHROW > 0 && OUT_REGS && WRITE_SH)
+        {
+            // the gradient row is expanded here, from the clamp-masked colour gradient the per-triangle function hands back: the
+            // row then never has its address taken inside that function and stays in registers.  The vertex row is consumed
+            // first (dL_dvertex overwrites it in place).
+            const f3 center = divf(add(add(f3{vp[0], vp[1], vp[2]}, f3{vp[3], vp[4], vp[5]}), f3{vp[6], vp[7], vp[8]}), 3.0f);
+            const f3 masked = Body::bwd(a, radii, g, grad_rec, idx, vp, shp, s_v + lane * 9, (float *)nullptr, dL_dcenter2D, dL_dfeature, dL_dopacity);
+#pragma unroll
+            for (int k = 0; k < SHROW; k++) osr[k] = 0.0f;
+            if (radii[idx] > 0) sh_grad_store(a.D, a.M, center, f3{a.campos[0], a.campos[1], a.campos[2]}, masked, osr);
+            float4 *rowo = (float4 *)(dL_dshs + (size_t)idx * SHROW);
+#pragma unroll
+            for (int c = 0; c < SHROW / 4; c++) rowo[c] = *(const float4 *)(osr + 4 * c);
+        }
+        else
+        {
+            float *row = (SHROW > 0 && !OUT_REGS) ? s_sh + lane * (SHROW + 1) : nullptr;
+            Body::bwd(a, radii, g, grad_rec, idx, vp, shp, s_v + lane * 9, WRITE_SH ? row : nullptr, dL_dcenter2D, dL_dfeature, dL_dopacity);
+        }
     }
     __syncthreads();
     stage_rows_out<9, 9>(s_v, dL_dvertex, row0, a.P, lane);
-    if (SHROW > 0 && WRITE_SH) stage_rows_out<SHROW, SHROW + 1>(s_sh, dL_dshs, row0, a.P, lane);
+    if (SHROW > 0 && WRITE_SH && !OUT_REGS) stage_rows_out<SHROW, SHROW + 1>(s_sh, dL_dshs, row0, a.P, lane);
 }
 
 // Staging policy: vertex rows whenever the pointers are 16-byte aligned; SH rows in when at least half of each row is
@@ -104,17 +146,17 @@ void launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const Geomet
     const dim3 grid((a.P + 63) / 64), block(64);
     switch (sh_in ? shrow : 0)
     {
-    case 48: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 48>), grid, block, 0, s, a, radii, g); break;
-    case 27: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 27>), grid, block, 0, s, a, radii, g); break;
-    case 12: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 12>), grid, block, 0, s, a, radii, g); break;
-    case 3: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 3>), grid, block, 0, s, a, radii, g); break;
-    default: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 0>), grid, block, 0, s, a, radii, g); break;
+    case 48: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 48, true>), grid, block, 0, s, a, radii, g); break; // rows are 16-byte multiples
+    case 27: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 27, false>), grid, block, 0, s, a, radii, g); break;
+    case 12: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 12, true>), grid, block, 0, s, a, radii, g); break;
+    case 3: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 3, false>), grid, block, 0, s, a, radii, g); break;
+    default: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 0, false>), grid, block, 0, s, a, radii, g); break;
     }
 }
 
 #define TS_BWD_STAGED(SHROW, SH_IN, WRITE_SH)                                                                                \
-    hipLaunchKernelGGL((preprocess_bwd_staged_kernel<Body, SHROW, SH_IN, WRITE_SH>), grid, block, 0, s, a, radii, g, grad_rec, \
-                       dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity)
+    hipLaunchKernelGGL((preprocess_bwd_staged_kernel<Body, SHROW, SH_IN, WRITE_SH, (SHROW > 0 && SHROW % 4 == 0)>), grid, block, 0, s, a, \
+                       radii, g, grad_rec, dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity)
 #define TS_BWD_STAGED_ROW(SHROW)                                                                                             \
     do                                                                                                                       \
     {                                                                                                                        \

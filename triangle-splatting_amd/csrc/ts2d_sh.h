@@ -74,7 +74,10 @@ __device__ __forceinline__ void sh_grad_store(int deg, int M, f3 pos, f3 campos,
 #pragma unroll
     for (int k = 0; k < 16; k++)
         if (k < written) st3(dL_dsh + 3 * k, scale(b[k], dL_dRGB));
-    for (int k = written * 3; k < M * 3; k++) dL_dsh[k] = 0.0f;
+    // constant indices under a predicate (instead of a loop with run-time bounds): the row may live in registers
+#pragma unroll
+    for (int k = 0; k < 48; k++)
+        if (k >= written * 3 && k < M * 3) dL_dsh[k] = 0.0f;
 }
 
 // backward.cu:9-119.  Writes all M coefficient gradients (zeros above the active degree) unless dL_dsh is null (the
