@@ -20,7 +20,7 @@ namespace
 {
 // One triangle.  `vp` = its 9 vertex floats, `shp` = its SH row (3 M floats); either global memory or an LDS row.
 __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int32_t *__restrict__ radii, const GeometryStateView &g,
-                                                   int idx, const float *vp, const float *shp)
+                                                   int idx, const float *vp, const float *shp, float4 *rec_row)
 {
     int out_radius = 0;
     uint32_t out_tiles = 0;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int3
     g.rect[idx] = out_rect;
     g.clamped[idx] = out_clamped;
     g.depth[idx] = out_depth;
-    float4 *r = g.rec + 4 * (size_t)idx;
+    float4 *r = rec_row; // the triangle's 64-byte render record: g.rec + 4 idx, or an LDS row the workgroup writes out in one block
     r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
     r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
     r[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);

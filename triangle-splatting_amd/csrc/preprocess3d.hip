@@ -22,7 +22,7 @@ __device__ __forceinline__ float proj_to_pix(float v, int S) { return (v + 1.0f)
 
 // One triangle; `vp` / `shp` = its vertex / SH rows (global memory or LDS, ts2d_preprocess_launch.h).
 __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, int32_t *__restrict__ radii, const GeometryStateView &g,
-                                                     int idx, const float *vp, const float *shp)
+                                                     int idx, const float *vp, const float *shp, float4 *rec_row)
 {
     int out_radius = 0;
     uint32_t out_tiles = 0;
@@ -94,7 +94,7 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
     g.rect[idx] = out_rect;
     g.clamped[idx] = out_clamped;
     g.depth[idx] = out_depth;
-    float4 *r = g.rec + 4 * (size_t)idx;
+    float4 *r = rec_row; // the triangle's 64-byte render record: g.rec + 4 idx, or an LDS row the workgroup writes out in one block
     r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
     r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
     r[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);

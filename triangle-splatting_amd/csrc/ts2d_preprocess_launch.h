@@ -30,7 +30,7 @@ __global__ void __launch_bounds__(256) preprocess_fwd_direct_kernel(PreprocessAr
     const int idx = blockIdx.x * 256 + threadIdx.x;
     clear_tickets(g, idx);
     if (idx >= a.P) return;
-    Body::fwd(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
+    Body::fwd(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr, g.rec + 4 * (size_t)idx);
 }
 
 // vertex rows always staged; SH rows (SHROW = 3 M > 0 floats) travel either through LDS as well (SH_REGS = false) or straight into
@@ -54,9 +54,22 @@ __global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArg
     if (SHROW > 0 && !SH_REGS) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
     __syncthreads();
     clear_tickets(g, idx);
-    if (idx >= a.P) return;
-    const float *shp = SHROW > 0 ? (SH_REGS ? shr : s_sh + lane * (SHROW + 1)) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
-    Body::fwd(a, radii, g, idx, s_v + lane * 9, shp);
+    // the 64 render records of the workgroup are one contiguous 4 KB block: each lane parks its record in LDS (row stride 80 bytes:
+    // conflict-free 128-bit accesses) and the block leaves with coalesced dwordx4 stores instead of four stores at a 64-byte lane stride
+    __shared__ float4 s_rec[64 * 5];
+    if (idx < a.P)
+    {
+        const float *shp = SHROW > 0 ? (SH_REGS ? shr : s_sh + lane * (SHROW + 1)) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
+        Body::fwd(a, radii, g, idx, s_v + lane * 9, shp, s_rec + lane * 5);
+    }
+    __syncthreads();
+    float4 *out = g.rec + 4 * (size_t)row0;
+#pragma unroll
+    for (int it = 0; it < 4; it++)
+    {
+        const int i = it * 64 + lane;
+        if (row0 + (i >> 2) < a.P) out[i] = s_rec[(i >> 2) * 5 + (i & 3)];
+    }
 }
 
 template <class Body>
