@@ -47,3 +47,33 @@ def test_async_forward_equals_synchronous_and_reports_overflow(variant):
         assert float(args[0].grad.abs().sum()) == 0.0
     finally:
         pkg.set_instance_capacity(None)
+
+
+def test_concurrent_forwards_read_their_own_instance_count():
+    """The instance count reaches the host through a ring of pinned words (api.hip, acquire_early_count): forwards running at the
+    same time on different streams and threads must each get their own."""
+    import threading
+    import torch
+    scenes = [synthetic.scene(20_000 + 7_000 * i, 320, 200, 1, seed=50 + i) for i in range(3)]
+    want = [helpers.hip_forward_backward(s, True, False, backward=False)["num_rendered"] for s in scenes]
+    assert len(set(want)) == 3
+    errors = []
+
+    def worker(i):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(25):
+                    got = helpers.hip_forward_backward(scenes[i], True, False, backward=False)["num_rendered"]
+                    if got != want[i]:
+                        errors.append((i, got, want[i]))
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:3]

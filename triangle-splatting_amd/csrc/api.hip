@@ -168,18 +168,24 @@ int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
                      EarlyCount *early);
 bool acquire_early_count(EarlyCount &e)
 {
-    constexpr int SLOTS = 64; // calls that may be between their copy and their wait at the same time (streams x threads)
+    constexpr int SLOTS = 64, MAXDEV = 16; // calls that may be between their launch and their wait at the same time, per device
     static unsigned long long *ring = [] {
-        void *p = nullptr;
-        return hipHostMalloc(&p, SLOTS * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess ? (unsigned long long *)p : nullptr;
+        void *p = nullptr; // pinned and mapped into every device's address space
+        return hipHostMalloc(&p, (size_t)MAXDEV * SLOTS * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped) == hipSuccess
+                   ? (unsigned long long *)p : nullptr;
     }();
-    static hipEvent_t events[SLOTS] = {};
+    static hipEvent_t events[MAXDEV][SLOTS] = {}; // an event belongs to the device it was created on
     static std::atomic<unsigned> next{0};
-    if (!ring) return false;
+    static std::mutex mu;
+    int dev = 0;
+    if (!ring || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return false;
     const unsigned i = next.fetch_add(1) % SLOTS;
-    if (!events[i] && hipEventCreateWithFlags(&events[i], hipEventDisableTiming) != hipSuccess) return false;
-    e.host = ring + i;
-    e.ev = events[i];
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!events[dev][i] && hipEventCreateWithFlags(&events[dev][i], hipEventDisableTiming) != hipSuccess) return false;
+    }
+    e.host = ring + (size_t)dev * SLOTS + i;
+    e.ev = events[dev][i];
     return true;
 }
 } // namespace
