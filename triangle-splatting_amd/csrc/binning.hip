@@ -524,6 +524,33 @@ void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const Bin
     hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, n_dev, b.tile, im.ranges);
 }
 
+// ---- the same sort for other callers (knn.hip: 30-bit Morton codes) --------------------------------------------------------
+size_t ts_radix_scratch_bytes(size_t n)
+{
+    RadixScratchView r{};
+    char *p = nullptr;
+    ts_carve_radix(p, n, r);
+    return (size_t)p + TS_ALIGN;
+}
+// Stable LSD sort of (key, value) pairs by key bits [0, end_bit).  k[0] / v[0] hold the input, k[1] / v[1] are the ping-pong partners;
+// returns which pair holds the result (passes & 1).
+int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s)
+{
+    if (n == 0) return 0;
+    RadixScratchView r{};
+    char *p = (char *)ts_align_up((size_t)scratch);
+    ts_carve_radix(p, n, r);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((r.slabs + 8 + 255) / 256)), dim3(256), 0, s, r.tickets, r.slabs + 8);
+    const int passes = (end_bit + 7) / 8;
+    int src = 0;
+    for (int ps = 0; ps < passes; ps++)
+    {
+        radix_pass(k[src], v[src], k[src ^ 1], v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), r, s);
+        src ^= 1;
+    }
+    return src;
+}
+
 // ---- rocPRIM comparators (tests/test_binning_gpu.py; never on the product path) --------------------------------------------------
 int ts_compare_sort_pairs_rocprim(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
                                   int end_bit, hipStream_t s)

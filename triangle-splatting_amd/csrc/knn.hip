@@ -14,7 +14,6 @@
 
 #include <cfloat>
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace
 {
@@ -274,10 +273,7 @@ KnnCarve knn_carve(void *ws, int P)
     c.boxes = (Box *)take((size_t)c.nboxes * sizeof(Box));
     c.partial = (Box *)take((size_t)c.npartial * sizeof(Box));
     c.bbox = (Box *)take(sizeof(Box));
-    c.sort_temp_bytes = 0;
-    if (n > 0)
-        (void)rocprim::radix_sort_pairs(nullptr, c.sort_temp_bytes, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr,
-                                        (uint32_t *)nullptr, n, 0, 30, (hipStream_t)0);
+    c.sort_temp_bytes = ts_radix_scratch_bytes(n); // the hand-written radix sort of binning.hip
     c.sort_temp = take(c.sort_temp_bytes);
     c.bytes = (size_t)(p - (char *)ws);
     return c;
@@ -288,10 +284,9 @@ hipError_t knn_prepare(int P, const float *points, const KnnCarve &c, hipStream_
     hipLaunchKernelGGL(bbox_partial_kernel, dim3(c.npartial), dim3(TPB), 0, s, P, points, c.partial);
     hipLaunchKernelGGL(bbox_finish_kernel, dim3(1), dim3(64), 0, s, c.npartial, c.partial, c.bbox);
     hipLaunchKernelGGL(morton_kernel, dim3((P + TPB - 1) / TPB), dim3(TPB), 0, s, P, points, c.bbox, c.codes, c.ids);
-    size_t tb = c.sort_temp_bytes;
-    hipError_t e = rocprim::radix_sort_pairs(c.sort_temp, tb, c.codes, c.codes_sorted, c.ids, c.ids_sorted, (size_t)P, 0, 30, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(gather_boxes_kernel, dim3(c.nboxes), dim3(TPB), 0, s, P, points, c.ids_sorted, c.sp, c.boxes);
+    uint32_t *const k[2] = {c.codes, c.codes_sorted}, *const v[2] = {c.ids, c.ids_sorted};
+    const int at = ts_radix_sort_pairs(k, v, (size_t)P, 30, c.sort_temp, s); // 30-bit Morton codes: four 8-bit passes, stable
+    hipLaunchKernelGGL(gather_boxes_kernel, dim3(c.nboxes), dim3(TPB), 0, s, P, points, v[at], c.sp, c.boxes);
     return hipGetLastError();
 }
 } // namespace

@@ -177,6 +177,8 @@ void ts_launch_count_instances(const GeometryStateView &g, int32_t P, unsigned l
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P);                        // where the scan leaves N
 void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s); // stable, tile bits only
 void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
+size_t ts_radix_scratch_bytes(size_t n);                                                          // the same sort for other callers (knn.hip)
+int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s);
 // rocPRIM comparators (tests only): same contracts as the hand-written steps, results into caller-provided device buffers
 int ts_compare_sort_pairs_rocprim(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
                                   int end_bit, hipStream_t s);
