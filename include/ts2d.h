@@ -135,8 +135,10 @@ size_t ts2d_binning_state_bytes(int64_t num_rendered, int32_t width, int32_t hei
 size_t ts2d_image_state_bytes(int32_t width, int32_t height);
 size_t ts2d_backward_scratch_bytes(int32_t P);
 
-/* Per-triangle preprocess + prefix sum.  Writes radii[P] and the geometry state, then blocks on
- * `stream` once to return num_rendered (the reference's cudaMemcpy at rasterizer.cu:191). */
+/* Per-triangle preprocess, depth order and prefix sum.  Writes radii[P] and the geometry state and returns num_rendered (the
+ * reference's blocking cudaMemcpy, rasterizer.cu:191).  The count is summed right after the per-triangle kernel and handed to the
+ * host through a pinned word; the depth sort and the scan are queued behind it, so on return they may still be running on
+ * `stream` -- the host waits for the count only, never for the whole stream. */
 int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii,
                      const ts2d_state *state, int64_t *num_rendered, void *stream);
 
