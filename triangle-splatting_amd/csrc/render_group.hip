@@ -437,6 +437,18 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
             B = fmaf(dd, a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
         }
     }
+    // The six colour / normal columns of the per-step reduction are (dL_dpixel constant) x contrib: their registers are filled
+    // pre-swapped (ts2d_group.h, row_reduce16c) with constants that depend on which quarter of its 16-lane group the lane is in.
+    // Quad (registers 0..3) = r, b, g, nx by final position; pair (registers 4, 5) = ny, nz.
+    const int quarter = sub >> 2;
+    const float kq0 = quarter == 0 ? dpr : (quarter == 1 ? dpg : (quarter == 2 ? dpb : dnx)); // [X0 X1 Y0 Y1], X0 = r, X1 = g, Y0 = b, Y1 = nx
+    const float kq1 = quarter == 0 ? dpb : (quarter == 1 ? dnx : (quarter == 2 ? dpr : dpg)); // [Y0 Y1 X0 X1]
+    const float kq2 = quarter == 0 ? dpg : (quarter == 1 ? dpr : (quarter == 2 ? dnx : dpb)); // [X1 X0 Y1 Y0]
+    const float kq3 = quarter == 0 ? dnx : (quarter == 1 ? dpb : (quarter == 2 ? dpg : dpr)); // [Y1 Y0 X1 X0]
+    const float kp4 = (sub & 8) ? dnz : dny, kp5 = (sub & 8) ? dny : dnz;
+    // gradient-record column (0..5 screen vertices, 6 opacity, 7..9 rgb, 10..12 normal, 13..15 vertex depths) of the value lane `sub`
+    // ends up with: register reg(sub) of the network, registers -> columns {7, 9, 8, 10, 11, 12, 0, 1, 2, 3, 4, 5, 6, 13, 14, 15}
+    const int rcol = (int)((0xF15ADC39E0486B27ull >> (4 * sub)) & 15ull);
     // entries at list positions >= the largest n_contrib of a block are skipped by all of its pixels (backward.cu:377-379)
     float lm = (float)last;
     lm = fmaxf(lm, dpp<DPP_XOR1>(lm));
@@ -561,17 +573,17 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
                     const float sdot = fmaf(da3, b.a3, fmaf(da2, b.a2, da1 * b.a1));
                     const float e1 = da1 - sdot, e2 = da2 - sdot, e3 = da3 - sdot;
                     float v[16];
-                    v[bitrev4(0)] = e3 * b.p2y - e2 * b.p3y;  // perp(t_1).x =  t_1.y
-                    v[bitrev4(1)] = e2 * b.p3x - e3 * b.p2x;  // perp(t_1).y = -t_1.x
-                    v[bitrev4(2)] = e1 * b.p3y - e3 * b.p1y;
-                    v[bitrev4(3)] = e3 * b.p1x - e1 * b.p3x;
-                    v[bitrev4(4)] = e2 * b.p1y - e1 * b.p2y;
-                    v[bitrev4(5)] = e1 * b.p2x - e2 * b.p1x;
-                    v[bitrev4(6)] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
-                    v[bitrev4(7)] = dpr * contrib; v[bitrev4(8)] = dpg * contrib; v[bitrev4(9)] = dpb * contrib; // backward.cu:412
-                    v[bitrev4(10)] = dnx * contrib; v[bitrev4(11)] = dny * contrib; v[bitrev4(12)] = dnz * contrib; // backward.cu:421-423
-                    v[bitrev4(13)] = w * b.a1; v[bitrev4(14)] = w * b.a2; v[bitrev4(15)] = w * b.a3;             // backward.cu:429-431
-                    const float red = row_reduce16(v, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull); // lane (l & 15): column (l & 15) of its group's entry
+                    v[0] = kq0 * contrib; v[1] = kq1 * contrib; v[2] = kq2 * contrib; v[3] = kq3 * contrib; // dL/drgb, dL/dn.x (backward.cu:412, 421)
+                    v[4] = kp4 * contrib; v[5] = kp5 * contrib;                                             // dL/dn.y, dL/dn.z (:422-423)
+                    v[6] = e3 * b.p2y - e2 * b.p3y;  // perp(t_1).x =  t_1.y
+                    v[7] = e2 * b.p3x - e3 * b.p2x;  // perp(t_1).y = -t_1.x
+                    v[8] = e1 * b.p3y - e3 * b.p1y;
+                    v[9] = e3 * b.p1x - e1 * b.p3x;
+                    v[10] = e2 * b.p1y - e1 * b.p2y;
+                    v[11] = e1 * b.p2x - e2 * b.p1x;
+                    v[12] = hit ? dL_dalpha * G : 0.0f; // backward.cu:490 (not gated by the clamp)
+                    v[13] = w * b.a1; v[14] = w * b.a2; v[15] = w * b.a3; // backward.cu:429-431
+                    const float red = row_reduce16c(v, 0xCCCCCCCCCCCCCCCCull, 0xAAAAAAAAAAAAAAAAull); // lane sub: gradient-record column rcol
                     if (!shared_row) *acc = q0acc + red;
                     else
                     {
@@ -597,8 +609,8 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
                     {
                         const uint32_t eid = __float_as_uint(cst[e * ROW + 17]);
                         float val = sums[e * 16 + sub];
-                        if (sub < 6) val *= cst[e * ROW + 6];
-                        if (RICH || sub < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, val);
+                        if (rcol < 6) val *= cst[e * ROW + 6];
+                        if (RICH || rcol < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + rcol, val);
                     }
                 }
             }

@@ -97,6 +97,46 @@ __device__ __forceinline__ float row_reduce16(float (&v)[16], unsigned long long
 #undef TSG_L3
     return v[15];
 }
+// The same network when six of the sixteen columns are products  k_c(pixel) * x(pixel, entry)  of a per-pixel constant and ONE common
+// per-step factor (the backward's dL/drgb and dL/dnormal: k = dL_dpixel, x = contrib).  A pair (X, Y) of such columns needs one level-1
+// instruction instead of two if the two registers are filled "pre-swapped": v[X] = kA x with kA = column X's constant on lanes 0-7 of
+// the row and column Y's on lanes 8-15, v[Y] = kB x with the two exchanged -- then  Y = ror8(v[Y]) + v[X]  is already the level-1 result.
+// A quad of such columns (two pairs meeting at level 2) continues the idea with constants that depend on the lane's quarter and saves
+// the level-2 instruction too.  Registers 0-3 = the quad, 4-5 = the pair, 6-15 as in row_reduce16: 26 DPP adds
+// instead of 30.  Which lane ends up with which register is unchanged: reg(l) = 8 (l & 1) + 4 ((l >> 1) & 1) + {0, 2, 1, 3}[l >> 2].
+__device__ __forceinline__ float row_reduce16c(float (&v)[16], unsigned long long mask_b1, unsigned long long mask_b0)
+{
+#define TSG_L1(X, Y)                                                                    \
+    "v_add_f32_dpp " Y ", " Y ", " Y " row_ror:8 row_mask:0xf bank_mask:0xc\n"         \
+    "v_add_f32_dpp " Y ", " X ", " X " row_ror:8 row_mask:0xf bank_mask:0x3\n"
+#define TSG_L1C(X, Y) "v_add_f32_dpp " Y ", " Y ", " X " row_ror:8 row_mask:0xf bank_mask:0xf\n"
+#define TSG_L2(X, Y)                                                                    \
+    "v_add_f32_dpp " Y ", " Y ", " Y " row_half_mirror row_mask:0xf bank_mask:0xa\n"   \
+    "v_add_f32_dpp " Y ", " X ", " X " row_half_mirror row_mask:0xf bank_mask:0x5\n"
+#define TSG_L3(X, Y, QP, M)                                                             \
+    "v_add_f32_dpp " X ", " X ", " X " quad_perm:" QP " row_mask:0xf bank_mask:0xf\n"  \
+    "v_add_f32_dpp " Y ", " Y ", " Y " quad_perm:" QP " row_mask:0xf bank_mask:0xf\n"  \
+    "v_cndmask_b32_e64 " Y ", " X ", " Y ", " M "\n"
+    asm volatile("s_nop 1\n"
+                 TSG_L1C("%0", "%1") TSG_L1C("%2", "%3") TSG_L1C("%4", "%5") TSG_L1("%6", "%7")
+                 TSG_L1("%8", "%9") TSG_L1("%10", "%11") TSG_L1("%12", "%13") TSG_L1("%14", "%15")
+                 "v_add_f32_dpp %3, %3, %1 row_half_mirror row_mask:0xf bank_mask:0xf\n" // level 2 of the quad: one instruction
+                 TSG_L2("%5", "%7") TSG_L2("%9", "%11") TSG_L2("%13", "%15")
+                 TSG_L3("%3", "%7", "[2,3,0,1]", "%16") TSG_L3("%11", "%15", "[2,3,0,1]", "%16")
+                 "v_add_f32_dpp %7, %7, %7 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "s_nop 0\n"
+                 "v_add_f32_dpp %15, %15, %15 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n"
+                 "v_cndmask_b32_e64 %15, %7, %15, %17\n"
+                 "s_nop 1\n"
+                 : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                   "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                 : "s"(mask_b1), "s"(mask_b0));
+#undef TSG_L1
+#undef TSG_L1C
+#undef TSG_L2
+#undef TSG_L3
+    return v[15];
+}
 constexpr int bitrev4(int c) { return ((c & 1) << 3) | ((c & 2) << 1) | ((c & 4) >> 1) | ((c & 8) >> 3); }
 
 
