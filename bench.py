@@ -148,7 +148,7 @@ def main():
                 torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
             bucket.reduce_async()
             if factored:
-                state["shs_grad"] = parallel.exchange_factored_sh_grads(sink, vertex, D, M)  # summed over all ranks' views
+                state["shs_grad"] = parallel.exchange_factored_sh_grads(sink, vertex, D, M, uniform=True)  # summed over all ranks' views (one each)
             state["grads"] = bucket.wait()
         else:
             out = raster(vertex, center2D, opacity, shs=shs)

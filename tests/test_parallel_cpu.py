@@ -119,7 +119,7 @@ def _factored_worker(rank, world, port, q):
         # mean mode divides by the world size
         for col, cp in factors(rank):
             sink.append(col, cp)
-        got_mean = parallel.exchange_factored_sh_grads(sink, vertex, 1, M, mean=True, expand_fn=_expand_reference)
+        got_mean = parallel.exchange_factored_sh_grads(sink, vertex, 1, M, mean=True, expand_fn=_expand_reference, uniform=True)  # no agreement round
         ok = ok and torch.allclose(got_mean, want / world, atol=1e-6)
         q.put((rank, bool(ok)))
     finally:

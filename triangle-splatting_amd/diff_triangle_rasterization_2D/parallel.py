@@ -218,11 +218,13 @@ class factored_sh_grads:
 
 
 def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree: int, M: int, group=None,
-                               mean: bool = False, expand_fn=None) -> torch.Tensor:
+                               mean: bool = False, expand_fn=None, uniform: bool = False) -> torch.Tensor:
     """All-gathers the sink's factors over the ranks and returns the dense dL_dshs (P, M, 3) summed over every view of
     every rank (divided by the world size with mean=True, like GradBucket).  Ranks may hold different numbers of views
     (the shorter ones are padded with zero-colour rows).  `expand_fn(vertex, campos (V,3), dL_dcolor (V,P,3), sh_degree, M)` defaults to the HIP kernel behind
-    `_C.sh_grad_expand`; the CPU tests inject a reference implementation to exercise the protocol over gloo."""
+    `_C.sh_grad_expand`; the CPU tests inject a reference implementation to exercise the protocol over gloo.
+    `uniform=True` is the caller's promise that every rank holds the same number of views of the same P triangles (the usual
+    training step): the agreement round -- a small all-reduce and a blocking read per step -- is skipped."""
     if not sink.colors:
         raise RuntimeError("no SH-mode backward pass ran under factored_sh_grads()")
     if expand_fn is None:
@@ -237,7 +239,10 @@ def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree
         local[v, 3 * P:3 * P + 3] = cp
         local[v, 3 * P + 3] = 0.0
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    if world > 1:
+    if world > 1 and uniform:
+        gathered = torch.empty((world * V, 3 * P + 4), device=local.device, dtype=torch.float32)
+        dist.all_gather_into_tensor(gathered, local, group=group)
+    elif world > 1:
         # ranks may hold different numbers of views (shard_views with num_views % world != 0): agree on the largest count
         # and pad with zero-colour rows, which add nothing to the sum; a different triangle count is a caller error
         meta = torch.tensor([V, -V, P, -P], device=local.device, dtype=torch.int64)
