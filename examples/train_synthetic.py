@@ -48,16 +48,7 @@ class Camera:
         self.device = device
 
 
-def exponential_scheduler(v_init, v_final, max_steps):
-    """src/diff_recon/utils/scheduler.py:5-23 without the delay terms."""
-    def f(step):
-        if step <= 0:
-            return v_init
-        if step >= max_steps:
-            return v_final
-        t = step / max_steps
-        return math.exp(math.log(v_init) * (1 - t) + math.log(v_final) * t)
-    return f
+from diff_recon_hip.schedulers import exponential_scheduler  # noqa: E402  (mirror of src/diff_recon/utils/scheduler.py)
 
 
 class SyntheticModel(DensificationStats):
@@ -93,17 +84,9 @@ class SyntheticModel(DensificationStats):
         self.log = []
 
     def model_update(self, iteration, render_pkgs):
-        """VanillaTSModel.model_update (:560-575), same order."""
-        for pkg in render_pkgs:
-            self.update(pkg)  # _training_statistic
-        mu = self.config.model_update
-        for name in ("densification", "opacity_pruning", "opacity_clipping", "scale_pruning", "scale_clipping", "contribution_pruning", "opacity_reset"):
-            res = getattr(D, name)(self, iteration)
-            if res is not None:
-                self.log.append((iteration, name, res, self._vertex.shape[0]))
-        if mu.gamma_schedule.start_iter < iteration <= mu.gamma_schedule.end_iter:  # _set_gamma
-            self.gamma = self.gamma_scheduler(iteration - mu.gamma_schedule.start_iter)
-        self.active_sh_degree = min(sum(iteration > it for it in mu.sh_schedule.one_up_iters), self.max_sh_degree)  # _set_sh_degree
+        """VanillaTSModel.model_update (:567-581), same order (diff_recon_hip.model_update.run_model_update)."""
+        for name, res in D.run_model_update(self, iteration, render_pkgs):
+            self.log.append((iteration, name, res, self._vertex.shape[0]))
 
 
 def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, seed=0, views=2, views_per_step=2, log=print, updates=True):

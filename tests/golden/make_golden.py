@@ -284,9 +284,47 @@ def model_update(rng):
     print("model_update.npz:", {k: out[f"{k}/vertex"].shape[0] for k in cases})
 
 
+
+# ---- schedules.npz: the reference's value schedules (utils/scheduler.py) and _set_gamma / _set_sh_degree ----------------------------
+def schedules():
+    sched = load("scheduler")
+    steps = np.array([-5, 0, 1, 2, 7, 50, 99, 100, 101, 250, 499, 500, 501, 2999, 3000, 10_000, 29_999, 30_000, 40_000])
+    out = {"steps": steps}
+    exp_cases = [(1.6e-4, 1.6e-6, 30_000, 0, 1.0), (1.0, 50.0, 25_000, 0, 1.0), (0.02, 0.05, 500, 0, 1.0), (1e-2, 1e-4, 3000, 100, 0.01),
+                 (5.0, 0.5, 100, 250, 0.5)]
+    out["exp_cases"] = np.array(exp_cases, dtype=np.float64)
+    out["exp_values"] = np.array([[float(sched.exponential_scheduler(a, b, int(m), int(d), dm)(int(t))) for t in steps] for a, b, m, d, dm in exp_cases])
+    out["step_values_a"] = np.array([sched.step_scheduler([1.0, 2.0, 4.0, 8.0], [100, 500, 3000])(int(t)) for t in steps])
+    out["step_values_b"] = np.array([sched.step_scheduler([3.0, 2.0, 1.0], [1, 100, 501])(int(t)) for t in steps])
+    es_cases = [(1.0, 50.0, 25_000, 10, 0, 1.0), (1e-2, 1e-4, 3000, 4, 100, 0.01)]
+    out["es_cases"] = np.array(es_cases, dtype=np.float64)
+    out["es_values"] = np.array([[float(sched.exponential_step_scheduler(a, b, int(m), int(n), int(d), dm)(int(t))) for t in steps]
+                                 for a, b, m, n, d, dm in es_cases])
+    # _set_gamma / _set_sh_degree on the reference's model object (methods only; no tensors involved)
+    Model, Logger = load_reference_model_class()
+    NS = types.SimpleNamespace
+    m = Model.__new__(Model)
+    m.config = NS(model_update=NS(gamma_schedule=NS(start_iter=500, end_iter=25_500), sh_schedule=NS(one_up_iters=[1000, 2000, 3000, 9000])))
+    m.gamma_scheduler = sched.exponential_scheduler(1.0, 50.0, 25_000)
+    m.max_sh_degree = 3
+    m.gamma, m.active_sh_degree = 1.0, 0
+    iters = np.array([1, 499, 500, 501, 1000, 1001, 2001, 3001, 9001, 13_000, 25_500, 25_501, 30_000])
+    g, d = [], []
+    for it in iters:
+        m._set_gamma(int(it))
+        m._set_sh_degree(int(it))
+        g.append(float(m.gamma))
+        d.append(int(m.active_sh_degree))
+    out.update(model_iters=iters, model_gamma=np.array(g), model_sh_degree=np.array(d))
+    np.savez(os.path.join(HERE, "schedules.npz"), **out)
+    print("schedules.npz:", out["exp_values"].shape, out["es_values"].shape)
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "model_update":
         model_update(np.random.default_rng(1))  # only this fixture (the others are unchanged since round 1)
+    elif len(sys.argv) > 1 and sys.argv[1] == "schedules":
+        schedules()
     else:
         main()
         model_update(np.random.default_rng(1))
+        schedules()

@@ -8,6 +8,8 @@
                           prune_points / densification / opacity_pruning / opacity_clipping / scale_pruning / scale_clipping /
                           opacity_reset / contribution_pruning with their Adam-state surgery on native row operators
                           (reference: src/diff_recon/models/VanillaTS_model.py:194-201, 214-345, 347-537)
+    schedulers.py         exponential_scheduler / step_scheduler / exponential_step_scheduler, gamma_at, sh_degree_at
+                          (reference: src/diff_recon/utils/scheduler.py:5-45, VanillaTS_model.py:548-565; pinned by tests/golden/schedules.npz)
     raw_triangle.py       RawTriangle with loadPLY / savePLY / saveGLB / loadGLB: the on-disk formats of a triangle model, numpy only
                           (reference: src/diff_recon/models/raw_triangle.py:12-33, 124-223)
     model_forward.py      render_view = the argument construction of VanillaTSModel.forward
@@ -19,5 +21,6 @@ from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss  #
 from .triangle_renderer import TriangleRenderer  # noqa: F401
 from .model_forward import gamma_rescale_ratio, rescale_triangles, ste_opacity, render_view  # noqa: F401
 from .model_update import (DensificationStats, prune_points, densification, opacity_pruning, opacity_clipping, scale_pruning,  # noqa: F401
-                           scale_clipping, opacity_reset, contribution_pruning)
+                           scale_clipping, opacity_reset, contribution_pruning, set_gamma, set_sh_degree, run_model_update)
+from . import schedulers  # noqa: F401
 from .raw_triangle import RawTriangle  # noqa: F401

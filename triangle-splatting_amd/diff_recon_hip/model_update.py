@@ -407,3 +407,37 @@ def contribution_pruning(m, iteration: int, inter_point_distance=None, get_insid
     m.contrib_denom[select_mask] = 0
     prune_points(m, prune_mask)
     return int(prune_idx.shape[0])
+
+
+def set_gamma(m, iteration: int):
+    """VanillaTSModel._set_gamma (:548-553)."""
+    from .schedulers import gamma_at
+    args = m.config.model_update.gamma_schedule
+    if args is not None:
+        m.gamma = gamma_at(iteration, m.gamma, args.start_iter, args.end_iter, m.gamma_scheduler)
+
+
+def set_sh_degree(m, iteration: int):
+    """VanillaTSModel._set_sh_degree (:555-565)."""
+    from .schedulers import sh_degree_at
+    args = m.config.model_update.sh_schedule
+    if args is not None:
+        m.active_sh_degree = sh_degree_at(iteration, args.one_up_iters, m.max_sh_degree)
+
+
+def run_model_update(m, iteration: int, render_pkgs=()):
+    """VanillaTSModel.model_update (:567-581), same order: statistics of the step's views, densification, the pruning / clipping
+    rules, opacity reset, then the gamma and SH-degree schedules.  `m` carries the reference's attribute names and inherits
+    DensificationStats (its `update` is `_training_statistic`).  Returns [(rule, result)] of the rules that fired."""
+    if m.config.model_update is None:
+        return []
+    for pkg in render_pkgs:
+        m.update(pkg)
+    fired = []
+    for rule in (densification, opacity_pruning, opacity_clipping, scale_pruning, scale_clipping, contribution_pruning, opacity_reset):
+        res = rule(m, iteration)
+        if res is not None:
+            fired.append((rule.__name__, res))
+    set_gamma(m, iteration)
+    set_sh_degree(m, iteration)
+    return fired
