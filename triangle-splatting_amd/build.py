@@ -37,6 +37,7 @@ SOURCES = {
     "binning.hip": [],
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
+    "render_q8.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render3d_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "api.hip": [],

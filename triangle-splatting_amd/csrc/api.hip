@@ -152,7 +152,7 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     // measurement / triage switches, read ONCE per process (none of them is needed by the product path)
     static const int s_ablate = [] { const char *e = getenv("TS2D_ABLATE"); return e ? atoi(e) : 0; }();
     static const int s_mfma = [] { const char *e = getenv("TS2D_BWD"); return (e && strcmp(e, "mfma") == 0) ? 1 : 0; }();
-    static const int s_legacy = [] { const char *e = getenv("TS2D_BLEND"); return (e && strcmp(e, "wave") == 0) ? 1 : 0; }();
+    static const int s_legacy = [] { const char *e = getenv("TS2D_BLEND"); return (e && strcmp(e, "wave") == 0) ? 1 : (e && strcmp(e, "q8") == 0) ? 3 : 0; }();
     r.ablate = s_ablate;
     r.bwd_mfma = s_mfma;
     r.legacy_blend = s_legacy;
@@ -296,14 +296,16 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     }
     {
         ProfScope ps("render_fwd", s);
-        if ((flags & TS2D_FLAG_3D) && r.legacy_blend)
+        if ((flags & TS2D_FLAG_3D) && r.legacy_blend == 1)
             ts_launch_render3d_fwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
                                    out->contrib_sum, out->contrib_max, s);
         else if (flags & TS2D_FLAG_3D)
             ts_launch_render3d_fwd_group(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
                                          out->contrib_sum, out->contrib_max, s);
-        else if (r.legacy_blend)
+        else if (r.legacy_blend == 1)
             ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+        else if (r.legacy_blend == 3)
+            ts_launch_render_fwd_q8(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
         else
             ts_launch_render_fwd_group(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
     }
@@ -446,14 +448,16 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     if (N > 0)
     {
         ProfScope ps("render_bwd", s);
-        if ((flags & TS2D_FLAG_3D) && r.legacy_blend)
+        if ((flags & TS2D_FLAG_3D) && r.legacy_blend == 1)
             ts_launch_render3d_bwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
                                    loss->dL_dout_normal, grad_rec, s);
         else if (flags & TS2D_FLAG_3D)
             ts_launch_render3d_bwd_group(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
                                          loss->dL_dout_normal, grad_rec, s);
-        else if (r.legacy_blend || r.bwd_mfma)
+        else if (r.legacy_blend == 1 || r.bwd_mfma)
             ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
+        else if (r.legacy_blend == 3)
+            ts_launch_render_bwd_q8(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
         else
             ts_launch_render_bwd_group(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
     }

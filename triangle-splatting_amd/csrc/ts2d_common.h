@@ -209,6 +209,11 @@ void ts_launch_render_fwd_group(const RenderArgs &a, const GeometryStateView &g,
 void ts_launch_render_bwd_group(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                                 const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
                                 const float *dL_dout_normal, float *grad_rec, hipStream_t s);
+// queue kernels (render_q8.hip): eight 4x2 pixel blocks per wave, each walking its own queue of triangles; the default
+void ts_launch_render_fwd_q8(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
+                             float *out_feature, float *out_depth, float *out_normal, float *contrib_sum, float *contrib_max, hipStream_t s);
+void ts_launch_render_bwd_q8(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
+                             const float *dL_dout_feature, const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec, hipStream_t s);
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                               float *dL_dfeature, float *dL_dopacity, hipStream_t s);
