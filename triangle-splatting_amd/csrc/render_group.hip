@@ -38,8 +38,12 @@
 namespace
 {
 // ROW (ts2d_group.h) = 20 floats per entry row of the constants table:
-//   [0..3] u1x u1y u2x u2y   [4..7] u3x u3y 1/area2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [17] id
-// (u_k = screen vertex k relative to the quadrant origin); row -1 is a dummy that fails every pixel's ecc test.
+//   [0..3] u1x u1y u2x u2y   [4..7] u3x u3y 1/area2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [17] id   [18] position in the batch
+// (u_k = screen vertex k relative to the quadrant origin); row -1 is a dummy that fails every pixel's ecc test.  The backward appends the
+// entry's 16 gradient sums to the row (BROW floats).  A list entry is the LDS BYTE OFFSET of its row (u16): the step loops spend no
+// instruction on unpacking or scaling an index (round 3: four half-rate instructions per step gone; gfx950 issues shifts, bit-field
+// extracts and 24-bit multiply-adds at half rate, tools/valu_bench3.hip).
+constexpr int BROW = ROW + 16;
 
 struct BlockCull
 {
@@ -47,14 +51,14 @@ struct BlockCull
     bool ov[4]; // the triangle's support (alpha >= 1/255 and ecc <= 10) can reach block g = (by >> 2) * 2 + (bx >> 2)
 };
 
-__device__ __forceinline__ void publish_row(float *row, const BlockCull &s, uint32_t id, const float4 &r1, const float4 &r2, const float4 &r3)
+__device__ __forceinline__ void publish_row(float *row, const BlockCull &s, uint32_t id, int jpos, const float4 &r1, const float4 &r2, const float4 &r3)
 {
     float4 *q = (float4 *)row;
     q[0] = make_float4(s.u1x, s.u1y, s.u2x, s.u2y);
     q[1] = make_float4(s.u3x, s.u3y, s.ia, r1.z);
     q[2] = make_float4(r1.w, r2.x, r2.y, r2.z);
     q[3] = make_float4(r2.w, r3.x, r3.y, r3.z);
-    q[4] = make_float4(r3.w, __uint_as_float(id), 0.0f, 0.0f);
+    q[4] = make_float4(r3.w, __uint_as_float(id), __int_as_float(jpos), 0.0f);
 }
 
 // The part of the setup that ends up in the entry's table row: vertices relative to the quadrant origin, 1 / area2.
@@ -70,14 +74,14 @@ __device__ __forceinline__ void entry_geometry(BlockCull &s, float v1x, float v1
 // first gather's registers alive across the first pass would cost the occupancy the compaction buys.
 template <bool RICH>
 __device__ __forceinline__ uint32_t republish_row(float *row, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, uint32_t pos,
-                                                  float OX, float OY)
+                                                  int jpos, float OX, float OY)
 {
     const uint32_t id = point_list[pos];
     const float4 *rp = rec + 4 * (size_t)id;
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = RICH ? rp[3] : make_float4(0, 0, 0, 0);
     BlockCull s;
     entry_geometry(s, r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, OX, OY);
-    publish_row(row, s, id, r1, r2, r3);
+    publish_row(row, s, id, jpos, r1, r2, r3);
     return id;
 }
 
@@ -127,7 +131,7 @@ __device__ __forceinline__ BlockCull block_cull(float v1x, float v1y, float v2x,
 }
 
 // Row -1: a unit triangle a thousand pixels away with opacity 0 -> every pixel of the quadrant sees ecc ~ 3000 and alpha 0.
-__device__ __forceinline__ void write_dummy_row(float *cst, int lane)
+__device__ __forceinline__ void write_dummy_row(float *row, int lane)
 {
     if (lane < ROW)
     {
@@ -135,7 +139,8 @@ __device__ __forceinline__ void write_dummy_row(float *cst, int lane)
         if (lane == 0 || lane == 1 || lane == 3 || lane == 4) v = 1000.0f;
         if (lane == 2 || lane == 5) v = 1001.0f;
         if (lane == 6) v = 1.0f;
-        cst[lane - ROW] = v;
+        if (lane == 18) v = __int_as_float(255); // batch position of the dummy: beyond every pixel's range
+        row[lane] = v;
     }
 }
 
@@ -204,7 +209,9 @@ __global__ void __launch_bounds__(256, 6) render_fwd_group_kernel(RenderArgs a, 
     const float bg0 = a.background[0], bg1 = a.C > 1 ? a.background[1] : 0.0f, bg2 = a.C > 2 ? a.background[2] : 0.0f;
     float *cst = cst_all[wave] + ROW;
     uint32_t *list = list_all[wave];
-    write_dummy_row(cst, lane);
+    write_dummy_row(cst - ROW, lane);
+    const char *lds0 = (const char *)cst_all;                                      // list entries are byte offsets from here
+    const uint32_t row0 = (uint32_t)(wave * (NR + 1) + 1) * (ROW * 4), dummy = row0 - ROW * 4; // row r of this wave: row0 + r * 80
     const RowSel rsel(lane);
     const int my_slot = (lane >> 3 & 1) + ((lane >> 2 & 1) << 1) + ((lane >> 1 & 1) << 2); // which of a window's 8 steps this lane reports
 
@@ -248,28 +255,28 @@ __global__ void __launch_bounds__(256, 6) render_fwd_group_kernel(RenderArgs a, 
         const int rank = lane_rank(any), nact = __popcll(any);
         const int r = rank & (NR - 1);
         bool mine = anybit && rank < NR;
-        if (mine) publish_row(cst + r * ROW, s, id, r1, r2, r3);
+        if (mine) publish_row(cst + r * ROW, s, id, lane, r1, r2, r3);
         for (int h = 0;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
-            list[lane] = 0xFFFFFFFFu; // four lists x NR entries of (row -1, position 255)
+            list[lane] = dummy | (dummy << 16); // four lists x NR entries: the dummy row
             int steps = 0;
 #pragma unroll
             for (int g = 0; g < 4; g++)
             {
                 const unsigned long long Mh = M[g] & mm;
-                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + lane_rank(Mh)] = (unsigned short)(r | (lane << 8));
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + lane_rank(Mh)] = (unsigned short)(row0 + r * (ROW * 4));
                 steps = max(steps, __popcll(Mh));
             }
-            const uint32_t *mylist = list + grp * (NR / 2);
+            const u16a *mylist = (const u16a *)list + grp * NR;
             TSG_STAT(2, steps);
             TSG_STAT(3, (steps + 7) / 8);
 #ifdef TS2D_STATS
             {   // [8] steps at which two groups hold the same entry (what the backward must serialise)  [9] passes  [10] second passes
                 const u16a *l16 = (const u16a *)list + (lane & (NR - 1));
-                const int l0 = l16[0] & 0xFF, l1 = l16[NR] & 0xFF, l2 = l16[2 * NR] & 0xFF, l3 = l16[3 * NR] & 0xFF;
-                TSG_STAT(8, __popcll(ballot(lane < NR && ((l0 != 0xFF && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != 0xFF && (l1 == l2 || l1 == l3)) ||
-                                                          (l2 != 0xFF && l2 == l3)))));
+                const uint32_t l0 = l16[0], l1 = l16[NR], l2 = l16[2 * NR], l3 = l16[3 * NR];
+                TSG_STAT(8, __popcll(ballot(lane < NR && ((l0 != dummy && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != dummy && (l1 == l2 || l1 == l3)) ||
+                                                          (l2 != dummy && l2 == l3)))));
                 TSG_STAT(9, 1);
                 TSG_STAT(10, h > 0 ? 1 : 0);
             }
@@ -279,7 +286,7 @@ __global__ void __launch_bounds__(256, 6) render_fwd_group_kernel(RenderArgs a, 
             {
                 float c[8];
                 uint32_t cjc[8];
-                const uint4 packed = *(const uint4 *)(mylist + (t0 >> 1)); // this group's next 8 entries
+                const uint4 packed = *(const uint4 *)(mylist + t0); // this group's next 8 entries (row byte offsets)
 #pragma unroll
                 for (int st = 0; st < 8; st++)
                 {
@@ -288,20 +295,22 @@ __global__ void __launch_bounds__(256, 6) render_fwd_group_kernel(RenderArgs a, 
                     if (t0 + st < steps)
                     {
                         const uint32_t word = st < 2 ? packed.x : (st < 4 ? packed.y : (st < 6 ? packed.z : packed.w));
-                        const uint32_t e16 = (word >> (16 * (st & 1))) & 0xFFFFu;
-                        const int jc = (int)(signed char)(e16 & 0xFFu), jpos = (int)(e16 >> 8); // table row, position in the batch
-                        const float *row = cst + jc * ROW;
+                        const float *row = (const float *)(lds0 + ((st & 1) ? (word >> 16) : (word & 0xFFFFu)));
                         const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
                         const Bary b = barycentrics(q0, q1, fx, fy);
                         const float4 q2 = *(const float4 *)(row + 8);
                         float4 q3 = make_float4(0, 0, 0, 0);
                         float vd3 = 0.0f;
+                        int jpos; // position in the batch
                         if (RICH)
                         {
                             q3 = *(const float4 *)(row + 12);
-                            vd3 = row[16];
+                            const float4 q4 = *(const float4 *)(row + 16);
+                            vd3 = q4.x;
+                            jpos = __float_as_int(q4.z);
                             cjc[st] = (uint32_t)jpos;
                         }
+                        else jpos = __float_as_int(row[18]);
                         const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
                         const float alpha = fminf(0.99f, q1.w * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:311-312
                         const bool hit = !done && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f;                     // forward.cu:307,313
@@ -344,7 +353,7 @@ __global__ void __launch_bounds__(256, 6) render_fwd_group_kernel(RenderArgs a, 
             }
             if (++h * NR >= nact) break;
             mine = anybit && rank >= NR;
-            if (mine) republish_row<RICH>(cst + r * ROW, point_list, rec, range.x + base + lane, OX, OY);
+            if (mine) republish_row<RICH>(cst + r * ROW, point_list, rec, range.x + base + lane, lane, OX, OY);
         }
     }
 
@@ -396,9 +405,8 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
                                                                    const float *__restrict__ dL_dout_depth,
                                                                    const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
-    __shared__ __attribute__((aligned(16))) float cst_all[4][(NR + 1) * ROW];
-    __shared__ __attribute__((aligned(16))) float sums_all[4][(NR + 1) * 16]; // row -1 absorbs the adds of idle groups
-    __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2];  // per group: NR entries of (row | batch position << 8)
+    __shared__ __attribute__((aligned(16))) float rows_all[4][(NR + 1) * BROW]; // constants + gradient sums; row -1 absorbs the adds of idle groups
+    __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2];   // per group: NR entries (u16 byte offsets of rows)
 #ifdef TSG_PAD_LDS
     __shared__ int pad_lds_b[TSG_PAD_LDS / 4];
     if (a.W < 0) pad_lds_b[threadIdx.x] = 1, list_all[0][0] = (signed char)pad_lds_b[255 - threadIdx.x];
@@ -416,10 +424,12 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
     const uint2 range = ranges[tile];
     const float g2 = 2.0f * a.gamma;
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
-    float *cst = cst_all[wave] + ROW;
-    float *sums = sums_all[wave] + 16;
+    float *rows = rows_all[wave] + BROW;
     uint32_t *list = list_all[wave];
-    write_dummy_row(cst, lane);
+    write_dummy_row(rows - BROW, lane);
+    char *lds0 = (char *)rows_all;                                                   // list entries are byte offsets from here
+    const uint32_t row0 = (uint32_t)(wave * (NR + 1) + 1) * (BROW * 4), dummy = row0 - BROW * 4; // row r of this wave: row0 + r * 144
+    const uint32_t accoff = ROW * 4 + 4 * sub;                                        // this lane's sum inside a row
 
     float T = inside ? final_T[pix] : 0.0f;            // backward.cu:318
     const int last = inside ? (int)n_contrib[pix] : 0; // backward.cu:320
@@ -491,23 +501,23 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
         const int lrel = last - base; // entries [0, lrel) of this batch are in front of the pixel's last contributor
         const int r = rank & (NR - 1);
         bool mine = anybit && (rank / NR) == (nact - 1) / NR;
-        if (mine) publish_row(cst + r * ROW, s, id, r1, r2, r3);
+        if (mine) publish_row(rows + r * BROW, s, id, lane, r1, r2, r3);
         for (int h = (nact - 1) / NR;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
             if (mine)
             {
-                float4 *z = (float4 *)(sums + r * 16);
+                float4 *z = (float4 *)(rows + r * BROW + ROW);
                 z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
             }
-            list[lane] = 0xFFFFFFFFu;
+            list[lane] = dummy | (dummy << 16);
             int steps = 0;
 #pragma unroll
             for (int g = 0; g < 4; g++) // back to front: the entry with the highest list position first
             {
                 const unsigned long long Mh = M[g] & mm;
                 const int n = __popcll(Mh);
-                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (n - 1 - lane_rank(Mh))] = (unsigned short)(r | (lane << 8));
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (n - 1 - lane_rank(Mh))] = (unsigned short)(row0 + r * (BROW * 4));
                 steps = max(steps, n);
             }
             const u16a *mylist = (const u16a *)list + grp * NR;
@@ -516,17 +526,16 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
             unsigned long long conflict;
             {
                 const u16a *l16 = (const u16a *)list + (lane & (NR - 1));
-                const int l0 = l16[0] & 0xFF, l1 = l16[NR] & 0xFF, l2 = l16[2 * NR] & 0xFF, l3 = l16[3 * NR] & 0xFF;
-                conflict = ballot(lane < NR && ((l0 != 0xFF && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != 0xFF && (l1 == l2 || l1 == l3)) ||
-                                                (l2 != 0xFF && l2 == l3)));
+                const uint32_t l0 = l16[0], l1 = l16[NR], l2 = l16[2 * NR], l3 = l16[3 * NR];
+                conflict = ballot(lane < NR && ((l0 != dummy && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != dummy && (l1 == l2 || l1 == l3)) ||
+                                                (l2 != dummy && l2 == l3)));
             }
             for (int t0 = 0; t0 < steps; t0++)
             {
                 {
-                    const uint32_t e16 = mylist[t0]; // this group's next entry; past the end of its list: row -1 = the dummy
-                    const int jc = (int)(signed char)(e16 & 0xFFu), jpos = (int)(e16 >> 8);
-                    const float *row = cst + jc * ROW;
-                    float *acc = sums + jc * 16 + sub;
+                    const uint32_t ra = mylist[t0]; // this group's next entry; past the end of its list: the dummy row
+                    const float *row = (const float *)(lds0 + ra);
+                    float *acc = (float *)(lds0 + ra + accoff);
                     const bool shared_row = TSG_PROBE == 3 ? false : (bool)((conflict >> t0) & 1); // wave-uniform
                     const float q0acc = *acc;                              // fetched early; only used when no other group adds to this row now
                     const float4 q0 = *(const float4 *)(row), q1 = *(const float4 *)(row + 4);
@@ -534,11 +543,15 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
                     const float4 q2 = *(const float4 *)(row + 8);
                     float4 q3 = make_float4(0, 0, 0, 0);
                     float vd3 = 0.0f;
+                    int jpos; // position in the batch
                     if (RICH)
                     {
                         q3 = *(const float4 *)(row + 12);
-                        vd3 = row[16];
+                        const float4 q4 = *(const float4 *)(row + 16);
+                        vd3 = q4.x;
+                        jpos = __float_as_int(q4.z);
                     }
+                    else jpos = __float_as_int(row[18]);
                     const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
                     const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f); // exp(-0.5 pw)
                     const float opG = q1.w * G;
@@ -564,7 +577,10 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
                     const float dL_dalpha = dL_dcontrib * T;
                     // backward.cu:443-447: dL_decc = dL_dpower * 2 gamma * power / (ecc + 1e-8) with power = -0.5 pw and
                     // dL_dpower = dL_dalpha * alpha unless the 0.99 clamp was active; z = -3 dL_decc goes to the arg-min barycentric
-                    const float zr = 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(b.ecc + 1e-8f);
+                    // (for gamma = 1, pw / (ecc + 1e-8) is ecc to 1e-8 / ecc relative, and a pair with ecc that small contributes ~ecc to begin
+                    // with: one multiplication instead of a reciprocal)
+                    const float zr = GAMMA1 ? 1.5f * g2 * (dL_dalpha * alpha) * b.ecc
+                                            : 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(b.ecc + 1e-8f);
                     const float z = (hit && opG < 0.99f) ? zr : 0.0f; // the select sits last: a lane that does not hit may hold inf / NaN in pw
                     const bool k1 = b.a1 == b.mn;        // backward.cu:449-461: a1 <= a2 && a1 <= a3, then a2 <= a1 && a2 <= a3, else a3
                     const bool k2 = !k1 && b.a2 == b.mn;
@@ -607,16 +623,16 @@ __global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, 
                     const int e = e0 + grp;
                     if (e < n)
                     {
-                        const uint32_t eid = __float_as_uint(cst[e * ROW + 17]);
-                        float val = sums[e * 16 + sub];
-                        if (rcol < 6) val *= cst[e * ROW + 6];
+                        const uint32_t eid = __float_as_uint(rows[e * BROW + 17]);
+                        float val = rows[e * BROW + ROW + sub];
+                        if (rcol < 6) val *= rows[e * BROW + 6];
                         if (RICH || rcol < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + rcol, val);
                     }
                 }
             }
             if (--h < 0) break;
             mine = anybit && rank < NR;
-            if (mine) republish_row<RICH>(cst + r * ROW, point_list, rec, range.x + base + lane, OX, OY);
+            if (mine) republish_row<RICH>(rows + r * BROW, point_list, rec, range.x + base + lane, lane, OX, OY);
         }
     }
 }
