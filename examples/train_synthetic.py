@@ -68,6 +68,7 @@ class SyntheticModel(DensificationStats):
         q = max(iters // 4, 1)
         every = lambda a, b, k, **kw: NS(start_iter=a, end_iter=b, hold_iter=b, interval_iter=k, **kw)
         self.config = NS(model_update=NS(
+            statistic=NS(start_iter=0, end_iter=iters),  # the window in which _training_statistic accumulates (VanillaTS_model.py:348-350)
             densification=every(q // 2, 3 * q, max(q // 3, 1), min_view_count=8, split_num=2, split_scale_threshold=60.0),
             opacity_pruning=every(q, iters, max(q // 2, 1)), opacity_clipping=every(q, iters, max(q // 2, 1)),
             scale_pruning=every(q, iters, q, radii_threshold=200.0, scale_threshold=200.0), scale_clipping=every(q, iters, max(q // 2, 1)),

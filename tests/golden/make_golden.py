@@ -280,6 +280,21 @@ def model_update(rng):
         with torch.no_grad():
             m._training_statistic(it + 1, pkg)
     snapshot(m, "training_statistic", out)
+    # the statistic WINDOW (:348-350): model_update over the same three iterations with statistic.start_iter = 1, end_iter = 2 -- only
+    # iteration 2 may move the accumulators; every other rule of the sequence is switched off so that the snapshot isolates the window
+    m = fresh()
+    for name in ("densification", "opacity_pruning", "opacity_clipping", "scale_pruning", "scale_clipping", "contribution_pruning", "opacity_reset",
+                 "gamma_schedule", "sh_schedule"):
+        setattr(m.config.model_update, name, None)
+    m.config.model_update.statistic = NS(start_iter=1, end_iter=2)
+    for it in range(3):
+        c2d = torch.zeros((P, 2), requires_grad=True)
+        c2d.grad = torch.from_numpy(out[f"statistic_in{it}/center2D_grad"])
+        radii = torch.from_numpy(out[f"statistic_in{it}/radii"])
+        pkg = {"center2D": c2d, "visible_mask": radii > 0, "radii": radii, "contrib_sum": torch.from_numpy(out[f"statistic_in{it}/contrib_sum"]),
+               "contrib_max": torch.from_numpy(out[f"statistic_in{it}/contrib_max"])}
+        m.model_update(it + 1, pkg)
+    snapshot(m, "statistic_window", out)
     np.savez_compressed(os.path.join(HERE, "model_update.npz"), **out)
     print("model_update.npz:", {k: out[f"{k}/vertex"].shape[0] for k in cases})
 

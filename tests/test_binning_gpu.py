@@ -99,3 +99,36 @@ def test_tiny_scene_in_recycled_state_buffers(P, variant):
         hf = helpers.hip_forward_backward(s, True, False, variant=variant)
         assert hf["num_rendered"] == of["num_rendered"]
         assert helpers.rel_l2(hf["out_feature"], of["out_feature"]) < 1e-4
+
+
+def test_last_arrival_handoffs_under_uneven_load():
+    """Every block-to-block hand-off of the binning kernels (per-slab / per-pass prefixes of the radix sort, the scan's block sums: write-through
+    stores, a drained ticket, sc1 loads in the last-arriving block -- a gfx950 hardware contract, binning.hip) repeated under UNEVEN load:
+    a second stream keeps some CUs busy with streaming copies and matrix products while sorts of several sizes run back to back on
+    the first, so that producers and the elected consumer meet on busy and idle CUs, same and different XCDs, warm and cold L1s.
+    Every result is compared bit for bit against numpy's stable sort; 60 sorts x up to 6 passes x 2 hand-off levels."""
+    import torch
+    rng = np.random.default_rng(2026)
+    side = torch.cuda.Stream()
+    big = torch.empty((64 << 20,), device="cuda", dtype=torch.float32)
+    a = torch.randn((2048, 2048), device="cuda")
+    stop = torch.cuda.Event()
+    sizes = [65_537, 262_145, 1_000_003, 300_007, 4_100_001, 70_001]
+    bad = 0
+    for it in range(60):
+        n = sizes[it % len(sizes)]
+        end_bit = [13, 32, 21, 32, 13, 8][it % 6]
+        keys = rng.integers(0, 2 ** min(end_bit, 32), n, dtype=np.uint64).astype(np.uint32)
+        if it % 3 == 0:
+            keys = (keys >> 7) << 7  # long runs of equal digits in the low passes
+        vals = np.arange(n, dtype=np.uint32)
+        with torch.cuda.stream(side):  # uneven neighbour load: a few large copies and GEMMs of varying length
+            for _ in range(1 + it % 4):
+                big[: (16 << 20) * (1 + it % 3)].mul_(1.0001)
+                a = (a @ a).clamp_(-1, 1)
+        ko, vo = _sort(keys, vals, end_bit, 0)
+        order = np.argsort(keys, kind="stable")
+        if not (np.array_equal(ko, keys[order]) and np.array_equal(vo, vals[order])):
+            bad += 1
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} of 60 sorts differ from the stable reference under load"

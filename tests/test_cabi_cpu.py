@@ -40,6 +40,19 @@ def test_library_exports_every_declared_symbol(lib):
         assert hasattr(lib, name), f"libts2d.so does not export {name}"
 
 
+def test_product_library_reads_no_environment_and_has_one_blend_path(hip_lib_built):
+    """libts2d.so carries one blend kernel family per variant (the lane-group kernels) and no run-time switch: the measurement
+    kernels of earlier rounds and their TS2D_BLEND / TS2D_BWD / TS2D_ABLATE variables exist only in tools/bin/libts2d_lab.so."""
+    import subprocess
+    blob = open(hip_lib_built, "rb").read()
+    for name in (b"TS2D_BLEND", b"TS2D_BWD", b"TS2D_ABLATE"):
+        assert name not in blob, name
+    syms = subprocess.run(["nm", "-D", "--defined-only", hip_lib_built], capture_output=True, text=True).stdout
+    launchers = sorted(set(re.findall(r"ts_launch_render\w*?(?=RK)", syms)))
+    assert launchers, "nm found no blend launchers"
+    assert all("group" in n for n in launchers), launchers
+
+
 def test_state_size_queries_are_monotone_and_aligned(lib):
     lib.ts2d_geometry_state_bytes.restype = ctypes.c_size_t
     lib.ts2d_geometry_state_bytes.argtypes = [ctypes.c_int32]

@@ -65,4 +65,4 @@ def test_reference_built_cameras(i, variant):
         T2._check_outputs(hf, of, ob, True)
     else:
         T3._check_state3d(s, hf, of)
-        T3._check_outputs(s, hf, of, ob, True)
+        T3._check_outputs(s, hf, of, ob, True, back=back_culling)

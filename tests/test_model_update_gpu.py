@@ -97,6 +97,36 @@ def test_training_statistic_matches_the_reference_method():
         np.testing.assert_allclose(getattr(stats, n).cpu().numpy(), z[f"training_statistic/{n}"], rtol=1e-6, atol=0, err_msg=n)
 
 
+def test_statistic_window_of_the_update_driver_matches_the_reference():
+    """VanillaTSModel.model_update (:567-581) with statistic.start_iter = 1, end_iter = 2 over iterations 1..3: only iteration 2 may move
+    the accumulators (`_training_statistic` returns early outside (start_iter, end_iter], :348-350).  Replayed through run_model_update."""
+    import torch
+    import diff_recon_hip as D
+    from diff_recon_hip import DensificationStats
+    z = np.load(GOLD)
+
+    class Model(DensificationStats):  # the reference's model object inherits the statistics arrays; same here
+        pass
+
+    m = Model.__new__(Model)
+    m.__dict__.update(vars(_model(z)))
+    P = z["input/gradient_accum"].shape[0]
+    for name in ("densification", "opacity_pruning", "opacity_clipping", "scale_pruning", "scale_clipping", "contribution_pruning", "opacity_reset"):
+        setattr(m.config.model_update, name, None)
+    m.config.model_update.gamma_schedule = m.config.model_update.sh_schedule = None
+    m.config.model_update.statistic = NS(start_iter=1, end_iter=2)
+    for it in range(3):
+        c2d = torch.zeros((P, 2), device="cuda", requires_grad=True)
+        c2d.grad = torch.from_numpy(z[f"statistic_in{it}/center2D_grad"]).cuda()
+        pkg = {"radii": torch.from_numpy(z[f"statistic_in{it}/radii"]).cuda(), "center2D": c2d,
+               "contrib_sum": torch.from_numpy(z[f"statistic_in{it}/contrib_sum"]).cuda(),
+               "contrib_max": torch.from_numpy(z[f"statistic_in{it}/contrib_max"]).cuda()}
+        assert D.run_model_update(m, it + 1, [pkg, None]) == []
+    for n in STATS:
+        np.testing.assert_allclose(getattr(m, n).cpu().numpy(), z[f"statistic_window/{n}"], rtol=1e-6, atol=0, err_msg=n)
+    assert not np.array_equal(z["statistic_window/gradient_denom"], z["training_statistic/gradient_denom"])  # the window matters in this fixture
+
+
 def test_statistics_without_rich_info_prune_grow_and_errors():
     import torch
     from diff_recon_hip import DensificationStats

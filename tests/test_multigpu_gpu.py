@@ -121,3 +121,40 @@ def test_two_ranks_one_view_each_equals_one_rank_two_views(variant):
         assert p.exitcode == 0
     res = [q.get(timeout=10) for _ in range(2)]
     assert all(ok for _, ok, _ in res), res
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_two_views_under_one_capture_are_not_double_counted(variant):
+    """Several views per rank under ONE capture with LEAF parameters (the reference's triangle_renderer passes model._vertex itself,
+    zero_grad(set_to_none=True) leaves .grad None): the bucket must hold g1 + g2 -- not g1 + 2 g2, which is what happens when autograd's
+    AccumulateGrad aliases param.grad to the bucket's view --, the parameters' .grad must stay untouched and every view's own center2D
+    tensor must get its own gradient (the per-view densification statistic)."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path[:0] = [root, os.path.join(root, "triangle-splatting_amd")]
+    import synthetic
+    from diff_triangle_rasterization_2D import parallel
+    dev = torch.device("cuda", 0)
+    s = synthetic.scene(P, W, H, D, seed=78)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    mk = lambda: (t(s["vertex"]).requires_grad_(True), t(s["shs"]).requires_grad_(True), t(s["opacity"]).requires_grad_(True))
+    vertex, shs, opacity = mk()
+    bucket = parallel.GradBucket([vertex.shape, opacity.shape, torch.Size((P, 2)), shs.shape], dev, names=["vertex", "opacity", "center2D", "color"])
+    c2ds = []
+    with bucket.capture():
+        for r in range(2):
+            _, c2d = _render(s, _view(r), variant, dev, vertex, shs, opacity)
+            c2ds.append(c2d)
+    assert vertex.grad is None and opacity.grad is None and shs.grad is None  # the gradients live in the bucket
+    got = dict(zip(("vertex", "opacity", "center2D", "color"), bucket.wait()))
+    v2, s2, o2 = mk()
+    ref_c2d = []
+    for r in range(2):
+        _, c2d = _render(s, _view(r), variant, dev, v2, s2, o2)
+        ref_c2d.append(c2d.grad.clone())
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    assert rel(got["vertex"], v2.grad) < 2e-5 and rel(got["opacity"], o2.grad) < 2e-5 and rel(got["color"], s2.grad) < 2e-5
+    assert rel(got["center2D"], ref_c2d[0] + ref_c2d[1]) < 2e-5
+    for mine, ref in zip(c2ds, ref_c2d):  # per-view statistic, untouched by the later view
+        assert mine.grad is not None and mine.grad.data_ptr() != got["center2D"].data_ptr()
+        assert rel(mine.grad, ref) < 2e-5

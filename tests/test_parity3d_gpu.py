@@ -1,9 +1,11 @@
 """GPU parity tests of the 3D variant (rasterizer_type "3D"): the HIP path selected by
 TS2D_FLAG_3D (through diff_triangle_rasterization_3D -> ctypes -> C ABI) against the CPU oracle's variant=3.
 
-Same bars as test_parity_gpu.py.  The blend kernels evaluate the barycentrics as N_k(q)/Den(q) with N_k, Den affine
-in the pixel offset (render3d.hip) where the oracle follows the reference's per-pixel ray/plane expressions, so
-floating-point outputs are compared with tolerances; all integer state must match bit for bit."""
+All integer state must match the oracle bit for bit.  The floating-point outputs are held to ONE criterion (helpers.py,
+"THE criterion for the floating-point outputs of the 3D variant"): without any outlier budget or mask, the product must sit inside
+the spread of the reference's own three builds (oracle/_ref: hipcc defaults, -fno-slp-vectorize, -ffp-contract=off = the oracle).
+Only where those builds are unavailable (oracle/_ref absent, or the reference process died on a degenerate configuration) the
+comparison falls back to the oracle alone, with every deviating triangle EXPLAINED in float64 (arg-min tie / edge-on view)."""
 import numpy as np
 import pytest
 
@@ -89,7 +91,15 @@ def _check_geometry_grads(s, of, hip, ora, name, scale=None):
     assert np.sqrt((err[keep] ** 2).sum()) / ref < GRAD_TOL, name
 
 
-def _check_outputs(s, hf, of, ob, rich, use_feature=False):
+def _check_outputs(s, hf, of, ob, rich, use_feature=False, back=False, fuzz_seed=None):
+    builds = helpers.ref3d_builds(s, rich, back, use_feature, fuzz_seed=fuzz_seed)
+    if builds is not None:
+        # the -ffp-contract=off build is what the oracle restates: identical integer state, and the product inside the builds' spread
+        nofma = builds["_ref3d_nofma_C"]
+        assert hf["num_rendered"] == nofma["num_rendered"] and np.array_equal(hf["radii"], nofma["radii"])
+        helpers.assert_inside_reference_spread_3d(hf, builds, what=f"seed {fuzz_seed}" if fuzz_seed is not None else "")
+        return
+    # fallback (no reference build at hand): the oracle alone, every deviating triangle explained in float64
     assert helpers.rel_l2(hf["out_feature"], of["out_feature"]) < IMG_TOL
     if rich:
         for k in ("depth", "normal", "contrib_sum", "contrib_max"):
@@ -121,7 +131,7 @@ def test_hip3d_matches_oracle(P, W, H, D, rich, gamma, back_culling, kw):
     ob = helpers.oracle_backward(s, of, rich)
     hf = helpers.hip_forward_backward(s, rich, back_culling, variant=3)
     _check_state3d(s, hf, of)
-    _check_outputs(s, hf, of, ob, rich)
+    _check_outputs(s, hf, of, ob, rich, back=back_culling)
 
 
 def test_feature_mode_3d():

@@ -9,6 +9,8 @@ Bars (BASELINE.json north_star / SURVEY.md 8c):
 The HIP blend kernels use FMA contraction and v_exp/v_log where the oracle uses glibc expf/powf without
 contraction, hence tolerances rather than bit equality on floating-point outputs.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -216,16 +218,29 @@ def test_full_size_properties(P, W, H, D, variant):
         assert float((2.5 * a - b2).norm() / b2.norm()) < 2e-4  # fp32 atomics: summation order differs between runs
 
 
-def test_mfma_backward_variant_matches(monkeypatch):
-    """TS2D_BWD=mfma (render.hip: per-entry sums on the matrix cores through an LDS transposition tile) against the oracle."""
-    monkeypatch.setenv("TS2D_BWD", "mfma")
-    for P, W, H, D, rich, gamma in [(3000, 130, 70, 3, True, 1.0), (4000, 96, 96, 1, False, 2.0)]:
-        s = synthetic.scene(P, W, H, D, seed=77)
-        s["gamma"] = gamma
-        of = helpers.oracle_forward(s, rich)
-        ob = helpers.oracle_backward(s, of, rich)
-        hf = helpers.hip_forward_backward(s, rich)
-        _check_outputs(hf, of, ob, rich)
+LAB_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libts2d_lab.so")
+
+
+@pytest.mark.parametrize("env", [{"TS2D_BWD": "mfma"}, {"TS2D_BLEND": "wave"}, {"TS2D_BLEND": "q8"}], ids=["bwd-mfma", "whole-quadrant", "queues"])
+def test_lab_library_variants_match(env):
+    """The measurement kernels of earlier rounds live in tools/bin/libts2d_lab.so only (python triangle-splatting_amd/build.py --lab):
+    render.hip (whole-quadrant kernels; TS2D_BWD=mfma = per-entry sums on the matrix cores), render_q8.hip (queue kernels).  Each
+    runs in its own process (the library and its switches are read once) against the oracle."""
+    import json
+    import subprocess
+    import sys
+    if not os.path.exists(LAB_LIB):
+        pytest.skip("tools/bin/libts2d_lab.so not built")
+    e = dict(os.environ, TS2D_LIBRARY_PATH=LAB_LIB, **env)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab_worker.py")], env=e, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("LAB_RESULT ")][-1][len("LAB_RESULT "):])
+    # the round-1 kernels evaluate the barycentrics as affine forms: their geometry gradients carry ~1e-3 on slivers (DESIGN.md section 2)
+    grad_tol = 4 * GRAD_TOL if env.get("TS2D_BLEND") == "wave" or env.get("TS2D_BWD") == "mfma" else GRAD_TOL
+    for case in res:
+        for k, v in case.items():
+            assert v < (grad_tol if k.startswith("dL_") else IMG_TOL), (env, k, v)
 
 
 @pytest.mark.parametrize("P,W,H,D,variant", [
@@ -244,9 +259,9 @@ def test_full_size_against_oracle(P, W, H, D, variant):
     tests/test_reference_gpu.py::test_headline_size_three_way_noise_floor).  Round 1 needed a budget of 205 triangles here:
     its blend kernels evaluated the barycentrics as affine forms of the pixel offset, ~10x noisier than the reference's
     pixel-relative cross products on sub-pixel slivers (profiles/r02_noise_floor_1M_before.json).
-    3D rasterizer (render3d.hip, not yet moved to the reference-form arithmetic): triangles seen within 2.9 degrees of
-    edge-on are set aside (there the reference's own fp32 ray/plane arithmetic is off by per cents)
-    plus a budget of 2e-4 of the triangles for discrete flips; set-aside rows must still be within 10x their own scale."""
+    3D rasterizer (render3d_group.hip, the reference's per-pixel ray / plane expressions): integer state bit-exact against the oracle,
+    floating-point outputs by the ONE criterion for the 3D variant (helpers.py): inside the spread of the reference's own three builds,
+    no budget and no mask."""
     import os
     if (os.cpu_count() or 1) < 32:
         pytest.skip("full-size oracle runs need a many-core host")
@@ -262,33 +277,15 @@ def test_full_size_against_oracle(P, W, H, D, variant):
                               of["state"].field(name).astype(np.int64).reshape(-1)), name
     nc_h = helpers.hip_state(hf, s, "n_contrib").astype(np.int64)
     assert (nc_h != of["state"].field("n_contrib").astype(np.int64)).mean() <= OUTLIER_FRAC
-    for k in ("out_feature", "depth", "normal"):
-        assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k
-    grazing = None
-    if variant == 3:
-        grazing = helpers.grazing_mask(of, T3.GRAZING_COS)
-        assert grazing.mean() < 0.1
     if variant == 2:
+        for k in ("out_feature", "depth", "normal"):
+            assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k
         for k in ("contrib_sum", "contrib_max"):
             assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k
         for k in ("dL_dshs", "dL_dopacity", "dL_dvertex", "dL_dcenter2D"):
             assert helpers.rel_l2(hf[k], ob[k]) < GRAD_TOL, (k, helpers.rel_l2(hf[k], ob[k]))
         return
-    budget = int(2e-4 * P) + 5
-    for k in ("contrib_sum", "contrib_max"):
-        assert helpers.robust_rel_l2(hf[k], of[k], budget, grazing) < IMG_TOL, k
-    for k in ("dL_dshs", "dL_dopacity"):
-        assert helpers.robust_rel_l2(hf[k], ob[k], budget, grazing) < GRAD_TOL, k
-    # its dL_dcenter2D -- the view-space xy of the SUM of the three vertex gradients, which largely cancel
-    # (R3D backward.cu:211-213) -- is measured against the vertex gradients it is summed from
-    # The bar for the 3D geometry gradients is the reference's distance to ITSELF: its own sources built with and without the SLP
-    # vectorizer differ by 8.2e-2 un-budgeted and by 2.2e-3 after setting aside the 25 worst triangles (tests/test_reference_gpu.py::
-    # test_3d_variant_sits_inside_the_references_own_spread, profiles/r02_noise_floor3d_93k.json); the oracle is the -ffp-contract=off
-    # build of the reference to 1e-6, the product fuses like the vectorizer-free build.
-    tol3d = 2.5 * GRAD_TOL
-    assert helpers.robust_rel_l2(hf["dL_dvertex"], ob["dL_dvertex"], budget, grazing) < tol3d
-    vref = np.linalg.norm(ob["dL_dvertex"].astype(np.float64))
-    assert helpers.robust_rel_l2(hf["dL_dcenter2D"], ob["dL_dcenter2D"], budget, grazing, ref=vref) < tol3d
+    T3._check_outputs(s, hf, of, ob, True)
 
 
 def test_backward_when_the_loss_ignores_the_rich_outputs():

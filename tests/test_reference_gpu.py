@@ -48,16 +48,7 @@ def _compare(a, b, rich, img_tol, grad_tol, what, s=None, of=None, variant=2):
         for k in ("dL_dvertex", "dL_dcenter2D"):
             assert helpers.rel_l2(a[k], b[k]) < grad_tol, (what, k, helpers.rel_l2(a[k], b[k]))
     else:
-        # 3D: the ray/plane barycentrics carry ~1e-5 of fp32 noise in ANY evaluation (the reference build and the oracle
-        # differ from each other as much as the product differs from either), which flips discrete decisions for a few
-        # pairs and is unbounded for triangles seen edge-on: those are set aside (grazing mask + a budget of 0.2 % of the
-        # triangles), the rest must meet the bar; dL_dcenter2D is measured against the vertex gradients it is summed from.
-        P = len(b["dL_dvertex"])
-        graz = helpers.grazing_mask(of, T3.GRAZING_COS)
-        budget = max(3, P // 500)
-        vref = np.linalg.norm(b["dL_dvertex"].astype(np.float64))
-        assert helpers.robust_rel_l2(a["dL_dvertex"], b["dL_dvertex"], budget, graz) < grad_tol, (what, "dL_dvertex")
-        assert helpers.robust_rel_l2(a["dL_dcenter2D"], b["dL_dcenter2D"], budget, graz, ref=vref) < grad_tol, (what, "dL_dcenter2D")
+        raise AssertionError("the 3D variant is compared through helpers.assert_inside_reference_spread_3d")
 
 
 @pytest.mark.parametrize("variant", [2, 3])
@@ -65,10 +56,29 @@ def _compare(a, b, rich, img_tol, grad_tol, what, s=None, of=None, variant=2):
 def test_oracle_and_hip_against_the_reference_build(P, W, H, D, rich, gamma, back_culling, kw, variant):
     s = synthetic.scene(P, W, H, D, seed=2468 + P + variant, **kw)
     s["gamma"] = gamma
-    rf = ref_build.forward_backward(s, rich, back_culling, variant=variant)
     of = helpers.oracle_forward(s, rich, back_culling, variant=variant)
     ob = helpers.oracle_backward(s, of, rich)
     oracle = dict(of, **ob)
+    if variant == 3:
+        # ONE criterion for the 3D variant (helpers.py): (a) the oracle IS the reference's -ffp-contract=off build -- every output to
+        # 2e-5 un-budgeted, identical integer state -- which pins it; (b) oracle and product sit inside the spread of the reference's
+        # three builds, no budget, no mask
+        builds = helpers.ref3d_builds(s, rich, back_culling)
+        if builds is None:
+            pytest.skip("oracle/_ref not built")
+        nofma = builds["_ref3d_nofma_C"]
+        assert oracle["num_rendered"] == nofma["num_rendered"] and np.array_equal(oracle["radii"], nofma["radii"])
+        for k in helpers.R3D_BARS:
+            if k in nofma and oracle.get(k) is not None and k in ("out_feature", "depth", "normal", "contrib_sum", "contrib_max", "dL_dshs", "dL_dopacity", "dL_dvertex", "dL_dcenter2D"):
+                if not rich and k in ("depth", "normal", "contrib_sum", "contrib_max"):
+                    continue
+                assert helpers._dist3d(k, oracle[k], nofma[k]) < 2e-5, ("oracle vs the reference's -ffp-contract=off build", k)
+        helpers.assert_inside_reference_spread_3d(oracle, builds, "oracle")
+        hf = helpers.hip_forward_backward(s, rich, back_culling, variant=variant)
+        assert hf["num_rendered"] == nofma["num_rendered"] and np.array_equal(hf["radii"], nofma["radii"])
+        helpers.assert_inside_reference_spread_3d(hf, builds, "HIP")
+        return
+    rf = ref_build.forward_backward(s, rich, back_culling, variant=variant)
     # (a) the oracle restates the reference (the reference build contracts FMAs and uses the device's exp / pow, the oracle
     # does neither: agreement at the 1e-5 level, asserted at the product's bars)
     _compare(oracle, rf, rich, IMG_TOL, GRAD_TOL, "oracle vs reference build", s, of, variant)
@@ -246,53 +256,55 @@ def test_random_configurations_against_the_reference_build(seed):
     import test_fuzz_gpu as F
     ref_build.load("_ref2d_C")  # skips when oracle/_ref is absent
     s, variant, rich, back, use_feature = F._case(1000 + seed)
+    hf = helpers.hip_forward_backward(s, rich, back, use_feature=use_feature, variant=variant)
+    if variant == 3:
+        # ONE criterion for the 3D variant (helpers.py); the three builds run in their own process, and where that process dies on a
+        # signal (the reference faults on some degenerate inputs it was never exercised on) the configuration is compared with the
+        # oracle instead -- it is never skipped
+        of = helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant)
+        if of["num_rendered"] == 0:
+            assert hf["num_rendered"] == 0
+            return
+        ob = helpers.oracle_backward(s, of, rich, use_feature=use_feature)
+        T3._check_state3d(s, hf, of, use_feature=use_feature)
+        T3._check_outputs(s, hf, of, ob, rich, use_feature=use_feature, back=back, fuzz_seed=1000 + seed)
+        return
+    rf = None
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, "ref.npz")
         worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_worker.py")
         # own process: the reference aborts on some degenerate inputs, which must not end the test session
         r = subprocess.run([sys.executable, worker, str(1000 + seed), out], capture_output=True, timeout=300)
-        # skip ONLY when the reference process was killed by a signal (its kernels fault on some degenerate inputs it was
-        # never exercised on); any other failure -- an import error, a Python exception in the worker -- fails the test
-        if r.returncode < 0:
-            pytest.skip(f"the reference build died on this configuration (signal {-r.returncode})")
-        assert r.returncode == 0 and os.path.exists(out), (r.returncode, r.stderr.decode(errors="replace")[-2000:])
-        z = np.load(out)
-        rf = {k: (int(z[k]) if k == "num_rendered" else z[k]) for k in z.files}
-    hf = helpers.hip_forward_backward(s, rich, back, use_feature=use_feature, variant=variant)
+        # a reference process killed by a SIGNAL (its kernels fault on some degenerate inputs it was never exercised on) does not excuse
+        # the configuration: it is then compared with the oracle, under the bars of tests/test_fuzz_gpu.py; any other failure -- an
+        # import error, a Python exception in the worker -- fails the test
+        if r.returncode >= 0:
+            assert r.returncode == 0 and os.path.exists(out), (r.returncode, r.stderr.decode(errors="replace")[-2000:])
+            z = np.load(out)
+            rf = {k: (int(z[k]) if k == "num_rendered" else z[k]) for k in z.files}
+    if rf is None:
+        F.test_random_configuration(1000 + seed)
+        return
     _same_integer_state(hf, rf, f"seed {seed}")
     if rf["num_rendered"] == 0:
         return
     assert helpers.rel_l2(hf["out_feature"], rf["out_feature"]) < IMG_TOL
     if rich:
-        graz = None
-        if variant == 3:
-            of = helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant)
-            graz = helpers.grazing_mask(of, T3.GRAZING_COS)
-        for k in ("depth", "normal"):
+        for k in ("depth", "normal", "contrib_sum", "contrib_max"):
             assert helpers.rel_l2(hf[k], rf[k]) < IMG_TOL, k
-        for k in ("contrib_sum", "contrib_max"):
-            assert helpers.robust_rel_l2(hf[k], rf[k], 0 if variant == 2 else 2, graz) < IMG_TOL, k
-    P = len(rf["dL_dvertex"])
     gk = "dL_dfeature" if use_feature else "dL_dshs"
     for k in ("dL_dopacity", gk):
         assert helpers.rel_l2(hf[k], rf[k]) < GRAD_TOL, k
     vref = np.linalg.norm(rf["dL_dvertex"].astype(np.float64))
     if vref == 0:
         return
-    if variant == 2:
-        # No outlier budget.  These scenes are small (P <= 4000), so ONE discrete decision (arg-min barycentric, alpha >= 1/255,
-        # T <= 1e-4) that flips between two fp32 evaluations can move the whole gradient norm by more than the bar (the reference
-        # build's screen vertices differ from the contraction-free product's and oracle's by ulps).  The criterion is therefore
-        # the three-way one of the headline test: the product meets the bar against the reference outright, or it is no
-        # further from the reference than 1.5 x the distance between the oracle and the reference on the same scene.
-        of = helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant)
-        ob = helpers.oracle_backward(s, of, rich, use_feature=use_feature)
-        for k in ("dL_dvertex", "dL_dcenter2D"):
-            d_hr, d_or = helpers.rel_l2(hf[k], rf[k]), helpers.rel_l2(ob[k], rf[k])
-            assert d_hr < GRAD_TOL or d_hr <= 1.5 * d_or, (k, d_hr, d_or)
-        return
-    # 3D variant (render3d.hip): discrete-flip budget + edge-on triangles set aside, see test_full_size_against_oracle
-    budget = max(3, P // 500) if P > 20 else 1
-    graz = helpers.grazing_mask(helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant), T3.GRAZING_COS)
-    assert helpers.robust_rel_l2(hf["dL_dvertex"], rf["dL_dvertex"], budget, graz) < GRAD_TOL
-    assert helpers.robust_rel_l2(hf["dL_dcenter2D"], rf["dL_dcenter2D"], budget, graz, ref=vref) < GRAD_TOL
+    # No outlier budget.  These scenes are small (P <= 4000), so ONE discrete decision (arg-min barycentric, alpha >= 1/255,
+    # T <= 1e-4) that flips between two fp32 evaluations can move the whole gradient norm by more than the bar (the reference
+    # build's screen vertices differ from the contraction-free product's and oracle's by ulps).  The criterion is therefore
+    # the three-way one of the headline test: the product meets the bar against the reference outright, or it is no
+    # further from the reference than 1.5 x the distance between the oracle and the reference on the same scene.
+    of = helpers.oracle_forward(s, rich, back, use_feature=use_feature, variant=variant)
+    ob = helpers.oracle_backward(s, of, rich, use_feature=use_feature)
+    for k in ("dL_dvertex", "dL_dcenter2D"):
+        d_hr, d_or = helpers.rel_l2(hf[k], rf[k]), helpers.rel_l2(ob[k], rf[k])
+        assert d_hr < GRAD_TOL or d_hr <= 1.5 * d_or, (k, d_hr, d_or)

@@ -1,8 +1,11 @@
 """Builds libts2d.so (the C-ABI HIP library of include/ts2d.h) for gfx950 with hipcc, in-tree.
 
-    python triangle-splatting_amd/build.py [--force] [--verbose]
+    python triangle-splatting_amd/build.py [--force] [--verbose] [--lab]
 
 Output: triangle-splatting_amd/diff_triangle_rasterization_2D/libts2d.so (git-ignored, travels with gpurun).
+--lab builds tools/bin/libts2d_lab.so instead: the same objects + the measurement kernels of earlier rounds (render.hip, render3d.hip,
+render_q8.hip) and api.hip compiled with -DTS2D_LAB, which reads TS2D_BLEND / TS2D_BWD / TS2D_ABLATE.  The product library contains
+one blend path per variant and reads no environment; only tools/ and tests/ load the lab library (TS2D_LIBRARY_PATH, see _C.py).
 hipcc cross-compiles without a GPU.  Per-file flags matter:
   * preprocess.hip is built with -ffp-contract=off (bit-comparable integer state, see the file header);
   * render.hip uses the default fast contraction and hardware float atomics (-munsafe-fp-atomics).
@@ -35,13 +38,17 @@ SOURCES = {
     "knn.hip": [],
     "model_update.hip": [],
     "binning.hip": [],
-    "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
-    "render_q8.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
-    "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render3d_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "api.hip": [],
 }
+LAB_SOURCES = {  # measurement kernels: libts2d_lab.so only
+    "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
+    "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
+    "render_q8.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
+    "api.hip": ["-DTS2D_LAB"],
+}
+LAB_LIB = os.path.join(os.path.dirname(HERE), "tools", "bin", "libts2d_lab.so")
 HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
            os.path.join("..", "..", "include", "ts_knn.h"),
@@ -69,13 +76,22 @@ def _newest_header() -> float:
     return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
     os.makedirs(OBJ_DIR, exist_ok=True)
     cc = hipcc()
     hdr_t = max(_newest_header(), os.path.getmtime(os.path.abspath(__file__)))
     jobs, objs = [], []
-    for src, extra in SOURCES.items():
-        s = os.path.join(CSRC, src)
+    sources = dict(SOURCES)
+    lib = LIB
+    if lab:
+        build(force, verbose)  # the product's objects are shared
+        sources = {k: v for k, v in SOURCES.items() if k != "api.hip"}
+        sources.update({("lab/" + k): v for k, v in LAB_SOURCES.items()})
+        lib = LAB_LIB
+        os.makedirs(os.path.join(OBJ_DIR, "lab"), exist_ok=True)
+        os.makedirs(os.path.dirname(LAB_LIB), exist_ok=True)
+    for src, extra in sources.items():
+        s = os.path.join(CSRC, os.path.basename(src))
         o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         cmd = [cc, *COMMON, *extra, "-c", s, "-o", o]
@@ -105,14 +121,15 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(compile_one, jobs))
-    if jobs or force or not os.path.exists(LIB):
-        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs])
-    return LIB
+    if jobs or force or not os.path.exists(lib) or os.path.getmtime(lib) < max(os.path.getmtime(o) for o in objs):
+        run([cc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib, *objs])
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--lab", action="store_true")
     a = ap.parse_args()
-    print(build(a.force, a.verbose))
+    print(build(a.force, a.verbose, a.lab))

@@ -149,13 +149,18 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.gamma = geom->gamma; r.background_depth = geom->background_depth;
     r.background = geom->background;
     r.rich_info = flags & TS2D_FLAG_RICH_INFO;
-    // measurement / triage switches, read ONCE per process (none of them is needed by the product path)
+    r.ablate = r.bwd_mfma = r.legacy_blend = 0;
+#ifdef TS2D_LAB
+    // libts2d_lab.so only (tools/build_lab.py; never the product library): measurement / triage kernels selected by environment
+    // variables, read ONCE per process.  TS2D_BLEND=wave: round 1's whole-quadrant kernels (render.hip, render3d.hip);
+    // TS2D_BLEND=q8: round 3's queue kernels (render_q8.hip); TS2D_BWD=mfma: render_bwd with f32 MFMA sums; TS2D_ABLATE: ablations.
     static const int s_ablate = [] { const char *e = getenv("TS2D_ABLATE"); return e ? atoi(e) : 0; }();
     static const int s_mfma = [] { const char *e = getenv("TS2D_BWD"); return (e && strcmp(e, "mfma") == 0) ? 1 : 0; }();
     static const int s_legacy = [] { const char *e = getenv("TS2D_BLEND"); return (e && strcmp(e, "wave") == 0) ? 1 : (e && strcmp(e, "q8") == 0) ? 3 : 0; }();
     r.ablate = s_ablate;
     r.bwd_mfma = s_mfma;
     r.legacy_blend = s_legacy;
+#endif
     return r;
 }
 // Early read-back of the instance count (binning.hip, count_instances_kernel): a pinned host word + an event per call in flight
@@ -296,16 +301,19 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     }
     {
         ProfScope ps("render_fwd", s);
+#ifdef TS2D_LAB
         if ((flags & TS2D_FLAG_3D) && r.legacy_blend == 1)
             ts_launch_render3d_fwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
                                    out->contrib_sum, out->contrib_max, s);
-        else if (flags & TS2D_FLAG_3D)
+        else if (!(flags & TS2D_FLAG_3D) && r.legacy_blend == 1)
+            ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+        else if (!(flags & TS2D_FLAG_3D) && r.legacy_blend == 3)
+            ts_launch_render_fwd_q8(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
+        else
+#endif
+        if (flags & TS2D_FLAG_3D)
             ts_launch_render3d_fwd_group(r, cam->tan_fovx, cam->tan_fovy, g, b, im, out->out_feature, out->depth, out->normal,
                                          out->contrib_sum, out->contrib_max, s);
-        else if (r.legacy_blend == 1)
-            ts_launch_render_fwd(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
-        else if (r.legacy_blend == 3)
-            ts_launch_render_fwd_q8(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
         else
             ts_launch_render_fwd_group(r, g, b, im, out->out_feature, out->depth, out->normal, out->contrib_sum, out->contrib_max, s);
     }
@@ -448,16 +456,19 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     if (N > 0)
     {
         ProfScope ps("render_bwd", s);
+#ifdef TS2D_LAB
         if ((flags & TS2D_FLAG_3D) && r.legacy_blend == 1)
             ts_launch_render3d_bwd(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
                                    loss->dL_dout_normal, grad_rec, s);
-        else if (flags & TS2D_FLAG_3D)
+        else if (!(flags & TS2D_FLAG_3D) && (r.legacy_blend == 1 || r.bwd_mfma))
+            ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
+        else if (!(flags & TS2D_FLAG_3D) && r.legacy_blend == 3)
+            ts_launch_render_bwd_q8(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
+        else
+#endif
+        if (flags & TS2D_FLAG_3D)
             ts_launch_render3d_bwd_group(r, cam->tan_fovx, cam->tan_fovy, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth,
                                          loss->dL_dout_normal, grad_rec, s);
-        else if (r.legacy_blend == 1 || r.bwd_mfma)
-            ts_launch_render_bwd(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
-        else if (r.legacy_blend == 3)
-            ts_launch_render_bwd_q8(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
         else
             ts_launch_render_bwd_group(r, g, b, im, loss->dL_dout_feature, loss->dL_dout_depth, loss->dL_dout_normal, grad_rec, s);
     }

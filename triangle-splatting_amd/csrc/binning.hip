@@ -51,6 +51,12 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, int lane) //
 // launch and returns true on all of its threads.  Data handed to the elected block travels as write-through (sc0 sc1) stores and
 // L1-bypassing (sc1) loads on both sides (peer_store / peer_load): with every store drained (s_waitcnt vmcnt(0)) before the ticket
 // is taken, no L2 write-back fence is needed (MI355X_MICROARCH.md, "valid forms": a release fence per block costs 2-6 us).
+// This is a HARDWARE contract of gfx950 (write-through sc0 sc1 stores + drain on the producer, sc1 loads on the consumer, both relaxed in
+// the language's memory model), not something the HIP memory model promises: hence the target check below, and
+// tests/test_binning_gpu.py::test_last_arrival_handoffs_under_uneven_load hammers every hand-off next to a noisy neighbour stream.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "last_arrival() relies on gfx950's write-through store / L1-bypassing load behaviour; re-validate before building for another target"
+#endif
 __device__ __forceinline__ bool last_arrival(uint32_t *ticket, uint32_t count)
 {
     __shared__ bool elected;

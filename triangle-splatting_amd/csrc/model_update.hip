@@ -10,6 +10,9 @@
 #include "ts2d_common.h"
 #include "ts2d_wave.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mask_count_kernel's block hand-off relies on gfx950's write-through store / L1-bypassing load behaviour; re-validate before building for another target"
+#endif
 namespace
 {
 __global__ void __launch_bounds__(256) training_statistic_kernel(int P, int V, const int32_t *__restrict__ radii,
@@ -78,6 +81,8 @@ __global__ void __launch_bounds__(256) mask_count_kernel(int P, const uint8_t *_
     const int nblocks = gridDim.x;
     if (t == 0)
     {
+        // same hand-off as binning.hip's last_arrival(): write-through store, drained, then the ticket; sc1 loads in the elected block --
+        // a gfx950 hardware contract (MI355X_MICROARCH.md "valid forms"), checked for the target at the top of this file
         __hip_atomic_store(blocksum + blockIdx.x, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const uint32_t tk = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -150,7 +150,7 @@ def scatter_rows(src: torch.Tensor, pos: torch.Tensor, dst: torch.Tensor, dst_ro
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor, dst: torch.Tensor, dst_row0: int = 0):
     """dst[dst_row0 + j] = src[idx[j]]."""
-    if idx.shape[0] == 0:
+    if idx.shape[0] == 0 or src.numel() == 0 or _row_bytes(src) == 0:  # zero-width rows: f_rest is (P, 0, 3) when max_sh_degree = 0
         return
     src = src.contiguous()
     with torch.cuda.device(src.device):
@@ -431,8 +431,14 @@ def run_model_update(m, iteration: int, render_pkgs=()):
     DensificationStats (its `update` is `_training_statistic`).  Returns [(rule, result)] of the rules that fired."""
     if m.config.model_update is None:
         return []
-    for pkg in render_pkgs:
-        m.update(pkg)
+    # _training_statistic (:347-350) returns early when config.model_update.statistic is None, outside (start_iter, end_iter], or
+    # without a render package: outside that window the accumulators must not move (densification, scale and contribution pruning
+    # select on them)
+    args = m.config.model_update.statistic
+    if args is not None and args.start_iter < iteration <= args.end_iter:
+        for pkg in render_pkgs:
+            if pkg is not None:
+                m.update(pkg)
     fired = []
     for rule in (densification, opacity_pruning, opacity_clipping, scale_pruning, scale_clipping, contribution_pruning, opacity_reset):
         res = rule(m, iteration)

@@ -26,6 +26,10 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libts2d.so")
+# Measurement / triage only (tools/, tests/triage/, the lab-library tests): a statistics or lab build of the same C ABI
+# (tools/bin/libts2d_stats.so, tools/bin/libts2d_lab.so) can be loaded in place of the product library.  The product library
+# itself reads no environment variable.
+_LIB_PATH = os.environ.get("TS2D_LIBRARY_PATH") or _LIB_PATH
 
 if not os.path.exists(_LIB_PATH):
     raise ImportError(

@@ -178,13 +178,29 @@ class _RasterizeTriangles(torch.autograd.Function):
             if sink is not None:
                 sink.append(g_feat, rs.campos)
             if bucket is not None:
+                nv = bucket.named_views()
+                use_shs = shs.numel() > 0
+                captured = (("vertex", g_vertex), ("opacity", g_opacity), ("center2D", g_center2D),
+                            ("color", (g_shs if use_shs else g_feat) if sink is None else None))
                 if place is None:  # a further view under the same capture: added to what the first one wrote
-                    nv = bucket.named_views()
-                    use_shs = shs.numel() > 0
-                    for name, g in (("vertex", g_vertex), ("opacity", g_opacity), ("center2D", g_center2D),
-                                    ("color", (g_shs if use_shs else g_feat) if sink is None else None)):
+                    for name, g in captured:
                         if name in nv and g is not None:
                             nv[name].add_(g.view(nv[name].shape))
+                # What autograd gets back under a capture: NOTHING for the captured parameter slots -- their gradient lives in the bucket
+                # until bucket.wait() (handing out the bucket's own views would let AccumulateGrad alias `param.grad` to the bucket, and a
+                # second view would then be added twice: once above, once by autograd) -- and a PRIVATE tensor for dL_dcenter2D, which
+                # is a per-view statistic (each render call owns its center2D, VanillaTS_model.py:347-363), not a parameter gradient.
+                if "vertex" in nv:
+                    g_vertex = None
+                if "opacity" in nv:
+                    g_opacity = None
+                if "color" in nv and sink is None:
+                    if use_shs:
+                        g_shs = None
+                    else:
+                        g_feat = None
+                if "center2D" in nv and place is not None:
+                    g_center2D = g_center2D.clone()
                 bucket._filled = True
         # The placeholder standing in for the unused one of shs/feature is a CPU `torch.Tensor([])`
         # (reference :183-184) that never requires grad; hand autograd None for it.

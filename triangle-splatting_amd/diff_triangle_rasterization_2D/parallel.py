@@ -36,7 +36,9 @@ class GradBucket:
     * `capture()`: while active, the backward pass of TriangleRasterizer (2D and 3D packages) writes dL_dvertex / dL_dopacity /
       dL_dcenter2D (and a dense dL_dshs / dL_dfeature when the bucket has a slot for it) STRAIGHT into the bucket's views --
       the kernels take the output pointers through the C ABI, so no pack copy exists.  A second backward under the same capture
-      (several views per rank) is added to the first.
+      (several views per rank) is added to the first.  Under a capture autograd receives NO gradient for the captured slots
+      (`param.grad` stays as it was): the gradients come from `wait()`; dL_dcenter2D, the per-view densification statistic, is
+      still delivered to each view's own center2D tensor.
     * `reduce_async()` = reduce-scatter + all-gather of the flat buffer: on the fully connected xGMI mesh every
       GPU sends each peer exactly the 1 / world slice that peer owns, over all seven links at once, and gets the reduced slices
       back the same way; between the two halves a rank owns its reduced slice, which is where a sharded optimizer step would go.
