@@ -78,6 +78,9 @@ def main():
                     help="2D = the headline path (BASELINE.json); 3D = the ray/plane variant (SURVEY.md 8f rank 1), not the headline")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="N > 1: all-reduce the dense dL_dshs (60 floats/triangle) instead of the factored exchange (15 + 3 per view)")
+    ap.add_argument("--sync-exchange", action="store_true",
+                    help="N > 1: wait for the gradient exchange inside the step that produced it (round 2 behaviour); default: double-buffered "
+                         "buckets, the exchange of step i is waited for after step i+1's kernels are queued (one-step-delayed application)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--sync-free", action="store_true",
                     help="use the sync-free forward (ts2d_forward, capacity = 1.25 x the instance count of the cold step) instead of the "
@@ -130,26 +133,50 @@ def main():
     bucket = None
     factored = world > 1 and not args.dense_exchange
     M = shs.shape[1]
+    buckets, shx, wait_events = [], [], []
+    overlap = world > 1 and not args.sync_exchange
     if world > 1:
         shapes = [vertex.shape, opacity.shape, torch.Size((P, 2))] + ([] if factored else [shs.shape])
-        bucket = GradBucket(shapes, dev, names=["vertex", "opacity", "center2D"] + ([] if factored else ["color"]))
+        # two process groups = two RCCL communicators / streams: the bucket's reduce-scatter + all-gather and the SH-gradient all-gather
+        # are in flight together; two buckets: the exchange of step i has the whole of step i + 1 to finish
+        bucket_group, sh_group = parallel.exchange_groups()
+        for _ in range(2 if overlap else 1):
+            buckets.append(GradBucket(shapes, dev, group=bucket_group, names=["vertex", "opacity", "center2D"] + ([] if factored else ["color"])))
+            shx.append(parallel.FactoredShExchange(sh_group, dev))
+        bucket = buckets[0]
     sink = parallel.ShGradSink()
 
-    state = {}
+    state = {"step": 0}
+
+    def collect(i):
+        """Waits (on the compute stream) for the exchange that step i started; the wait is bracketed by events = the EXPOSED exchange time."""
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        state["grads"] = buckets[i % len(buckets)].wait()
+        if factored:
+            state["shs_grad"] = shx[i % len(shx)].wait()  # dense dL_dshs summed over all ranks' views (one each)
+        e1.record()
+        wait_events.append((e0, e1))
 
     def step():
         center2D = torch.zeros((P, 2), device=dev, requires_grad=True)  # like triangle_renderer.py:67
         if bucket is not None:
             # N > 1: the backward kernels write dL_dvertex / dL_dopacity / dL_dcenter2D (and, with --dense-exchange, dL_dshs)
             # straight into the exchange bucket; its reduce-scatter + all-gather starts on a side stream as soon as the backward
-            # is queued and overlaps the factored SH-gradient exchange + expansion (parallel.py)
-            with bucket.capture(), parallel.factored_sh_grads(sink, enabled=factored):
+            # is queued, the factored SH-gradient all-gather + expansion on another (parallel.py)
+            i = state["step"]
+            b, x = buckets[i % len(buckets)], shx[i % len(shx)]
+            with b.capture(), parallel.factored_sh_grads(sink, enabled=factored):
                 out = raster(vertex, center2D, opacity, shs=shs)
                 torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
-            bucket.reduce_async()
+            b.reduce_async()
             if factored:
-                state["shs_grad"] = parallel.exchange_factored_sh_grads(sink, vertex, D, M, uniform=True)  # summed over all ranks' views (one each)
-            state["grads"] = bucket.wait()
+                x.start(sink, vertex, D, M, uniform=True)
+            if not overlap:
+                collect(i)       # synchronous: this step's gradients, now
+            elif i > 0:
+                collect(i - 1)   # one-step-delayed application: the previous step's gradients arrive while this step's exchange is in flight
+            state["step"] = i + 1
         else:
             out = raster(vertex, center2D, opacity, shs=shs)
             torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
@@ -188,11 +215,15 @@ def main():
     if events:
         _C.profile_reset()
         _C.profile_only(dominant)
+    wait_events.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if overlap:
+        collect(state["step"] - 1)  # the last step's exchange belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    exposed_ms = sum(a.elapsed_time(b) for a, b in wait_events) / max(args.steps, 1) if wait_events else None
     if events:
         _C.profile_enable(False)
         _C.profile_only("")
@@ -224,6 +255,10 @@ def main():
                    "forward": "sync-free (ts2d_forward, device-side instance count)" if args.sync_free else "reference sequence (blocking read of num_rendered)",
                    "parallelism": f"image-parallel x{world}" + ((", RCCL reduce-scatter + all-gather of one 12-float/triangle bucket the backward writes into (GradBucket.capture) + all-gather of factored SH grads (3 floats/triangle/view)" if factored
                                        else ", RCCL all-reduce of dense per-triangle grads (60 floats/triangle)") if world > 1 else ""),
+                   "exchange": ({"mode": "overlapped: double-buffered buckets, step i's exchange is waited for behind step i+1's kernels (one-step-delayed application)"
+                                         if overlap else "synchronous: waited for inside the step",
+                                 "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
+                                 "process_groups": 2} if world > 1 else None),
                    "algorithmic_bytes_per_step": alg["total"],
                    "achieved_hbm_gbs_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9, 2),
                    "hbm_roofline_frac_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},

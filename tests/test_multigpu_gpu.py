@@ -158,3 +158,65 @@ def test_two_views_under_one_capture_are_not_double_counted(variant):
     for mine, ref in zip(c2ds, ref_c2d):  # per-view statistic, untouched by the later view
         assert mine.grad is not None and mine.grad.data_ptr() != got["center2D"].data_ptr()
         assert rel(mine.grad, ref) < 2e-5
+
+
+def _rccl_world1_worker(port, q):
+    """The RCCL branch of the exchange on ONE GPU: a process group of one rank over the nccl (= RCCL) backend, collectives forced."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    root = os.path.dirname(here)
+    sys.path[:0] = [root, os.path.join(root, "triangle-splatting_amd"), here]
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        import synthetic
+        from diff_triangle_rasterization_2D import parallel
+        assert dist.get_backend() == "nccl"
+        s = synthetic.scene(P, W, H, D, seed=79)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        M = s["shs"].shape[1]
+        vertex, shs, opacity = t(s["vertex"]).requires_grad_(True), t(s["shs"]).requires_grad_(True), t(s["opacity"]).requires_grad_(True)
+        # reference: plain backward, no bucket
+        _, c2d = _render(s, _view(0), 2, dev, vertex, shs, opacity)
+        want = [vertex.grad.clone(), opacity.grad.clone(), c2d.grad.clone(), shs.grad.clone()]
+        vertex.grad = opacity.grad = shs.grad = None
+        errs = {}
+        rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+        for mode in ("rs_ag", "all_reduce"):
+            bucket = parallel.GradBucket([vertex.shape, opacity.shape, torch.Size((P, 2))], dev, names=["vertex", "opacity", "center2D"], mode=mode,
+                                         force_collectives=True)
+            _, sh_group = None, dist.new_group(backend="nccl")  # what parallel.exchange_groups() creates at world > 1
+            shx = parallel.FactoredShExchange(sh_group, dev)
+            for it in range(3):  # repeated WITHOUT host synchronisation: the side streams must order themselves against the compute stream
+                sink = parallel.ShGradSink()
+                _render(s, _view(0), 2, dev, vertex, shs, opacity, bucket, sink)
+                bucket.reduce_async()           # reduce_scatter_tensor into the rank's own slice of the SAME buffer, all_gather back (side stream)
+                shx.start(sink, vertex, D, M, uniform=True)
+                got = bucket.wait()
+                got_shs = shx.wait()
+                got[0].mul_(1.0)                # compute-stream work right behind the wait
+            torch.cuda.synchronize()
+            errs[mode] = [rel(g, w) for g, w in zip(list(got) + [got_shs], want)]
+            assert bucket.flat.numel() % 4 == 0 and vertex.grad is None
+        ok = all(e < 2e-5 for v in errs.values() for e in v)
+        q.put((bool(ok), errs))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_reduce_scatter_all_gather_branch_runs_on_one_gpu():
+    """The reduce-scatter + all-gather branch of GradBucket (RCCL only: gloo has no reduce_scatter_tensor and takes the all-reduce
+    fallback in every other test) and the side-stream SH exchange on a second communicator, executed over the nccl backend in a group
+    of one rank (legal in NCCL / RCCL): in-place slice semantics, side-stream ordering against the backward kernels that fill the
+    bucket, repeated steps without host synchronisation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q))
+    p.start()
+    p.join(600)
+    assert p.exitcode == 0
+    ok, errs = q.get(timeout=10)
+    assert ok, errs

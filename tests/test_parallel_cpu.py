@@ -258,3 +258,70 @@ def test_factored_sink_context_and_errors(hip_lib_built):
     sink.append(torch.zeros((1, 3)), torch.zeros(3))
     with pytest.raises(RuntimeError):
         parallel.exchange_factored_sh_grads(sink, torch.zeros((1, 3, 3)), 0, 1)
+
+
+def _wide_worker(rank, world, port, q):
+    """World sizes 4 and 8 (gloo): the flat bucket over every rank, two process groups in flight, double-buffered buckets with the
+    one-step-delayed collection of bench.py, the factored SH exchange with UNEVEN view counts (world + 3 views: some ranks hold two)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diff_triangle_rasterization_2D import parallel
+        from diff_triangle_rasterization_2D.parallel import GradBucket
+
+        P, M = 29, 4
+        shapes = [(P, 3, 3), (P, 1), (P, 2)]
+        bucket_group, sh_group = parallel.exchange_groups()
+        ok = sh_group is not None
+        buckets = [GradBucket([torch.Size(s) for s in shapes], "cpu", group=bucket_group, names=["vertex", "opacity", "center2D"]) for _ in range(2)]
+        # padded to equal 16-byte-aligned slices for every world size
+        ok = ok and buckets[0].padded % (4 * world) == 0 and buckets[0].padded >= sum(torch.Size(s).numel() for s in shapes)
+
+        def grads_of(step, r):
+            g = torch.Generator().manual_seed(1000 * step + r)
+            return [torch.rand(s, generator=g) for s in shapes]
+
+        vertex = torch.rand((P, 3, 3), generator=torch.Generator().manual_seed(3)) * 10
+        nviews = world + 3
+        views = {v: (torch.rand((P, 3), generator=torch.Generator().manual_seed(900 + v)),
+                     torch.rand(3, generator=torch.Generator().manual_seed(950 + v)) * 50 + 20) for v in range(nviews)}
+        want_shs = _expand_reference(vertex, torch.stack([views[v][1] for v in range(nviews)]), torch.stack([views[v][0] for v in range(nviews)]), 1, M)
+        shx = [parallel.FactoredShExchange(sh_group), parallel.FactoredShExchange(sh_group)]
+        collected = {}
+        for step in range(3):  # the protocol of bench.py: start step i's exchange, then collect step i - 1's
+            b = buckets[step % 2]
+            b.pack(grads_of(step, rank))
+            b.reduce_async()
+            sink = parallel.ShGradSink()
+            for v in parallel.shard_views(nviews, rank, world):
+                sink.append(*views[v])
+            shx[step % 2].start(sink, vertex, 1, M, expand_fn=_expand_reference, uniform=False)
+            if step > 0:
+                collected[step - 1] = ([t.clone() for t in buckets[(step - 1) % 2].wait()], shx[(step - 1) % 2].wait())
+        collected[2] = ([t.clone() for t in buckets[0].wait()], shx[0].wait())
+        for step in range(3):
+            expect = [sum(grads_of(step, r)[k] for r in range(world)) for k in range(len(shapes))]
+            got, got_shs = collected[step]
+            ok = ok and all(torch.allclose(a, b, atol=1e-5) for a, b in zip(got, expect)) and torch.allclose(got_shs, want_shs, atol=1e-5)
+        counts = [len(parallel.shard_views(nviews, r, world)) for r in range(world)]
+        ok = ok and sum(counts) == nviews and max(counts) == 2 and min(counts) == 1
+        stats = parallel.reduce_render_stats({"radii": torch.tensor([1, 5, 2]) * (rank + 1), "visible_count": torch.tensor([1, 0, 1])})
+        ok = ok and stats["radii"].tolist() == [world, 5 * world, 2 * world] and stats["visible_count"].tolist() == [world, 0, world]
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_exchange_protocol_world_4_and_8_uneven_views(hip_lib_built, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_wide_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert dict(q.get(timeout=5) for _ in range(world)) == {r: True for r in range(world)}

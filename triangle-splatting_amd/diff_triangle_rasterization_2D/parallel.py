@@ -48,13 +48,16 @@ class GradBucket:
     SLOTS = ("vertex", "opacity", "center2D", "color")  # names a capture can fill; `color` = dL_dshs or dL_dfeature
 
     def __init__(self, shapes: Sequence[torch.Size], device, dtype=torch.float32, group=None, mean: bool = False,
-                 names: Optional[Sequence[str]] = None, mode: str = "rs_ag"):
+                 names: Optional[Sequence[str]] = None, mode: str = "rs_ag", force_collectives: bool = False):
         self.shapes = [torch.Size(s) for s in shapes]
         self.numels = [int(torch.Size(s).numel()) for s in self.shapes]
         self.names = list(names) if names is not None else [None] * len(self.shapes)
         self.group = group
         self.mean = mean
         self.mode = mode
+        # force_collectives: issue the collectives even in a group of ONE rank -- how the RCCL reduce-scatter + all-gather branch (in-place
+        # slices, side-stream ordering) is executed on a single-GPU box (tests/test_multigpu_gpu.py); a no-op arithmetically
+        self.force_collectives = force_collectives
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         total = sum(self.numels)
         self.padded = -(-total // (4 * world)) * (4 * world)  # equal 16-byte-aligned slices for reduce-scatter
@@ -87,7 +90,7 @@ class GradBucket:
     def reduce_async(self):
         """Starts the cross-rank sum of the bucket; on GPUs it runs on a side stream ordered after the current stream."""
         self._filled = False
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.force_collectives):
             return
         world = dist.get_world_size(self.group)
 
@@ -217,6 +220,45 @@ class factored_sh_grads:
         import diff_triangle_rasterization_2D as pkg
         pkg._sh_grad_sink = self._prev
         return False
+
+
+def exchange_groups():
+    """(bucket_group, sh_group): two process groups over all ranks.  On RCCL every group has its own communicator and stream, so the
+    bucket's reduce-scatter + all-gather and the SH-gradient all-gather can be in flight TOGETHER (on one group they would queue behind
+    each other); on the ring they use the links in both directions.  Collective call: every rank must call it, in the same order."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return None, None
+    return None, dist.new_group(backend=dist.get_backend())
+
+
+class FactoredShExchange:
+    """`exchange_factored_sh_grads` started on a side stream: `start()` right after the backward, `wait()` where the dense dL_dshs is
+    needed (before the optimizer step -- or one step later, see bench.py).  Everything it touches stays referenced until `wait()`."""
+
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self._stream = torch.cuda.Stream(device=device) if (device is not None and torch.device(device).type == "cuda") else None
+        self._out = None
+        self._keep = None
+
+    def start(self, sink: ShGradSink, vertex: torch.Tensor, sh_degree: int, M: int, mean: bool = False, expand_fn=None, uniform: bool = True):
+        if self._stream is None:
+            self._out = exchange_factored_sh_grads(sink, vertex, sh_degree, M, self.group, mean, expand_fn, uniform)
+            return
+        colors, campos = list(sink.colors), list(sink.campos)
+        self._keep = (colors, campos, vertex)
+        self._stream.wait_stream(torch.cuda.current_stream(vertex.device))
+        with torch.cuda.stream(self._stream):
+            self._out = exchange_factored_sh_grads(sink, vertex, sh_degree, M, self.group, mean, expand_fn, uniform)
+            for tns in colors + [vertex]:
+                tns.record_stream(self._stream)  # allocated on the compute stream, last used on this one
+
+    def wait(self) -> Optional[torch.Tensor]:
+        if self._stream is not None and self._out is not None:
+            torch.cuda.current_stream(self._out.device).wait_stream(self._stream)
+            self._out.record_stream(torch.cuda.current_stream(self._out.device))
+        out, self._out, self._keep = self._out, None, None
+        return out
 
 
 def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree: int, M: int, group=None,
