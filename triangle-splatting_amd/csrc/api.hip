@@ -354,17 +354,16 @@ int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
         else ts_launch_preprocess_fwd(a, radii, g, s);
     }
     TS_CHECK(flags, s, "preprocess_fwd");
-    if (early)
     {
-        {
-            ProfScope ps("count", s);
-            ts_launch_count_instances(g, P, early->host, s); // writes the pinned host word itself
-        }
-        TS_HIP(hipEventRecord(early->ev, s));
+        // the first histogram of the depth sort also sums the instance count and writes it to the pinned host word itself: the host
+        // waits for the event behind THIS launch only and allocates the binning buffer while the rest of the sort runs
+        ProfScope ps("depth_census", s);
+        ts_sort_by_depth_begin(g, P, early ? early->host : nullptr, s);
     }
+    if (early) TS_HIP(hipEventRecord(early->ev, s));
     {
         ProfScope ps("depth_sort", s);
-        ts_sort_by_depth(g, P, s);
+        ts_sort_by_depth_finish(g, P, s);
     }
     TS_CHECK(flags, s, "depth_sort");
     {
@@ -744,7 +743,18 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
     case 14: src = im.final_T; bytes = (size_t)W * H * 4; break;
     case 15: src = b.k[(b.passes & 1) ^ 1]; bytes = (size_t)N * 4; break; // the ping-pong partner of the sorted list
     case 16: src = b.v[(b.passes & 1) ^ 1]; bytes = (size_t)N * 4; break;
-    case 17: src = g.perm; bytes = (size_t)P * 4; break;
+    case 17: // triangle ids in depth order: the 4th pass's output, or the 3rd's when the census found the top key byte constant
+    {
+        uint32_t top_const = 0;
+        if (P > 0)
+        {
+            TS_HIP(hipMemcpyAsync(&top_const, g.top_const, 4, hipMemcpyDeviceToHost, s));
+            TS_HIP(hipStreamSynchronize(s));
+        }
+        src = top_const ? g.sv[0] : g.sv[1];
+        bytes = (size_t)P * 4;
+        break;
+    }
     case 18: src = g.rec; bytes = (size_t)P * TS_REC_FLOATS * 4; break; // raw 64-byte render records (2D or 3D layout)
     default: return fail(TS2D_ERR_INVALID, "unknown field %d", field);
     }

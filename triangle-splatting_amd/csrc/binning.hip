@@ -75,6 +75,8 @@ template <typename T>
 __device__ __forceinline__ T peer_load(const T *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 template <typename T>
 __device__ __forceinline__ void peer_store(T *p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// triangle ids in (depth, id) order: the 4th pass's output, or the 3rd's when the 4th was skipped (written by an earlier launch)
+__device__ __forceinline__ const uint32_t *sorted_ids(const GeometryStateView &g) { return *g.top_const ? g.sv[0] : g.sv[1]; }
 
 // Sync-free forward (ts2d_forward): the pair count lives on the device.  `n_dev` (null on the synchronous path) points at the
 // 64-bit instance count the scan left behind; a count above `n` (the capacity the buffers were carved for) renders nothing and is
@@ -94,23 +96,74 @@ __device__ __forceinline__ bool resolve_count(const unsigned long long *n_dev, i
 // Digit counts of every chunk, and -- by the blocks that arrive last -- their prefixes: the last block of a slab (64 chunks)
 // turns the slab's rows into exclusive column prefixes and its totals; the last slab to finish turns the slab totals into
 // their prefix over the slabs and forms the exclusive prefix of the 256 digit totals.  One launch, no spinning.
+//
+// The FIRST pass of the depth sort (CENSUS) also takes stock of what it reads anyway (round 3: two launches and one pass fewer per step):
+//   * N = sum(tiles_touched), the instance count the host is waiting for (the reference hands num_rendered to the host,
+//     rasterizer.cu:189-191); it does not depend on the depth order, so it leaves as soon as this kernel is done -- through a pinned host
+//     word -- while the rest of the sort runs (round 2 spent a kernel of its own on it);
+//   * which key bits differ between VISIBLE triangles (culled ones carry key 0 and emit nothing wherever they land): depths are positive
+//     floats, and when they all share their top byte -- sign + seven exponent bits: every scene whose depths span less than a factor
+//     of four -- the fourth pass has nothing to order.  The verdict goes to `census->top_const`; the last pass's kernels return at once
+//     when it is set and the consumers of the order take the third pass's output (sorted_ids()).
+struct DepthCensus
+{
+    const uint32_t *tiles_touched; // per key
+    unsigned long long *chunk_sum; // per chunk (scratch)
+    uint32_t *chunk_or, *chunk_and; // per chunk (scratch)
+    unsigned long long *n_out;     // device: where the scan will leave N as well
+    unsigned long long *host_out;  // pinned host word or null
+    uint32_t *top_const;           // device flag
+};
+__device__ __forceinline__ bool pass_skipped(const uint32_t *skip_flag) { return skip_flag && peer_load(skip_flag) != 0u; }
+
+template <bool CENSUS>
 __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, const unsigned long long *n_dev, int shift,
-                                                       uint32_t mask, RadixScratchView r)
+                                                       uint32_t mask, RadixScratchView r, DepthCensus census, const uint32_t *skip_flag)
 {
     __shared__ uint32_t bins[NB];
+    __shared__ unsigned long long csum[4];
+    __shared__ uint32_t cor[4], cand[4];
     if (!resolve_count(n_dev, n, r)) return;
+    if (!CENSUS && pass_skipped(skip_flag)) return;
     const int t = threadIdx.x, chunk = blockIdx.x;
     bins[t] = 0u;
     __syncthreads();
     const int64_t base = (int64_t)chunk * CH;
+    unsigned long long tsum = 0;
+    uint32_t kor = 0u, kand = 0xFFFFFFFFu;
 #pragma unroll 4
     for (int b = 0; b < CH / 256; b++)
     {
         const int64_t i = base + 256 * b + t;
-        if (i < n) atomicAdd(&bins[(keys[i] >> shift) & mask], 1u);
+        if (i < n)
+        {
+            const uint32_t k = keys[i];
+            atomicAdd(&bins[(k >> shift) & mask], 1u);
+            if (CENSUS)
+            {
+                tsum += census.tiles_touched[i];
+                if (k != 0u) { kor |= k; kand &= k; }
+            }
+        }
+    }
+    if (CENSUS)
+    {
+        for (int o = 32; o > 0; o >>= 1)
+        {
+            tsum += __shfl_xor(tsum, o);
+            kor |= __shfl_xor(kor, o);
+            kand &= __shfl_xor(kand, o);
+        }
+        if ((t & 63) == 0) { csum[t >> 6] = tsum; cor[t >> 6] = kor; cand[t >> 6] = kand; }
     }
     __syncthreads();
     peer_store(r.table + (size_t)chunk * NB + t, bins[t]);
+    if (CENSUS && t == 0)
+    {
+        peer_store(census.chunk_sum + chunk, csum[0] + csum[1] + csum[2] + csum[3]);
+        peer_store(census.chunk_or + chunk, cor[0] | cor[1] | cor[2] | cor[3]);
+        peer_store(census.chunk_and + chunk, cand[0] & cand[1] & cand[2] & cand[3]);
+    }
 
     const int slab = chunk >> 6, c0 = slab * 64, c1 = min(r.chunks, c0 + 64);
     if (!last_arrival(r.tickets + 2 + slab, (uint32_t)(c1 - c0))) return;
@@ -154,6 +207,36 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
         __syncthreads();
     }
     r.binbase[t] = tot[t] - total;
+    if (CENSUS)
+    {
+        // this block arrived last of all: every chunk's census is visible (same hand-off as the digit counts)
+        unsigned long long sum = 0;
+        uint32_t o = 0u, a = 0xFFFFFFFFu;
+        for (int c = t; c < r.chunks; c += 256)
+        {
+            sum += peer_load(census.chunk_sum + c);
+            o |= peer_load(census.chunk_or + c);
+            a &= peer_load(census.chunk_and + c);
+        }
+        for (int d = 32; d > 0; d >>= 1)
+        {
+            sum += __shfl_xor(sum, d);
+            o |= __shfl_xor(o, d);
+            a &= __shfl_xor(a, d);
+        }
+        __syncthreads();
+        if ((t & 63) == 0) { csum[t >> 6] = sum; cor[t >> 6] = o; cand[t >> 6] = a; }
+        __syncthreads();
+        if (t == 0)
+        {
+            const unsigned long long N = csum[0] + csum[1] + csum[2] + csum[3];
+            const uint32_t varying = (cor[0] | cor[1] | cor[2] | cor[3]) ^ (cand[0] & cand[1] & cand[2] & cand[3]);
+            *census.n_out = N;
+            peer_store(census.top_const, (varying >> 24) == 0u ? 1u : 0u); // no visible triangle at all: or = 0, and = ~0 -> varying = ~0 -> not set
+            // pinned, device-visible host word: the host reads it after the event recorded behind this kernel (no copy kernel in between)
+            if (census.host_out) __hip_atomic_store(census.host_out, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // One workgroup = one chunk of CH pairs; wave w owns the w-th quarter (KB steps of 64 consecutive pairs, held in registers).
@@ -167,10 +250,11 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
 template <bool IDENTITY_VALUES>
 __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                           uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n,
-                                                          const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r)
+                                                          const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r, const uint32_t *skip_flag)
 {
     constexpr int KB = CH / 256; // steps per wave
     if (!resolve_count(n_dev, n, r)) return;
+    if (pass_skipped(skip_flag)) return;
     __shared__ uint32_t stage_k[CH], stage_v[CH];
     __shared__ uint32_t wcnt[4][NB]; // per-wave digit counts, then the chunk-local start of the (wave, digit) run
     __shared__ int32_t gdelta[NB];   // global run start of the digit minus its chunk-local start
@@ -248,52 +332,25 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
     }
 }
 
-void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
-                int nbits, const RadixScratchView &r, hipStream_t s)
+void radix_hist(const uint32_t *kin, int64_t n, const unsigned long long *n_dev, int shift, int nbits, const RadixScratchView &r, hipStream_t s,
+                const DepthCensus *census = nullptr, const uint32_t *skip_flag = nullptr)
 {
     const dim3 grid((unsigned)r.chunks);
-    hipLaunchKernelGGL(rs_hist_kernel, grid, dim3(256), 0, s, kin, n, n_dev, shift, (1u << nbits) - 1u, r);
-    if (vin) hipLaunchKernelGGL((rs_scatter_kernel<false>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r);
-    else hipLaunchKernelGGL((rs_scatter_kernel<true>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r);
+    if (census) hipLaunchKernelGGL((rs_hist_kernel<true>), grid, dim3(256), 0, s, kin, n, n_dev, shift, (1u << nbits) - 1u, r, *census, skip_flag);
+    else hipLaunchKernelGGL((rs_hist_kernel<false>), grid, dim3(256), 0, s, kin, n, n_dev, shift, (1u << nbits) - 1u, r, DepthCensus{}, skip_flag);
 }
-
-// ---- early instance count: N = sum(tiles_touched), known as soon as preprocess is done ------------------------------------------
-// The reference's interface hands num_rendered to the host (rasterizer.cu:189-191), which sizes the binning buffer from it.  N does not
-// depend on the depth order, so it is summed right after preprocess and copied to the host WHILE the depth sort runs: the host
-// round trip (blocking read, buffer allocation, next launches: ~55 us of idle GPU in round 2's timeline) hides behind 0.15 ms of
-// queued kernels.  Partial sums go through blocksum[] (rewritten later by gather_blocksum_kernel), the total lands where that
-// kernel will put the same number again.
-constexpr int CB = 2048; // triangles per block
-__global__ void __launch_bounds__(256) count_instances_kernel(int P, GeometryStateView g, uint32_t *ticket, int nblocks_scan,
-                                                              unsigned long long *host_out)
+void radix_scatter(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
+                   int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag = nullptr)
 {
-    __shared__ unsigned long long wsum[4];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    unsigned long long sum = 0;
-#pragma unroll
-    for (int k = 0; k < CB / 256; k++)
-    {
-        const int i = blockIdx.x * CB + 256 * k + t;
-        if (i < P) sum += g.tiles_touched[i];
-    }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if (lane == 0) wsum[wave] = sum;
-    __syncthreads();
-    if (t == 0) peer_store((unsigned long long *)g.blocksum + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
-    if (!last_arrival(ticket, gridDim.x)) return;
-    sum = 0;
-    for (int b = t; b < (int)gridDim.x; b += 256) sum += peer_load((const unsigned long long *)g.blocksum + b);
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    __syncthreads();
-    if (lane == 0) wsum[wave] = sum;
-    __syncthreads();
-    if (t == 0)
-    {
-        const unsigned long long n = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        ((unsigned long long *)g.blocksum)[nblocks_scan] = n;
-        // pinned, device-visible host word: the host reads it after the event recorded behind this kernel (no copy kernel in between)
-        if (host_out) __hip_atomic_store(host_out, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
+    const dim3 grid((unsigned)r.chunks);
+    if (vin) hipLaunchKernelGGL((rs_scatter_kernel<false>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag);
+    else hipLaunchKernelGGL((rs_scatter_kernel<true>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag);
+}
+void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
+                int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag = nullptr)
+{
+    radix_hist(kin, n, n_dev, shift, nbits, r, s, nullptr, skip_flag);
+    radix_scatter(kin, vin, kout, vout, n, n_dev, shift, nbits, r, s, skip_flag);
 }
 
 // ---- step 2: tiles_sorted = tiles_touched[perm], 64-bit block sums, their prefix, N ---------------------------------------
@@ -304,12 +361,13 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
     __shared__ unsigned long long wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i0 = blockIdx.x * SB + 4 * t;
+    const uint32_t *ids = sorted_ids(g);
     uint32_t v[4];
     unsigned long long sum = 0;
 #pragma unroll
     for (int k = 0; k < 4; k++)
     {
-        v[k] = (i0 + k < P) ? g.tiles_touched[g.perm[i0 + k]] : 0u;
+        v[k] = (i0 + k < P) ? g.tiles_touched[ids[i0 + k]] : 0u;
         sum += v[k];
     }
     if (i0 + 3 < P) *(uint4 *)(g.tiles_sorted + i0) = make_uint4(v[0], v[1], v[2], v[3]);
@@ -410,7 +468,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     const uint32_t off = incl - tiles; // exclusive prefix
     if (tiles > 0)
     {
-        id = g.perm[i];
+        id = sorted_ids(g)[i];
         rect = g.rect[id];
     }
     const uint32_t minx = rect.x & 0xffffu, miny = rect.x >> 16, maxx = rect.y & 0xffffu, maxy = rect.y >> 16;
@@ -474,16 +532,30 @@ __global__ void zero_words_kernel(uint32_t *p, int n)
 }
 } // namespace
 
-// Step 1: (depth bits, id) -> perm.  Depth keys are view-space z of visible triangles (> 0, so the unsigned bit
-// pattern is monotone) and 0 for culled ones, which emit nothing wherever they land.
-void ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s)
+// Step 1: (depth bits, id) -> sorted ids.  Depth keys are view-space z of visible triangles (> 0, so the unsigned bit
+// pattern is monotone) and 0 for culled ones, which emit nothing wherever they land.  `begin` = the first histogram, which also
+// produces N (to `host_out` as well when given) and the key-bit census; `finish` = the other launches (the 4th pass returns at once
+// when the census found the top byte constant: then sk[0] / sv[0] hold the order).
+void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s)
 {
     if (P <= 0) return;
-    const uint32_t *depth = (const uint32_t *)g.depth;
-    radix_pass(depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s);
+    DepthCensus c;
+    c.tiles_touched = g.tiles_touched;
+    c.chunk_sum = (unsigned long long *)g.blocksum; // scratch: rewritten by gather_blocksum_kernel (chunks <= ceil(P / 1024))
+    c.chunk_or = g.tiles_sorted;                    // scratch: rewritten by gather_blocksum_kernel / scan_emit_kernel
+    c.chunk_and = g.offsets;
+    c.n_out = (unsigned long long *)g.blocksum + (P + SB - 1) / SB;
+    c.host_out = host_out;
+    c.top_const = g.top_const;
+    radix_hist((const uint32_t *)g.depth, P, nullptr, 0, 8, g.rs, s, &c);
+}
+void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s)
+{
+    if (P <= 0) return;
+    radix_scatter((const uint32_t *)g.depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s);
     radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 8, 8, g.rs, s);
     radix_pass(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, nullptr, 16, 8, g.rs, s);
-    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, s);
+    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, s, g.top_const);
 }
 
 // Step 2: tiles_sorted = tiles_touched[perm], block sums -> exclusive prefix, blocksum[nblocks] = N.
@@ -492,13 +564,6 @@ void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
     if (P <= 0) return;
     const int nblocks = (P + SB - 1) / SB;
     hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, g.rs.tickets + 1);
-}
-
-void ts_launch_count_instances(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s)
-{
-    if (P <= 0) return;
-    hipLaunchKernelGGL(count_instances_kernel, dim3((unsigned)((P + CB - 1) / CB)), dim3(256), 0, s, P, g, g.rs.tickets + 2 + g.rs.slabs,
-                       (P + SB - 1) / SB, host_out);
 }
 
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,

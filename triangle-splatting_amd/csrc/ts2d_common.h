@@ -50,7 +50,9 @@ struct GeometryStateView
     uint8_t *clamped;        // P   bit c set when colour channel c was clamped at 0
     uint32_t *sk[2], *sv[2]; // P each: ping-pong (key, value) buffers of the depth sort
     uint32_t *depth_sorted;  //     = sk[1]: depth keys in ascending order (after the 4th pass)
-    uint32_t *perm;          //     = sv[1]: triangle ids in (depth, id) order
+    uint32_t *perm;          //     = sv[1]: triangle ids in (depth, id) order after the 4th pass
+    uint32_t *top_const;     // device flag (one of the sort's scratch words, cleared with the tickets): the visible triangles' depth keys share
+                             // their top byte, the 4th pass was skipped and the order is in sk[0] / sv[0] (binning.hip, sorted_ids())
     uint32_t *tiles_sorted;  // P   tiles_touched[perm[i]]
     uint32_t *offsets;       // P   inclusive prefix sum of tiles_sorted: instance slots of the i-th nearest triangle
     uint64_t *blocksum;      // ceil(P / 1024) + 2   per-block sums of tiles_sorted, then their exclusive prefix; [nblocks] = N
@@ -113,6 +115,7 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.offsets, n);
     ts_carve(p, v.blocksum, (n + 1023) / 1024 + 2);
     ts_carve_radix(p, n, v.rs);
+    v.top_const = v.rs.tickets + v.rs.slabs + 4;
     return (size_t)(p - base) + TS_ALIGN;
 }
 
@@ -169,11 +172,11 @@ struct PreprocessArgs
 
 void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s);
 // binning.hip -- every step hand-written for gfx950 (the round-1 rocPRIM calls survive only as test comparators)
-void ts_sort_by_depth(const GeometryStateView &g, int32_t P, hipStream_t s);                 // (depth bits, id) -> perm
+void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s); // first histogram + N + key-bit census
+void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s);          // the rest: (depth bits, id) -> sorted ids
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);                  // tiles_sorted, block sums, N
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                          float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path
-void ts_launch_count_instances(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s);
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P);                        // where the scan leaves N
 void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s); // stable, tile bits only
 void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
