@@ -233,7 +233,7 @@ def test_lab_library_variants_match(env):
         pytest.skip("tools/bin/libts2d_lab.so not built")
     e = dict(os.environ, TS2D_LIBRARY_PATH=LAB_LIB, **env)
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab_worker.py")], env=e, capture_output=True,
-                       text=True, timeout=600)
+                       text=True, timeout=240)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("LAB_RESULT ")][-1][len("LAB_RESULT "):])
     # the round-1 kernels evaluate the barycentrics as affine forms: their geometry gradients carry ~1e-3 on slivers

@@ -397,26 +397,44 @@ __global__ void __launch_bounds__(256, 6) render_fwd_group_kernel(RenderArgs a, 
 // Each group reduces its 16 values over its 16 lanes (DPP row transpose-reduce) and adds them into the entry's row of a
 // wave-private LDS table (one group after the other: two groups may be working on the same entry); once per batch the rows
 // leave as coalesced 64-byte atomic adds, one gradient record per 16 lanes.
-template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256, 6) render_bwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+// WPB = quadrant waves per workgroup.  The four quadrant waves of a tile never talk to each other here, so the backward launches
+// them as single-wave workgroups (WPB = 1): the dispatcher then fills a freed wave slot with the next quadrant instead of waiting for
+// four slots of one CU, which shortens the tail of the launch (8160 tiles are only 5.3 rounds of 256-thread workgroups).  The four
+// quadrants of a tile stay neighbours in dispatch order and on one XCD (shared L2 for the tile's list and records).
+template <bool RICH, bool GAMMA1, int WPB>
+__global__ void __launch_bounds__(64 * WPB, 6) render_bwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                                    const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                                    const float *__restrict__ dL_dout_feature,
                                                                    const float *__restrict__ dL_dout_depth,
                                                                    const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
-    __shared__ __attribute__((aligned(16))) float rows_all[4][(NR + 1) * BROW]; // constants + gradient sums; row -1 absorbs the adds of idle groups
-    __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2];   // per group: NR entries (u16 byte offsets of rows)
+    __shared__ __attribute__((aligned(16))) float rows_all[WPB][(NR + 1) * BROW]; // constants + gradient sums; row -1 absorbs the adds of idle groups
+    __shared__ __attribute__((aligned(16))) uint32_t list_all[WPB][4 * NR / 2];   // per group: NR entries (u16 byte offsets of rows)
 #ifdef TSG_PAD_LDS
     __shared__ int pad_lds_b[TSG_PAD_LDS / 4];
     if (a.W < 0) pad_lds_b[threadIdx.x] = 1, list_all[0][0] = (signed char)pad_lds_b[255 - threadIdx.x];
 #endif
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    int tile, quad, wave; // quad = which 8x8 quadrant of the tile, wave = index into this workgroup's LDS arrays
+    if (WPB == 4)
+    {
+        tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+        quad = wave = threadIdx.x >> 6;
+    }
+    else
+    {
+        // block b runs on XCD b % 8 (observed; used for locality only): that XCD's j-th block is quadrant j & 3 of the (j >> 2)-th tile of its band
+        const int ntiles = a.grid_x * a.grid_y, q8 = ntiles >> 3, r8 = ntiles & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        if ((j >> 2) >= q8 + (x < r8 ? 1 : 0)) return; // the grid is padded to the longest band
+        tile = x * q8 + min(x, r8) + (j >> 2);
+        quad = j & 3;
+        wave = 0;
+    }
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     const int grp = lane >> 4, sub = lane & 15;
-    const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
+    const int X0 = tx * TS_TILE + (quad & 1) * 8, Y0 = ty * TS_TILE + (quad >> 1) * 8;
     const int lx = ((grp & 1) << 2) + (sub & 3), ly = ((grp >> 1) << 2) + (sub >> 2);
     const int px = X0 + lx, py = Y0 + ly;
     const bool inside = px < a.W && py < a.H;
@@ -677,6 +695,15 @@ void ts_launch_render_bwd_group(const RenderArgs &a, const GeometryStateView &g,
 {
     const dim3 grid((unsigned)(a.grid_x * a.grid_y));
     if (grid.x == 0) return;
-    TS_DISPATCH_G(render_bwd_group_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature, dL_dout_depth,
-                  dL_dout_normal, grad_rec);
+    constexpr int WPB = 1;
+    const int ntiles = a.grid_x * a.grid_y;
+    const dim3 grid1((unsigned)(WPB == 4 ? ntiles : 8 * 4 * ((ntiles + 7) / 8)));
+    const bool g1 = (a.gamma == 1.0f);
+#define TS_BWD(R, G) hipLaunchKernelGGL((render_bwd_group_kernel<R, G, WPB>), grid1, dim3(64 * WPB), 0, s, a, im.ranges, b.vals, g.rec, im.final_T, \
+                                        im.n_contrib, dL_dout_feature, dL_dout_depth, dL_dout_normal, grad_rec)
+    if (a.rich_info && g1) TS_BWD(true, true);
+    else if (a.rich_info) TS_BWD(true, false);
+    else if (g1) TS_BWD(false, true);
+    else TS_BWD(false, false);
+#undef TS_BWD
 }
