@@ -334,8 +334,34 @@ def schedules():
     np.savez(os.path.join(HERE, "schedules.npz"), **out)
     print("schedules.npz:", out["exp_values"].shape, out["es_values"].shape)
 
+# ---- depth_normal.npz: the reference's DepthNormalLoss (trainer_utils.py:204-257) + torch autograd ------------------------------------
+def depth_normal():
+    tu = load_trainer_utils()
+    rng = np.random.default_rng(11)
+    out = {}
+    cases = [(47, 64, 0.5, 0.9, 0.31, 0.23), (64, 48, 0.5, 0.9, 0.5, 0.66), (33, 41, None, 0.9, 0.4, 0.3), (40, 56, 0.25, 0.7, 0.31, 0.2)]
+    out["cases"] = np.array([[H, W, -1.0 if s is None else s, q, tx, ty] for H, W, s, q, tx, ty in cases], np.float64)
+    for i, (H, W, s, q, tx, ty) in enumerate(cases):
+        # a smooth depth map with a few discontinuities (what a rendered scene looks like), strictly positive
+        yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+        depth = 5.0 + 2.0 * np.sin(3 * xx + 1) * np.cos(2 * yy) + 1.5 * (xx + yy > 1.1) + 0.05 * rng.standard_normal((H, W))
+        normal = rng.standard_normal((3, H, W)) * 0.3 + np.array([0.1, -0.2, -1.0])[:, None, None]
+        normal[:, 0, 0] = 0.0  # a pixel without any coverage: exercises the eps branch of F.normalize
+        d = torch.tensor(depth, dtype=torch.float32, requires_grad=True)
+        n = torch.tensor(normal, dtype=torch.float32, requires_grad=True)
+        loss = tu.DepthNormalLoss(scale_factor=s, depth_grad_filter_quantile=q)(d, n, tx, ty)
+        loss.backward()
+        out[f"depth{i}"], out[f"normal{i}"] = d.detach().numpy(), n.detach().numpy()
+        out[f"loss{i}"] = np.float32(loss.item())
+        out[f"ddepth{i}"], out[f"dnormal{i}"] = d.grad.numpy(), n.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "depth_normal.npz"), **out)
+    print("depth_normal.npz:", [float(out[f"loss{i}"]) for i in range(len(cases))])
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "model_update":
+    if len(sys.argv) > 1 and sys.argv[1] == "depth_normal":
+        depth_normal()
+    elif len(sys.argv) > 1 and sys.argv[1] == "model_update":
         model_update(np.random.default_rng(1))  # only this fixture (the others are unchanged since round 1)
     elif len(sys.argv) > 1 and sys.argv[1] == "schedules":
         schedules()

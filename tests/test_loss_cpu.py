@@ -63,3 +63,18 @@ def test_model_forward_helpers(hip_lib_built):
     assert s.tolist() == [[0.0], [1.0]]
     s.sum().backward()
     assert o.grad.tolist() == [[1.0], [1.0]]  # straight-through
+
+
+def test_depth_normal_oracle_matches_the_reference_class():
+    """oracle/ts_loss_oracle.py:depth_normal_loss against tests/golden/depth_normal.npz = the reference's DepthNormalLoss
+    (trainer_utils.py:204-257) + torch autograd, executed by tests/golden/make_golden.py: scale factors 0.5 (every shipped config),
+    0.25 and None, odd image sizes, a zero rendered normal (eps branch of F.normalize)."""
+    import os
+    import numpy as np
+    from oracle import ts_loss_oracle as O
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "depth_normal.npz"))
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    for i, (H, W, s, q, tx, ty) in enumerate(z["cases"]):
+        loss, dd, dn = O.depth_normal_loss(z[f"depth{i}"], z[f"normal{i}"], tx, ty, None if s < 0 else float(s), q)
+        assert abs(loss - float(z[f"loss{i}"])) < 2e-6 * abs(float(z[f"loss{i}"]))
+        assert rel(dd, z[f"ddepth{i}"]) < 2e-5 and rel(dn, z[f"dnormal{i}"]) < 2e-5

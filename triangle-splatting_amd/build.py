@@ -35,6 +35,7 @@ SOURCES = {
     "preprocess3d.hip": ["-ffp-contract=off"],
     "shgrad.hip": ["-ffp-contract=off"],
     "photometric.hip": [],
+    "depth_normal.hip": ["-ffp-contract=off"],
     "knn.hip": [],
     "model_update.hip": [],
     "binning.hip": [],

@@ -539,6 +539,48 @@ int tsl_photometric_backward(const float *image, const float *gt, int32_t channe
     return TS2D_OK;
 }
 
+size_t tsl_depth_normal_workspace_bytes(int32_t height, int32_t width, float scale_factor)
+{
+    return ts_depth_normal_workspace_bytes(height, width, scale_factor);
+}
+
+static int depth_normal_args_ok(const float *depth, const float *normal, int32_t H, int32_t W, float tan_fovx, float tan_fovy, float scale,
+                                const void *ws, size_t ws_bytes)
+{
+    if (H <= 0 || W <= 0) return fail(TS2D_ERR_INVALID, "height and width must be positive");
+    if ((int64_t)H * W > (int64_t)16 * 1000 * 1000) return fail(TS2D_ERR_INVALID, "quantile() input tensor is too large"); // torch.quantile's own limit
+    if (!(tan_fovx > 0.0f) || !(tan_fovy > 0.0f)) return fail(TS2D_ERR_INVALID, "tan_fovx / tan_fovy must be positive");
+    if (scale > 0.0f && scale != 1.0f && ((int)floor((double)H * scale) < 1 || (int)floor((double)W * scale) < 1))
+        return fail(TS2D_ERR_INVALID, "scale_factor leaves no pixel");
+    if (!depth || !normal || !ws) return fail(TS2D_ERR_INVALID, "null pointer");
+    if (ws_bytes < ts_depth_normal_workspace_bytes(H, W, scale)) return fail(TS2D_ERR_CAPACITY, "workspace too small");
+    return TS2D_OK;
+}
+
+int tsl_depth_normal_forward(const float *depth, const float *normal, int32_t height, int32_t width, float tan_fovx, float tan_fovy,
+                             float scale_factor, float quantile, void *workspace, size_t workspace_bytes, float *out, void *stream)
+{
+    if (int rc = depth_normal_args_ok(depth, normal, height, width, tan_fovx, tan_fovy, scale_factor, workspace, workspace_bytes)) return rc;
+    if (!out) return fail(TS2D_ERR_INVALID, "null output");
+    if (!(quantile >= 0.0f && quantile <= 1.0f)) return fail(TS2D_ERR_INVALID, "quantile() q values must be in the range [0, 1]");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("depth_normal_fwd", s);
+    TS_HIP(ts_depth_normal_forward(depth, normal, height, width, tan_fovx, tan_fovy, scale_factor, quantile, workspace, out, s));
+    return TS2D_OK;
+}
+
+int tsl_depth_normal_backward(const float *depth, const float *normal, int32_t height, int32_t width, float tan_fovx, float tan_fovy,
+                              float scale_factor, const void *workspace, size_t workspace_bytes, const float *grad_out, float *dL_ddepth,
+                              float *dL_dnormal, void *stream)
+{
+    if (int rc = depth_normal_args_ok(depth, normal, height, width, tan_fovx, tan_fovy, scale_factor, workspace, workspace_bytes)) return rc;
+    if (!dL_ddepth && !dL_dnormal) return TS2D_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("depth_normal_bwd", s);
+    TS_HIP(ts_depth_normal_backward(depth, normal, height, width, tan_fovx, tan_fovy, scale_factor, workspace, grad_out, dL_ddepth, dL_dnormal, s));
+    return TS2D_OK;
+}
+
 // ---- include/ts_knn.h -------------------------------------------------------------------------------------------------
 size_t tsk_workspace_bytes(int32_t P) { return ts_knn_workspace_bytes(P); }
 

@@ -254,6 +254,13 @@ hipError_t ts_loss_forward(const float *image, const float *gt, int C, int H, in
 hipError_t ts_loss_backward(const float *image, const float *gt, int C, int H, int W, float w_l1, float w_ssim, const void *workspace,
                             const float *grad_out, float *dL_dimage, hipStream_t s);
 
+// ---- fused depth / normal consistency loss (depth_normal.hip, include/ts_loss.h) --------------------------------------------------
+size_t ts_depth_normal_workspace_bytes(int H, int W, float scale);
+hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, float scale, float quantile,
+                                   void *workspace, float *out, hipStream_t s);
+hipError_t ts_depth_normal_backward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, float scale,
+                                    const void *workspace, const float *grad_out, float *dL_ddepth, float *dL_dnormal, hipStream_t s);
+
 // ---- exact nearest-neighbour helpers (knn.hip, include/ts_knn.h) -------------------------------------------------------
 size_t ts_knn_workspace_bytes(int P);
 hipError_t ts_knn_mean_dist3(int P, const float *points, float *mean_dist2, void *ws, hipStream_t s);

@@ -123,3 +123,69 @@ class PhotometricLoss(nn.Module):
 
     def forward(self, image: torch.Tensor, gt_image: torch.Tensor) -> torch.Tensor:
         return _Photometric.apply(image, gt_image, self.w_L1, self.w_ssim)
+
+
+# ---- depth / normal consistency loss (trainer_utils.py:204-257) -------------------------------------------------------------------
+_lib.tsl_depth_normal_workspace_bytes.restype = C.c_size_t
+_lib.tsl_depth_normal_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_float]
+_lib.tsl_depth_normal_forward.restype = C.c_int
+_lib.tsl_depth_normal_forward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, C.c_size_t, _fp, _fp]
+_lib.tsl_depth_normal_backward.restype = C.c_int
+_lib.tsl_depth_normal_backward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _fp, C.c_size_t, _fp, _fp, _fp, _fp]
+
+
+class _DepthNormal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, normal, tan_fovx, tan_fovy, scale_factor, quantile):
+        if not depth.is_cuda or not normal.is_cuda:
+            raise RuntimeError("DepthNormalLoss (MI355X build) needs tensors on a HIP device; there is no CPU fallback")
+        if depth.dtype != torch.float32 or normal.dtype != torch.float32:
+            raise RuntimeError("expected scalar type Float")
+        if depth.dim() != 2 or normal.dim() != 3 or normal.shape[0] != 3 or tuple(normal.shape[1:]) != tuple(depth.shape):
+            raise ValueError("expected depth (H, W) and normal (3, H, W)")
+        H, W = depth.shape
+        d, n = depth.contiguous(), normal.contiguous()
+        scale = float(scale_factor) if scale_factor is not None else 1.0
+        with torch.cuda.device(depth.device):
+            nbytes = _lib.tsl_depth_normal_workspace_bytes(H, W, scale)
+            ws = torch.empty((nbytes,), device=depth.device, dtype=torch.uint8)
+            out = torch.empty((1,), device=depth.device, dtype=torch.float32)
+            _native._check(_lib.tsl_depth_normal_forward(d.data_ptr(), n.data_ptr(), H, W, float(tan_fovx), float(tan_fovy), scale, float(quantile),
+                                                         ws.data_ptr(), nbytes, out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+                           "depth_normal_loss")
+        ctx.args = (H, W, float(tan_fovx), float(tan_fovy), scale)
+        ctx.save_for_backward(d, n, ws)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        d, n, ws = ctx.saved_tensors
+        H, W, tx, ty, scale = ctx.args
+        with torch.cuda.device(d.device):
+            gd = torch.empty_like(d) if ctx.needs_input_grad[0] else None
+            gn = torch.empty_like(n) if ctx.needs_input_grad[1] else None
+            go = grad_out.contiguous().to(torch.float32)
+            _native._check(_lib.tsl_depth_normal_backward(d.data_ptr(), n.data_ptr(), H, W, tx, ty, scale, ws.data_ptr(), ws.numel(), go.data_ptr(),
+                                                          gd.data_ptr() if gd is not None else None, gn.data_ptr() if gn is not None else None,
+                                                          torch.cuda.current_stream().cuda_stream), "depth_normal_loss backward")
+        return gd, gn, None, None, None, None
+
+
+class DepthNormalLoss(nn.Module):
+    """trainer_utils.py:204-257 with the reference's constructor and call surface:
+    `DepthNormalLoss(scale_factor=0.5)(depth, normal, cam.tan_fovx, cam.tan_fovy)` (VanillaTS_trainer.py:30-31,84).  One fused forward
+    (three elementwise launches + the library's radix sort for the quantile) and four launches backward instead of ~100 eager kernels."""
+
+    def __init__(self, depth_grad: bool = True, normal_grad: bool = True, scale_factor: float = None, depth_grad_filter_quantile: float = 0.9):
+        super().__init__()
+        self.depth_grad = depth_grad
+        self.normal_grad = normal_grad
+        self.scale_factor = scale_factor
+        self.depth_grad_filter_quantile = depth_grad_filter_quantile
+
+    def forward(self, depth: torch.Tensor, normal: torch.Tensor, tan_fovx: float, tan_fovy: float) -> torch.Tensor:
+        if not self.depth_grad:
+            depth = depth.detach()
+        if not self.normal_grad:
+            normal = normal.detach()
+        return _DepthNormal.apply(depth, normal, tan_fovx, tan_fovy, self.scale_factor, self.depth_grad_filter_quantile)
