@@ -29,7 +29,7 @@ import torch
 
 import synthetic
 import diff_recon_hip as D
-from diff_recon_hip import DensificationStats, photometric_loss, render_view
+from diff_recon_hip import DensificationStats, DepthNormalLoss, photometric_loss, render_view
 
 
 class Camera:
@@ -90,8 +90,13 @@ class SyntheticModel(DensificationStats):
             self.log.append((iteration, name, res, self._vertex.shape[0]))
 
 
-def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, seed=0, views=2, views_per_step=2, log=print, updates=True):
+def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, seed=0, views=2, views_per_step=2, log=print, updates=True,
+          w_geometry=0.0):
+    """w_geometry > 0 adds the depth / normal consistency term of the *_VanillaTS_mesh.yaml configurations (geometry_loss: w_geometry 0.05,
+    scale_factor 0.5, from iteration start_iter on; VanillaTS_trainer.py:30-31,64-65,84,111) -- the producer of dL_dout_depth / dL_dout_normal."""
     dev = torch.device("cuda")
+    geometry_loss = DepthNormalLoss(scale_factor=0.5) if w_geometry > 0 else None
+    g_start_iter = iters // 2  # the reference's configs start it at half of the schedule (15 000 of 30 000)
     D_sh = 2
     s = synthetic.scene(triangles, width, height, D_sh, seed=seed, edge_px=10.0)
     cams = [Camera(s, dev, (6.0 * v, -3.0 * v, 0.0)) for v in range(views)]
@@ -115,6 +120,8 @@ def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, se
             v = (it * views_per_step + k) % views
             pkg = render_view(cams[v], m._vertex, m._f_dc, m._f_rest, m._opacity, is_training=True, gamma=m.gamma, active_sh_degree=m.active_sh_degree, **kw)
             loss = photometric_loss(pkg["render"], gts[v], 0.8, 0.2)  # w_L1 = 1 - w_ssim, VanillaTS_trainer.py:72,111
+            if geometry_loss is not None and it > g_start_iter:
+                loss = loss + w_geometry * geometry_loss(pkg["depth"], pkg["normal"], cams[v].tan_fovx, cams[v].tan_fovy)
             loss.backward()
             pkgs.append(pkg)
             total += loss.item()
@@ -137,8 +144,9 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=400)
     ap.add_argument("--triangles", type=int, default=20000)
     ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--w-geometry", type=float, default=0.0, help="weight of the depth / normal consistency loss (0.05 in the *_VanillaTS_mesh configs)")
     a = ap.parse_args()
-    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views)
+    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views, w_geometry=a.w_geometry)
     for row in m.log:
         print("  update", row)
     print(f"{a.rasterizer}: loss {losses[0]:.5f} -> {losses[-1]:.5f} in {a.iters} iterations, {sec * 1e3:.2f} ms/iteration (incl. Python)")
