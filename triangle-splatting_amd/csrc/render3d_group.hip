@@ -93,18 +93,20 @@ __device__ __forceinline__ Cull3 cull3(V3 v1, V3 v2, V3 v3, V3 n, float op, floa
     return c;
 }
 
-__device__ __forceinline__ void publish_row3(float *row, V3 v1, V3 v2, V3 v3, V3 n, const Cull3 &c, const float4 &r3, float w18)
+// [19] = the entry's position in its batch; a list entry is the LDS byte offset of its row (render_group.hip, round 3)
+constexpr int BROW3 = ROW + 16; // backward row: constants + the entry's 16 gradient sums
+__device__ __forceinline__ void publish_row3(float *row, V3 v1, V3 v2, V3 v3, V3 n, const Cull3 &c, const float4 &r3, float w18, int jpos)
 {
     float4 *q = (float4 *)row;
     q[0] = make_float4(v1.x, v1.y, v1.z, v2.x);
     q[1] = make_float4(v2.y, v2.z, v3.x, v3.y);
     q[2] = make_float4(v3.z, n.x, n.y, n.z);
     q[3] = make_float4(c.d0, c.inn, r3.x, r3.y);
-    q[4] = make_float4(r3.z, r3.w, w18, 0.0f);
+    q[4] = make_float4(r3.z, r3.w, w18, __int_as_float(jpos));
 }
 // Second pass of a batch with more than NR surviving entries (rare): the lane gathers its entry's record again (see render_group.hip)
 __device__ __forceinline__ void republish_row3(float *row, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, uint32_t pos,
-                                               bool with_id)
+                                               bool with_id, int jpos)
 {
     const uint32_t id = point_list[pos];
     const float4 *rp = rec + 4 * (size_t)id;
@@ -113,16 +115,16 @@ __device__ __forceinline__ void republish_row3(float *row, const uint32_t *__res
     Cull3 c;
     c.inn = 1.0f / vdot(n, n);
     c.d0 = vdot(v1, n);
-    publish_row3(row, v1, v2, v3, n, c, r3, with_id ? __uint_as_float(id) : 0.0f);
+    publish_row3(row, v1, v2, v3, n, c, r3, with_id ? __uint_as_float(id) : 0.0f, jpos);
 }
 // Row -1: a unit triangle in the plane z = 1, a thousand units off axis, opacity 0: every pixel sees ecc ~ 3000
-__device__ __forceinline__ void write_dummy_row3(float *cst, int lane)
+__device__ __forceinline__ void write_dummy_row3(float *row, int lane)
 {
     if (lane < ROW)
     {
-        // v1 = (1000, 1000, 1), v2 = (1001, 1000, 1), v3 = (1000, 1001, 1), n = (0, 0, 1), d0 = 1, 1/n.n = 1
+        // v1 = (1000, 1000, 1), v2 = (1001, 1000, 1), v3 = (1000, 1001, 1), n = (0, 0, 1), d0 = 1, 1/n.n = 1; batch position 255
         const float tab[ROW] = {1000.0f, 1000.0f, 1.0f, 1001.0f, 1000.0f, 1.0f, 1000.0f, 1001.0f, 1.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        cst[lane - ROW] = tab[lane];
+        row[lane] = lane == 19 ? __int_as_float(255) : tab[lane];
     }
 }
 
@@ -211,7 +213,9 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
     const float bg0 = a.background[0], bg1 = a.C > 1 ? a.background[1] : 0.0f, bg2 = a.C > 2 ? a.background[2] : 0.0f;
     float *cst = cst_all[wave] + ROW;
     uint32_t *list = list_all[wave];
-    write_dummy_row3(cst, lane);
+    write_dummy_row3(cst - ROW, lane);
+    const char *lds0 = (const char *)cst_all;
+    const uint32_t row0 = (uint32_t)(wave * (NR + 1) + 1) * (ROW * 4), dummy = row0 - ROW * 4;
     const RowSel rsel(lane);
 
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, anx = 0.0f, any_ = 0.0f, anz = 0.0f, ad = 0.0f;
@@ -244,17 +248,17 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
         const int rank = lane_rank(any), nact = __popcll(any);
         const int r = rank & (NR - 1);
         bool mine = anybit && rank < NR;
-        if (mine) publish_row3(cst + r * ROW, v1, v2, v3, n, c, r3, 0.0f);
+        if (mine) publish_row3(cst + r * ROW, v1, v2, v3, n, c, r3, 0.0f, lane);
         for (int h = 0;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
-            list[lane] = 0xFFFFFFFFu;
+            list[lane] = dummy | (dummy << 16);
             int steps = 0;
 #pragma unroll
             for (int g = 0; g < 4; g++)
             {
                 const unsigned long long Mh = M[g] & mm;
-                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + lane_rank(Mh)] = (unsigned short)(r | (lane << 8));
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + lane_rank(Mh)] = (unsigned short)(row0 + r * (ROW * 4));
                 steps = max(steps, __popcll(Mh));
             }
             const uint32_t *mylist = list + grp * (NR / 2);
@@ -271,9 +275,8 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
                     if (t0 + st < steps)
                     {
                         const uint32_t word = st < 2 ? packed.x : (st < 4 ? packed.y : (st < 6 ? packed.z : packed.w));
-                        const uint32_t e16 = (word >> (16 * (st & 1))) & 0xFFFFu;
-                        const int jc = (int)(signed char)(e16 & 0xFFu), jpos = (int)(e16 >> 8); // table row, position in the batch
-                        const float *row = cst + jc * ROW;
+                        const float *row = (const float *)(lds0 + ((st & 1) ? (word >> 16) : (word & 0xFFFFu)));
+                        const int jpos = __float_as_int(row[19]); // position in the batch
                         const Hit3 h = hit3<false>(row, ray);
                         const float pw = GAMMA1 ? h.ecc * h.ecc : pow_nonneg(h.ecc, g2);
                         const float alpha = fminf(0.99f, h.op * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:259-260
@@ -310,7 +313,7 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
             }
             if (++h * NR >= nact) break;
             mine = anybit && rank >= NR;
-            if (mine) republish_row3(cst + r * ROW, point_list, rec, range.x + base + lane, false);
+            if (mine) republish_row3(cst + r * ROW, point_list, rec, range.x + base + lane, false, lane);
         }
     }
     if (RICH)
@@ -348,23 +351,35 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
 //   dL/dv1 = w2 cross(n, p_v3) / n.n + dL_ddepth n / (p_ray.n)        (:391, 402-403)
 //   dL_ddepth = dL_ddepth_pixel contrib + w1 da1_ddepth + w2 da2_ddepth, da1_ddepth = n.cross(v3 - v2, p_ray) / n.n, ...   (:389, 395, 401)
 //   dL/dn  = dL_dnormal_pixel contrib + (w1 (c1 - 2 a1 n) + w2 (c2 - 2 a2 n)) / n.n + dL_ddepth p_v1 / (p_ray.n)   (:388, 394, 403, 406)
-template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256, 6) render3d_bwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
+template <bool RICH, bool GAMMA1, int WPB> // WPB = quadrant waves per workgroup (1: single-wave workgroups, see render_group.hip)
+__global__ void __launch_bounds__(64 * WPB, 6) render3d_bwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
                                                                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                      const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                                      const float *__restrict__ dL_dout_feature,
                                                                      const float *__restrict__ dL_dout_depth,
                                                                      const float *__restrict__ dL_dout_normal, float *__restrict__ grad_rec)
 {
-    __shared__ __attribute__((aligned(16))) float cst_all[4][(NR + 1) * ROW];
-    __shared__ __attribute__((aligned(16))) float sums_all[4][(NR + 1) * 16];
-    __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2];
+    __shared__ __attribute__((aligned(16))) float rows_all[WPB][(NR + 1) * BROW3];
+    __shared__ __attribute__((aligned(16))) uint32_t list_all[WPB][4 * NR / 2];
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    int tile, quad, wave;
+    if (WPB == 4)
+    {
+        tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+        quad = wave = threadIdx.x >> 6;
+    }
+    else
+    {
+        const int ntiles = a.grid_x * a.grid_y, q8 = ntiles >> 3, r8 = ntiles & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        if ((j >> 2) >= q8 + (x < r8 ? 1 : 0)) return; // the grid is padded to the longest band
+        tile = x * q8 + min(x, r8) + (j >> 2);
+        quad = j & 3;
+        wave = 0;
+    }
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63;
     const int grp = lane >> 4, sub = lane & 15;
-    const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
+    const int X0 = tx * TS_TILE + (quad & 1) * 8, Y0 = ty * TS_TILE + (quad >> 1) * 8;
     const int lx = ((grp & 1) << 2) + (sub & 3), ly = ((grp >> 1) << 2) + (sub >> 2);
     const int px = X0 + lx, py = Y0 + ly;
     const bool inside = px < a.W && py < a.H;
@@ -374,10 +389,12 @@ __global__ void __launch_bounds__(256, 6) render3d_bwd_group_kernel(RenderArgs a
     const uint2 range = ranges[tile];
     const float g2 = 2.0f * a.gamma;
     const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
-    float *cst = cst_all[wave] + ROW;
-    float *sums = sums_all[wave] + 16;
+    float *rows = rows_all[wave] + BROW3;
     uint32_t *list = list_all[wave];
-    write_dummy_row3(cst, lane);
+    write_dummy_row3(rows - BROW3, lane);
+    char *lds0 = (char *)rows_all;
+    const uint32_t row0 = (uint32_t)(wave * (NR + 1) + 1) * (BROW3 * 4), dummy = row0 - BROW3 * 4;
+    const uint32_t accoff = ROW * 4 + 4 * sub;
 
     float T = inside ? final_T[pix] : 0.0f;
     const int last = inside ? (int)n_contrib[pix] : 0;
@@ -436,39 +453,39 @@ __global__ void __launch_bounds__(256, 6) render3d_bwd_group_kernel(RenderArgs a
         const int lrel = last - base;
         const int r = rank & (NR - 1);
         bool mine = anybit && (rank / NR) == (nact - 1) / NR;
-        if (mine) publish_row3(cst + r * ROW, v1, v2, v3, n, c, r3, __uint_as_float(id));
+        if (mine) publish_row3(rows + r * BROW3, v1, v2, v3, n, c, r3, __uint_as_float(id), lane);
         for (int h = (nact - 1) / NR;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
             if (mine)
             {
-                float4 *z = (float4 *)(sums + r * 16);
+                float4 *z = (float4 *)(rows + r * BROW3 + ROW);
                 z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
             }
-            list[lane] = 0xFFFFFFFFu;
+            list[lane] = dummy | (dummy << 16);
             int steps = 0;
 #pragma unroll
             for (int g = 0; g < 4; g++)
             {
                 const unsigned long long Mh = M[g] & mm;
                 const int nn = __popcll(Mh);
-                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (nn - 1 - lane_rank(Mh))] = (unsigned short)(r | (lane << 8));
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (nn - 1 - lane_rank(Mh))] = (unsigned short)(row0 + r * (BROW3 * 4));
                 steps = max(steps, nn);
             }
             const u16a *mylist = (const u16a *)list + grp * NR;
             unsigned long long conflict;
             {
                 const u16a *l16 = (const u16a *)list + (lane & (NR - 1));
-                const int l0 = l16[0] & 0xFF, l1 = l16[NR] & 0xFF, l2 = l16[2 * NR] & 0xFF, l3 = l16[3 * NR] & 0xFF;
-                conflict = ballot(lane < NR && ((l0 != 0xFF && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != 0xFF && (l1 == l2 || l1 == l3)) ||
-                                                (l2 != 0xFF && l2 == l3)));
+                const uint32_t l0 = l16[0], l1 = l16[NR], l2 = l16[2 * NR], l3 = l16[3 * NR];
+                conflict = ballot(lane < NR && ((l0 != dummy && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != dummy && (l1 == l2 || l1 == l3)) ||
+                                                (l2 != dummy && l2 == l3)));
             }
             for (int t0 = 0; t0 < steps; t0++)
             {
-                const uint32_t e16 = mylist[t0];
-                const int jc = (int)(signed char)(e16 & 0xFFu), jpos = (int)(e16 >> 8);
-                const float *row = cst + jc * ROW;
-                float *acc = sums + jc * 16 + sub;
+                const uint32_t ra = mylist[t0];
+                const float *row = (const float *)(lds0 + ra);
+                float *acc = (float *)(lds0 + ra + accoff);
+                const int jpos = __float_as_int(row[19]);
                 const bool shared_row = (conflict >> t0) & 1;
                 const float acc0 = *acc;
                 const Hit3 h = hit3<true>(row, ray);
@@ -532,14 +549,14 @@ __global__ void __launch_bounds__(256, 6) render3d_bwd_group_kernel(RenderArgs a
                     const int e = e0 + grp;
                     if (e < nn)
                     {
-                        const uint32_t eid = __float_as_uint(cst[e * ROW + 18]);
-                        unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, sums[e * 16 + sub]);
+                        const uint32_t eid = __float_as_uint(rows[e * BROW3 + 18]);
+                        unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, rows[e * BROW3 + ROW + sub]);
                     }
                 }
             }
             if (--h < 0) break;
             mine = anybit && rank < NR;
-            if (mine) republish_row3(cst + r * ROW, point_list, rec, range.x + base + lane, true);
+            if (mine) republish_row3(rows + r * BROW3, point_list, rec, range.x + base + lane, true, lane);
         }
     }
 }
@@ -571,6 +588,15 @@ void ts_launch_render3d_bwd_group(const RenderArgs &a, float tan_fovx, float tan
 {
     const dim3 grid((unsigned)(a.grid_x * a.grid_y));
     if (grid.x == 0) return;
-    TS_DISPATCH_G3(render3d_bwd_group_kernel, a, tan_fovx, tan_fovy, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature,
-                   dL_dout_depth, dL_dout_normal, grad_rec);
+    constexpr int WPB = 1;
+    const int ntiles = a.grid_x * a.grid_y;
+    const dim3 grid1((unsigned)(WPB == 4 ? ntiles : 8 * 4 * ((ntiles + 7) / 8)));
+    const bool g1 = (a.gamma == 1.0f);
+#define TS_BWD3(R, G) hipLaunchKernelGGL((render3d_bwd_group_kernel<R, G, WPB>), grid1, dim3(64 * WPB), 0, s, a, tan_fovx, tan_fovy, im.ranges, b.vals, \
+                                         g.rec, im.final_T, im.n_contrib, dL_dout_feature, dL_dout_depth, dL_dout_normal, grad_rec)
+    if (a.rich_info && g1) TS_BWD3(true, true);
+    else if (a.rich_info) TS_BWD3(true, false);
+    else if (g1) TS_BWD3(false, true);
+    else TS_BWD3(false, false);
+#undef TS_BWD3
 }
