@@ -46,6 +46,12 @@ KERNEL(k_lshladd, "", "v_lshl_add_u32 %0, %1, 6, %2\n v_lshl_add_u32 %3, %4, 6, 
 KERNEL(k_lshl, "", "v_lshlrev_b32 %0, 3, %1\n v_lshrrev_b32 %3, 5, %4\n")
 KERNEL(k_bfe, "", "v_bfe_u32 %0, %1, 8, 8\n v_bfe_i32 %3, %4, 0, 8\n")
 KERNEL(k_mad24, "", "v_mad_u32_u24 %0, %1, %2, %0\n v_mad_u32_u24 %3, %4, %5, %3\n")
+KERNEL(k_bfi, "", "v_bfi_b32 %0, %1, %2, %0\n v_bfi_b32 %3, %4, %5, %3\n")
+KERNEL(k_or3, "", "v_or3_b32 %0, %1, %2, %0\n v_and_or_b32 %3, %4, %5, %3\n")
+KERNEL(k_xor, "", "v_xor_b32 %0, %1, %0\n v_or_b32 %3, %4, %3\n")
+KERNEL(k_max_f, "", "v_max_f32 %0, %1, %0\n v_max_f32 %3, %4, %3\n")
+KERNEL(k_fmac, "", "v_fmac_f32 %0, %1, %2\n v_fmac_f32 %3, %4, %5\n")
+KERNEL(k_cvt, "", "v_cvt_f32_u32 %0, %1\n v_cvt_u32_f32 %3, %4\n")
 KERNEL(k_min3, "", "v_min3_f32 %0, %1, %2, %0\n v_min3_f32 %3, %4, %5, %3\n")
 KERNEL(k_min, "", "v_min_f32 %0, %1, %0\n v_min_f32 %3, %4, %3\n")
 KERNEL(k_swap32, "", "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %3, %4\n")
@@ -92,6 +98,7 @@ int main()
     RUN("cndmask sgpr", k_cnd_sgpr); RUN("v_cmp vcc", k_cmp_vcc); RUN("v_cmp sgpr", k_cmp_sgpr); RUN("cmp+cndmask", k_cmp_cnd);
     RUN("dpp quad_perm", k_dpp_quad); RUN("dpp row_ror", k_dpp_ror); RUN("dpp bank_mask", k_dpp_bank); RUN("dpp mov", k_dpp_mov);
     RUN("add/and u32", k_andsub); RUN("v_lshl_add", k_lshladd); RUN("v_lshl/lshr", k_lshl); RUN("v_bfe", k_bfe); RUN("v_mad_u32_u24", k_mad24);
+    RUN("v_bfi_b32", k_bfi); RUN("v_or3/and_or", k_or3); RUN("v_xor/or", k_xor); RUN("v_max_f32", k_max_f); RUN("v_fmac_f32", k_fmac); RUN("v_cvt", k_cvt);
     RUN("v_min3_f32", k_min3); RUN("v_min_f32", k_min);
     RUN("permlane32", k_swap32); RUN("v_rcp_f32", k_rcp); RUN("v_exp_f32", k_exp);
     RUN("3fma+exp", k_fma3_exp, 128.0); RUN("fma+dpp", k_fma_dpp); RUN("3fma+dpp", k_fma3_dpp, 128.0); RUN("fma+cndmask", k_fma_cnd);
