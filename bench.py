@@ -298,29 +298,30 @@ USEFUL_FLOP_PER_PAIR = {"render_fwd": 60, "render_bwd": 175}  # fp32 operations 
 FP32_VECTOR_PEAK = 157.3e12                                   # MI355X_MICROARCH.md
 
 
-MIX_CYCLES_PER_VALU_INST = {"render_bwd": 3.3, "render_fwd": 3.0}
-
-
 def compute_side(kernel, avg_ms, headline):
-    """The roofline the blend kernels actually sit on (they are VALU-bound), from the committed SQ-counter pass
-    of the same workload (profiles/blend_pmc.json, tools/collect_blend_pmc.sh) and the lane-group statistics
-    (profiles/blend_stats.json): VALU issue-slot utilisation = SQ_INSTS_VALU x 2 cycles (wave64 on a SIMD-32) over
-    SIMDs x kernel cycles -- at most 1 by construction --, blended (pixel, triangle) pairs per second and the useful fp32
-    rate as a fraction of the 157 TFLOP/s vector peak.  Durations: the timed-region HIP events of THIS run."""
+    """The roofline the blend kernels actually sit on (they are bound by VALU issue), from the committed SQ-counter
+    pass of the same workload (profiles/blend_pmc.json, tools/collect_blend_pmc.sh), the static instruction mix of the kernel's step
+    loop (profiles/r03_valu_mix.json, tools/isa_mix.py) and the lane-group statistics (profiles/blend_stats.json).  Two bounds on the
+    VALU time, both in the kernel's own cycles (GRBM_GUI_ACTIVE of the launch):
+      valu_busy_frac_lower = SQ_INSTS_VALU x 2 cycles (every instruction at the full wave64-on-SIMD32 rate) / (SIMDs x cycles);
+      valu_busy_frac_upper = SQ_INSTS_VALU x the step loop's mix priced with the issue costs measured in REAL shader cycles
+                             (tools/valu_bench3.hip: 2 / 4 / 8 cycles for full-rate / half-rate / transcendental instructions; half-rate
+                             instructions interleaved with FMAs issue faster than that, hence an upper estimate).
+    Plus blended (pixel, triangle) pairs per second and the useful fp32 rate as a fraction of the 157 TFLOP/s vector peak.
+    Durations: the timed-region HIP events of THIS run."""
     out = {}
     try:
         v = json.load(open(os.path.join(ROOT, "profiles", "blend_pmc.json"))).get(PMC_NAMES.get(kernel, ""))
         if v:
-            out.update(valu_insts_per_launch=v["SQ_INSTS_VALU"], valu_issue_slot_frac=v["valu_issue_frac_at_2cyc"],
+            out.update(valu_insts_per_launch=v["SQ_INSTS_VALU"], valu_busy_frac_lower=v["valu_issue_frac_at_2cyc"],
                        transcendental_insts_per_launch=v.get("SQ_INSTS_VALU_TRANS_F32"), lds_busy_frac=v.get("lds_busy_frac"),
-                       avg_waves_per_simd=v.get("avg_waves_per_simd"), wave_cycle_split=v.get("wave_cycle_split"))
-            # the same count priced with the MEASURED per-class issue costs (tools/valu_bench2.hip: 2.5 cycles full rate, 4.3 for
-            # compare / select / min / every DPP form, 8.3 transcendental) at the static instruction mix of the kernel's step
-            # loop (DESIGN.md 5.3): an estimate of how much of the VALU issue capacity the launch consumes
-            mix = MIX_CYCLES_PER_VALU_INST.get(kernel)
+                       avg_waves_per_simd=v.get("avg_waves_per_simd"), wave_cycle_split=v.get("wave_cycle_split"),
+                       kernel_cycles=v.get("kernel_cycles"))
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json"))).get(kernel)
             if mix and v.get("kernel_cycles"):
-                out.update(valu_cycles_per_inst_at_measured_mix=mix,
-                           valu_busy_frac_est=round(v["SQ_INSTS_VALU"] * mix / (1024.0 * v["kernel_cycles"]), 4))
+                out.update(step_loop_mix={k: mix[k] for k in ("full", "half", "trans")},
+                           priced_cycles_per_valu_instruction=mix["priced_cycles_per_valu_instruction"],
+                           valu_busy_frac_upper=round(min(1.0, v["SQ_INSTS_VALU"] * mix["priced_cycles_per_valu_instruction"] / (1024.0 * v["kernel_cycles"])), 4))
     except Exception:
         pass
     try:

@@ -214,15 +214,25 @@ def test_depth_normal_loss_full_size_against_oracle_and_flags():
     n = torch.from_numpy(normal).cuda().requires_grad_(True)
     loss = DepthNormalLoss(scale_factor=0.5)(d, n, 0.3148, 0.3148 * H / W)
     loss.backward()
-    want, dd, dn = O.depth_normal_loss(depth, normal, 0.3148, 0.3148 * H / W, 0.5, 0.9)
+    aux = {}
+    want, dd, dn = O.depth_normal_loss(depth, normal, 0.3148, 0.3148 * H / W, 0.5, 0.9, aux=aux)
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     assert abs(float(loss) - want) < 1e-5 * abs(want)
-    # dL/ddepth is a sum of differences of nearly equal terms (Scharr adjoint of 1 / d-scaled values): float32 against the float64
-    # oracle sits at ~5e-4 at this size (against the reference's own float32 autograd the small cases above agree to 1e-4)
-    assert rel(d.grad.cpu().numpy(), dd) < 1e-3 and rel(n.grad.cpu().numpy(), dn) < 1e-4
+    # The mask is a hard threshold (G < quantile(G, 0.9), trainer_utils.py:240-241): among two million pixels a few sit within float32
+    # rounding of it and land on the other side in a float32 evaluation (the reference's own included); each carries its whole per-pixel
+    # gradient (measured: 8 of 2 073 600 pixels, up to 1.7e-5 of the threshold away; without them the gradients agree to 1.6e-5).  Pixels
+    # with |G - thr| < 1e-4 thr are set aside, everything else must agree.
+    tie = np.abs(aux["G"] - aux["threshold"]) < 1e-4 * aux["threshold"]
+    assert tie.sum() < 2000
+    gn = n.grad.cpu().numpy()
+    assert rel(gn[:, ~tie], dn[:, ~tie]) < 1e-4
+    # dL/ddepth spreads every pixel's term over its neighbours (up-sampling, Scharr and down-sampling adjoints) and is a sum of differences
+    # of nearly equal terms: float32 against the float64 oracle sits at ~5e-4 at this size (against the reference's own float32 autograd
+    # the small cases above agree to 1e-4)
+    assert rel(d.grad.cpu().numpy(), dd) < 1e-3
     d2 = torch.from_numpy(depth).cuda().requires_grad_(True)
     n2 = torch.from_numpy(normal).cuda().requires_grad_(True)
     DepthNormalLoss(depth_grad=False, scale_factor=0.5)(d2, n2, 0.3148, 0.3148 * H / W).backward()
-    assert d2.grad is None and rel(n2.grad.cpu().numpy(), dn) < 1e-4
+    assert d2.grad is None and rel(n2.grad.cpu().numpy()[:, ~tie], dn[:, ~tie]) < 1e-4
     with pytest.raises(RuntimeError):
         DepthNormalLoss(scale_factor=0.5)(torch.from_numpy(depth), torch.from_numpy(normal), 0.3, 0.2)

@@ -26,15 +26,34 @@ def load(d, counter):
 
 
 known = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+# optional 4th argument: a --pmc FETCH_SIZE pass of tools/bin/gather_calib (64-byte record gathers / a streaming read of KNOWN size)
+gather_factor = stream_factor = None
+if len(sys.argv) > 4:
+    f = sorted(glob.glob(sys.argv[4] + "/*/*_counter_collection.csv"))[-1]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "FETCH_SIZE":
+            acc["gather64" if "gather64" in r["Kernel_Name"] else "stream64" if "stream64" in r["Kernel_Name"] else "other"].append(float(r["Counter_Value"]))
+    n_rec = 4 * 1000 * 1000 + 1
+    if acc.get("gather64"):
+        gather_factor = (n_rec * 68.0) / (sum(acc["gather64"]) / len(acc["gather64"]) * 1024.0)  # 64 B record + 4 B index per lane
+    if acc.get("stream64"):
+        stream_factor = (n_rec * 64.0) / (sum(acc["stream64"]) / len(acc["stream64"]) * 1024.0)
 (fetch, nf), (write, nw) = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 wcal = 1.0
 if known > 0 and write.get("fillBuffer", 0) > 0:
     wcal = known / (write["fillBuffer"] * 1024.0)
 out = {"_calibration": {"fetch_factor": 2.0, "write_factor": round(wcal, 4),
                         "write_calibrated_on": f"fill kernel of {int(known)} known bytes: WRITE_SIZE reported {write.get('fillBuffer', 0):.1f} KiB",
-                        "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (wide reads); WRITE_SIZE x write_factor (own calibration)"}}
+                        "fetch_factor_measured_64B_record_gather": None if gather_factor is None else round(gather_factor, 4),
+                        "fetch_factor_measured_streaming_dwordx4": None if stream_factor is None else round(stream_factor, 4),
+                        "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (wide reads); WRITE_SIZE x write_factor (own calibration); the blend kernels read "
+                                "64-byte records by gather: `hbm_bytes_per_launch_gather_calibrated` prices their FETCH_SIZE with the factor measured "
+                                "on a gather of known size (tools/gather_calib.hip)"}}
 for k in sorted(set(fetch) | set(write)):
     f_kib, w_kib = fetch.get(k, 0.0), write.get(k, 0.0)
     out[k] = {"FETCH_SIZE_KiB": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1), "launches": nf.get(k, nw.get(k, 0)),
               "hbm_bytes_per_launch": int((2.0 * f_kib + wcal * w_kib) * 1024)}
+    if gather_factor is not None and k.startswith("render"):
+        out[k]["hbm_bytes_per_launch_gather_calibrated"] = int((gather_factor * f_kib + wcal * w_kib) * 1024)
 print(json.dumps(out, indent=1))
