@@ -480,9 +480,11 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
                 conflict = ballot(lane < NR && ((l0 != dummy && (l0 == l1 || l0 == l2 || l0 == l3)) || (l1 != dummy && (l1 == l2 || l1 == l3)) ||
                                                 (l2 != dummy && l2 == l3)));
             }
+            uint32_t ra_next = mylist[0];
             for (int t0 = 0; t0 < steps; t0++)
             {
-                const uint32_t ra = mylist[t0];
+                const uint32_t ra = ra_next;
+                ra_next = mylist[min(t0 + 1, NR - 1)]; // one step ahead (render_group.hip)
                 const float *row = (const float *)(lds0 + ra);
                 float *acc = (float *)(lds0 + ra + accoff);
                 const int jpos = __float_as_int(row[19]);
@@ -508,7 +510,8 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
                 const float dL_dcontrib = X - B;
                 B = fmaf(al, X, oma * B);
                 const float dL_dalpha = dL_dcontrib * T; // :383
-                const float zr = 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(h.ecc + 1e-8f); // -3 dL_decc, :384-385
+                // -3 dL_decc, :384-385 (gamma = 1: pw / (ecc + 1e-8) is ecc to 1e-8 / ecc relative, see render_group.hip)
+                const float zr = GAMMA1 ? 1.5f * g2 * (dL_dalpha * alpha) * h.ecc : 1.5f * g2 * (dL_dalpha * alpha) * pw * __builtin_amdgcn_rcpf(h.ecc + 1e-8f);
                 const float z = (hit && opG < 0.99f) ? zr : 0.0f;
                 const bool k1 = h.a1 == h.mn;
                 const bool k2 = !k1 && h.a2 == h.mn;
