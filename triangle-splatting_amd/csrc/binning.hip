@@ -31,7 +31,7 @@
 
 namespace
 {
-constexpr int CH = TS_RS_CHUNK, NB = TS_RS_BINS;
+constexpr int NB = TS_RS_BINS;
 
 __device__ __forceinline__ unsigned long long ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 
@@ -81,6 +81,7 @@ __device__ __forceinline__ const uint32_t *sorted_ids(const GeometryStateView &g
 // Sync-free forward (ts2d_forward): the pair count lives on the device.  `n_dev` (null on the synchronous path) points at the
 // 64-bit instance count the scan left behind; a count above `n` (the capacity the buffers were carved for) renders nothing and is
 // reported through the state's status word.  The launch covers the capacity; blocks past the actual count return at once.
+template <int CH>
 __device__ __forceinline__ bool resolve_count(const unsigned long long *n_dev, int64_t &n, RadixScratchView &r)
 {
     if (n_dev)
@@ -116,14 +117,14 @@ struct DepthCensus
 };
 __device__ __forceinline__ bool pass_skipped(const uint32_t *skip_flag) { return skip_flag && peer_load(skip_flag) != 0u; }
 
-template <bool CENSUS>
+template <bool CENSUS, int CH>
 __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict__ keys, int64_t n, const unsigned long long *n_dev, int shift,
                                                        uint32_t mask, RadixScratchView r, DepthCensus census, const uint32_t *skip_flag)
 {
     __shared__ uint32_t bins[NB];
     __shared__ unsigned long long csum[4];
     __shared__ uint32_t cor[4], cand[4];
-    if (!resolve_count(n_dev, n, r)) return;
+    if (!resolve_count<CH>(n_dev, n, r)) return;
     if (!CENSUS && pass_skipped(skip_flag)) return;
     const int t = threadIdx.x, chunk = blockIdx.x;
     bins[t] = 0u;
@@ -247,13 +248,13 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
 //   3. every pair is parked in LDS at its chunk-local sorted position, and the chunk leaves in that order: consecutive threads
 //      write consecutive addresses inside each digit's run (scattering straight from registers costs a 32-64 B fabric write
 //      per 4-byte store on this chip: measured 2x slower than rocPRIM; staged, the stores are coalesced runs).
-template <bool IDENTITY_VALUES>
+template <bool IDENTITY_VALUES, int CH>
 __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                           uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n,
                                                           const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r, const uint32_t *skip_flag)
 {
     constexpr int KB = CH / 256; // steps per wave
-    if (!resolve_count(n_dev, n, r)) return;
+    if (!resolve_count<CH>(n_dev, n, r)) return;
     if (pass_skipped(skip_flag)) return;
     __shared__ uint32_t stage_k[CH], stage_v[CH];
     __shared__ uint32_t wcnt[4][NB]; // per-wave digit counts, then the chunk-local start of the (wave, digit) run
@@ -336,15 +337,24 @@ void radix_hist(const uint32_t *kin, int64_t n, const unsigned long long *n_dev,
                 const DepthCensus *census = nullptr, const uint32_t *skip_flag = nullptr)
 {
     const dim3 grid((unsigned)r.chunks);
-    if (census) hipLaunchKernelGGL((rs_hist_kernel<true>), grid, dim3(256), 0, s, kin, n, n_dev, shift, (1u << nbits) - 1u, r, *census, skip_flag);
-    else hipLaunchKernelGGL((rs_hist_kernel<false>), grid, dim3(256), 0, s, kin, n, n_dev, shift, (1u << nbits) - 1u, r, DepthCensus{}, skip_flag);
+    const uint32_t mask = (1u << nbits) - 1u;
+    const bool small = r.chunk == TS_RS_CHUNK_SMALL;
+    if (census && small) hipLaunchKernelGGL((rs_hist_kernel<true, TS_RS_CHUNK_SMALL>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, *census, skip_flag);
+    else if (census) hipLaunchKernelGGL((rs_hist_kernel<true, TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, *census, skip_flag);
+    else if (small) hipLaunchKernelGGL((rs_hist_kernel<false, TS_RS_CHUNK_SMALL>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, DepthCensus{}, skip_flag);
+    else hipLaunchKernelGGL((rs_hist_kernel<false, TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, DepthCensus{}, skip_flag);
 }
 void radix_scatter(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
                    int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag = nullptr)
 {
     const dim3 grid((unsigned)r.chunks);
-    if (vin) hipLaunchKernelGGL((rs_scatter_kernel<false>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag);
-    else hipLaunchKernelGGL((rs_scatter_kernel<true>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag);
+    const bool small = r.chunk == TS_RS_CHUNK_SMALL;
+#define TS_SCATTER(ID, C) hipLaunchKernelGGL((rs_scatter_kernel<ID, C>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag)
+    if (vin && small) TS_SCATTER(false, TS_RS_CHUNK_SMALL);
+    else if (vin) TS_SCATTER(false, TS_RS_CHUNK);
+    else if (small) TS_SCATTER(true, TS_RS_CHUNK_SMALL);
+    else TS_SCATTER(true, TS_RS_CHUNK);
+#undef TS_SCATTER
 }
 void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
                 int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag = nullptr)
@@ -596,11 +606,12 @@ void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const Bin
 }
 
 // ---- the same sort for other callers (knn.hip: 30-bit Morton codes) --------------------------------------------------------
+static int generic_chunk(size_t n) { return n <= (size_t)2500000 ? TS_RS_CHUNK_SMALL : TS_RS_CHUNK; } // few keys: more, shorter workgroups
 size_t ts_radix_scratch_bytes(size_t n)
 {
     RadixScratchView r{};
     char *p = nullptr;
-    ts_carve_radix(p, n, r);
+    ts_carve_radix(p, n, r, generic_chunk(n));
     return (size_t)p + TS_ALIGN;
 }
 // Stable LSD sort of (key, value) pairs by key bits [0, end_bit).  k[0] / v[0] hold the input, k[1] / v[1] are the ping-pong partners;
@@ -610,7 +621,7 @@ int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, in
     if (n == 0) return 0;
     RadixScratchView r{};
     char *p = (char *)ts_align_up((size_t)scratch);
-    ts_carve_radix(p, n, r);
+    ts_carve_radix(p, n, r, generic_chunk(n));
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((r.slabs + 8 + 255) / 256)), dim3(256), 0, s, r.tickets, r.slabs + 8);
     const int passes = (end_bit + 7) / 8;
     int src = 0;
@@ -656,12 +667,12 @@ int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
     BinningStateView b{};
     RadixScratchView r{};
     char *p = nullptr;
-    ts_carve_radix(p, n, r);
+    ts_carve_radix(p, n, r, generic_chunk(n)); // <= 2.5 M pairs exercise the 2048-pair kernels, more the 4096-pair ones
     const size_t scratch = (size_t)p + TS_ALIGN, bytes = scratch + 4 * (n * 4 + TS_ALIGN);
     char *base = nullptr;
     if (hipMalloc((void **)&base, bytes) != hipSuccess) return 2;
     p = base;
-    ts_carve_radix(p, n, b.rs);
+    ts_carve_radix(p, n, b.rs, generic_chunk(n));
     for (int i = 0; i < 2; i++) { ts_carve(p, b.k[i], n); ts_carve(p, b.v[i], n); }
     b.passes = (end_bit + 7) / 8;
     hipError_t e = hipMemcpyAsync(b.k[0], keys_in, n * 4, hipMemcpyDeviceToDevice, s);

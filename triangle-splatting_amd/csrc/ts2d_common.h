@@ -29,8 +29,11 @@
 #define TS_GRAD_FLOATS 16
 
 // Scratch of one stable LSD radix pass over n (key, value) pairs (binning.hip): per-chunk digit counts, their per-slab
-// and per-digit prefixes.  One chunk = TS_RS_CHUNK consecutive pairs = one workgroup; one slab = 64 chunks.
+// and per-digit prefixes.  One chunk = consecutive pairs handled by one workgroup; one slab = 64 chunks.  The chunk length is a property
+// of the sort: 4096 pairs for the instance sort (millions of pairs: longer digit runs = better coalesced scatter stores), 2048 for the
+// per-triangle depth sort (1 M keys are only 245 workgroups of 4096 -- one per CU; measured 0.103 vs 0.113 ms, profiles/r03_notes.md).
 #define TS_RS_CHUNK 4096
+#define TS_RS_CHUNK_SMALL 2048
 #define TS_RS_BINS 256
 struct RadixScratchView
 {
@@ -39,6 +42,7 @@ struct RadixScratchView
     uint32_t *binbase; // 256            exclusive prefix of the digit totals
     uint32_t *tickets; // TS_RS_TICKETS  "last block finishes" tickets: [0] pass, [1] scan blocks, [2 + slab] per slab; zero between launches
     int chunks, slabs;
+    int chunk; // pairs per chunk: TS_RS_CHUNK or TS_RS_CHUNK_SMALL
 };
 
 struct GeometryStateView
@@ -86,9 +90,10 @@ static inline void ts_carve(char *&p, T *&out, size_t count)
     p += count * sizeof(T);
 }
 
-static inline void ts_carve_radix(char *&p, size_t n, RadixScratchView &r)
+static inline void ts_carve_radix(char *&p, size_t n, RadixScratchView &r, int chunk = TS_RS_CHUNK)
 {
-    r.chunks = (int)((n + TS_RS_CHUNK - 1) / TS_RS_CHUNK);
+    r.chunk = chunk;
+    r.chunks = (int)((n + chunk - 1) / chunk);
     r.slabs = (r.chunks + 63) / 64;
     ts_carve(p, r.table, (size_t)r.chunks * TS_RS_BINS);
     ts_carve(p, r.slabtot, (size_t)r.slabs * TS_RS_BINS);
@@ -114,7 +119,7 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.tiles_sorted, n);
     ts_carve(p, v.offsets, n);
     ts_carve(p, v.blocksum, (n + 1023) / 1024 + 2);
-    ts_carve_radix(p, n, v.rs);
+    ts_carve_radix(p, n, v.rs, TS_RS_CHUNK_SMALL);
     v.top_const = v.rs.tickets + v.rs.slabs + 4;
     return (size_t)(p - base) + TS_ALIGN;
 }
