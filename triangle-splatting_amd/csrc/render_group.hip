@@ -33,7 +33,8 @@
 #include "ts2d_group.h"
 
 #ifndef TSG_PROBE
-#define TSG_PROBE 0 // profiling builds: 1 = no contribution atomics, 2 = no contribution statistics at all (results wrong)
+#define TSG_PROBE 0 // profiling builds: 1 = no contribution atomics, 2 = no contribution statistics at all, 3 = no serialised accumulate,
+                    // 4 = backward without its step loop (what the per-batch work alone costs) -- results wrong
 #endif
 namespace
 {
@@ -539,6 +540,7 @@ __global__ void __launch_bounds__(64 * WPB, 7) render_bwd_group_kernel(RenderArg
                 steps = max(steps, n);
             }
             const u16a *mylist = (const u16a *)list + grp * NR;
+            if (TSG_PROBE == 4) steps = 0;
 
             // steps at which two groups work on the SAME entry (their sums must then be added to its row one after the other)
             unsigned long long conflict;
