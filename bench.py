@@ -310,6 +310,8 @@ def compute_side(kernel, avg_ms, headline):
     Plus blended (pixel, triangle) pairs per second and the useful fp32 rate as a fraction of the 157 TFLOP/s vector peak.
     Durations: the timed-region HIP events of THIS run."""
     out = {}
+    if not headline:  # the counter passes were collected on the 2D headline workload only: nothing to quote for another one
+        return None
     try:
         v = json.load(open(os.path.join(ROOT, "profiles", "blend_pmc.json"))).get(PMC_NAMES.get(kernel, ""))
         if v:
