@@ -169,15 +169,16 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
     const int slab = chunk >> 6, c0 = slab * 64, c1 = min(r.chunks, c0 + 64);
     if (!last_arrival(r.tickets + 2 + slab, (uint32_t)(c1 - c0))) return;
     uint32_t run = 0;
-    for (int c = c0; c < c1; c += 16)
     {
-        uint32_t v[16];
+        // the elected block is alone on the launch's critical path: all 64 rows of the slab are requested before the first one is used
+        // (one memory round trip instead of four)
+        uint32_t v[64];
 #pragma unroll
-        for (int k = 0; k < 16; k++) v[k] = (c + k < c1) ? peer_load(r.table + (size_t)(c + k) * NB + t) : 0u;
+        for (int k = 0; k < 64; k++) v[k] = (c0 + k < c1) ? peer_load(r.table + (size_t)(c0 + k) * NB + t) : 0u;
 #pragma unroll
-        for (int k = 0; k < 16; k++)
+        for (int k = 0; k < 64; k++)
         {
-            if (c + k < c1) r.table[(size_t)(c + k) * NB + t] = run;
+            if (c0 + k < c1) r.table[(size_t)(c0 + k) * NB + t] = run;
             run += v[k];
         }
     }
@@ -185,29 +186,28 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
 
     if (!last_arrival(r.tickets, (uint32_t)r.slabs)) return;
     uint32_t total = 0;
-    for (int s = 0; s < r.slabs; s += 8)
+    for (int s = 0; s < r.slabs; s += 32)
     {
-        uint32_t v[8];
+        uint32_t v[32];
 #pragma unroll
-        for (int k = 0; k < 8; k++) v[k] = (s + k < r.slabs) ? peer_load(r.slabtot + (size_t)(s + k) * NB + t) : 0u;
+        for (int k = 0; k < 32; k++) v[k] = (s + k < r.slabs) ? peer_load(r.slabtot + (size_t)(s + k) * NB + t) : 0u;
 #pragma unroll
-        for (int k = 0; k < 8; k++)
+        for (int k = 0; k < 32; k++)
         {
             if (s + k < r.slabs) r.slabtot[(size_t)(s + k) * NB + t] = total;
             total += v[k];
         }
     }
-    __shared__ uint32_t tot[NB];
-    tot[t] = total;
-    __syncthreads();
-    for (int d = 1; d < NB; d <<= 1) // inclusive Hillis-Steele over the 256 digit totals
     {
-        const uint32_t add = (t >= d) ? tot[t - d] : 0u;
+        // exclusive prefix of the 256 digit totals: wave64 DPP scan + the preceding waves' totals
+        __shared__ uint32_t wtot[4];
+        const uint32_t inc = wave_inclusive_scan(total, t & 63);
+        if ((t & 63) == 63) wtot[t >> 6] = inc;
         __syncthreads();
-        tot[t] += add;
-        __syncthreads();
+        uint32_t before = 0;
+        for (int w = 0; w < (t >> 6); w++) before += wtot[w];
+        r.binbase[t] = before + inc - total;
     }
-    r.binbase[t] = tot[t] - total;
     if (CENSUS)
     {
         // this block arrived last of all: every chunk's census is visible (same hand-off as the digit counts)
@@ -240,6 +240,34 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
     }
 }
 
+// Ticket-free histogram (round 3): a pass of the hierarchical version above is a chain of seven dependent memory round trips (keys ->
+// counts -> ticket -> slab rows -> ticket -> slab totals -> prefixes) that one elected block walks alone while the chip idles; at 1 M keys
+// that chain IS the kernel (18 us for 4 MB of keys).  Here a block leaves its 256 counts as a table row and adds them to its slab's totals
+// with fire-and-forget atomics, and that is all; the scatter kernel that follows works out the three prefixes it needs from the rows
+// (<= 63 rows of its slab + the slabs' totals, loaded while its keys are on their way).
+template <int CH>
+__global__ void __launch_bounds__(256) rs_hist_direct_kernel(const uint32_t *__restrict__ keys, int64_t n, const unsigned long long *n_dev, int shift,
+                                                              uint32_t mask, RadixScratchView r, uint32_t *__restrict__ acc, const uint32_t *skip_flag)
+{
+    __shared__ uint32_t bins[NB];
+    if (!resolve_count<CH>(n_dev, n, r)) return;
+    if (pass_skipped(skip_flag)) return;
+    const int t = threadIdx.x, chunk = blockIdx.x;
+    bins[t] = 0u;
+    __syncthreads();
+    const int64_t base = (int64_t)chunk * CH;
+#pragma unroll
+    for (int b = 0; b < CH / 256; b++)
+    {
+        const int64_t i = base + 256 * b + t;
+        if (i < n) atomicAdd(&bins[(keys[i] >> shift) & mask], 1u);
+    }
+    __syncthreads();
+    const uint32_t c = bins[t];
+    r.table[(size_t)chunk * NB + t] = c;
+    if (c) __hip_atomic_fetch_add(acc + (size_t)(chunk >> 6) * NB + t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One workgroup = one chunk of CH pairs; wave w owns the w-th quarter (KB steps of 64 consecutive pairs, held in registers).
 //   1. wave-local stable ranks: per step the lanes holding equal digits find each other with `nbits` ballots (wave64 match),
 //      rank = v_mbcnt of the match mask on top of the digit's running count in the wave's LDS counters;
@@ -248,18 +276,22 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
 //   3. every pair is parked in LDS at its chunk-local sorted position, and the chunk leaves in that order: consecutive threads
 //      write consecutive addresses inside each digit's run (scattering straight from registers costs a 32-64 B fabric write
 //      per 4-byte store on this chip: measured 2x slower than rocPRIM; staged, the stores are coalesced runs).
-template <bool IDENTITY_VALUES, int CH>
+// DIRECT: the pass's histogram was rs_hist_direct_kernel; `acc` holds the slabs' digit totals and the table rows are raw counts.
+// `acc_clear` (either flavour): the other totals buffer, cleared here for the next pass's histogram (nobody reads it any more).
+template <bool IDENTITY_VALUES, int CH, bool DIRECT>
 __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                           uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n,
-                                                          const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r, const uint32_t *skip_flag)
+                                                          const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r, const uint32_t *skip_flag,
+                                                          const uint32_t *__restrict__ acc, uint32_t *__restrict__ acc_clear)
 {
     constexpr int KB = CH / 256; // steps per wave
     if (!resolve_count<CH>(n_dev, n, r)) return;
     if (pass_skipped(skip_flag)) return;
+    if (acc_clear && (int)blockIdx.x < r.slabs) acc_clear[(size_t)blockIdx.x * NB + threadIdx.x] = 0u;
     __shared__ uint32_t stage_k[CH], stage_v[CH];
     __shared__ uint32_t wcnt[4][NB]; // per-wave digit counts, then the chunk-local start of the (wave, digit) run
     __shared__ int32_t gdelta[NB];   // global run start of the digit minus its chunk-local start
-    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t wtot[4], gtot[4];
     const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const int chunk = blockIdx.x;
     const uint32_t mask = (1u << nbits) - 1u;
@@ -272,6 +304,32 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
         key[b] = 0xFFFFFFFFu;
         val[b] = 0u;
         if (i < n) { key[b] = kin[i]; val[b] = IDENTITY_VALUES ? (uint32_t)i : vin[i]; }
+    }
+    // DIRECT, thread t = digit t: how many pairs with digit t sit in earlier chunks of this slab, in earlier slabs, and in all slabs
+    uint32_t d_within = 0u, d_before = 0u, d_total = 0u;
+    if (DIRECT)
+    {
+        const int slab = chunk >> 6, c0 = slab * 64;
+        for (int c = c0; c < chunk; c += 16)
+        {
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = (c + k < chunk) ? r.table[(size_t)(c + k) * NB + t] : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++) d_within += v[k];
+        }
+        for (int sl = 0; sl < r.slabs; sl += 16)
+        {
+            uint32_t v[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) v[k] = (sl + k < r.slabs) ? acc[(size_t)(sl + k) * NB + t] : 0u;
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+            {
+                d_total += v[k];
+                d_before += (sl + k < slab) ? v[k] : 0u;
+            }
+        }
     }
 #pragma unroll
     for (int k = 0; k < NB / 64; k++) wcnt[wave][lane + 64 * k] = 0u;
@@ -309,7 +367,18 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
         uint32_t dbase = inc - tot;
         for (int w = 0; w < wave; w++) dbase += wtot[w];
         wcnt[0][t] = dbase; wcnt[1][t] = dbase + c0; wcnt[2][t] = dbase + c0 + c1; wcnt[3][t] = dbase + c0 + c1 + c2;
-        const uint32_t g = r.binbase[t] + r.slabtot[(size_t)(chunk >> 6) * NB + t] + r.table[(size_t)chunk * NB + t];
+        uint32_t g;
+        if (DIRECT)
+        {
+            // exclusive prefix of the digit totals over the digits, the same way as the chunk-local one above
+            const uint32_t ginc = wave_inclusive_scan(d_total, lane);
+            if (lane == 63) gtot[wave] = ginc;
+            __syncthreads();
+            uint32_t gbase = ginc - d_total;
+            for (int w = 0; w < wave; w++) gbase += gtot[w];
+            g = gbase + d_before + d_within;
+        }
+        else g = r.binbase[t] + r.slabtot[(size_t)(chunk >> 6) * NB + t] + r.table[(size_t)chunk * NB + t];
         gdelta[t] = (int32_t)(g - dbase);
     }
     __syncthreads();
@@ -345,15 +414,21 @@ void radix_hist(const uint32_t *kin, int64_t n, const unsigned long long *n_dev,
     else hipLaunchKernelGGL((rs_hist_kernel<false, TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, DepthCensus{}, skip_flag);
 }
 void radix_scatter(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
-                   int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag = nullptr)
+                   int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag = nullptr, const uint32_t *acc = nullptr,
+                   uint32_t *acc_clear = nullptr)
 {
     const dim3 grid((unsigned)r.chunks);
     const bool small = r.chunk == TS_RS_CHUNK_SMALL;
-#define TS_SCATTER(ID, C) hipLaunchKernelGGL((rs_scatter_kernel<ID, C>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag)
-    if (vin && small) TS_SCATTER(false, TS_RS_CHUNK_SMALL);
-    else if (vin) TS_SCATTER(false, TS_RS_CHUNK);
-    else if (small) TS_SCATTER(true, TS_RS_CHUNK_SMALL);
-    else TS_SCATTER(true, TS_RS_CHUNK);
+#define TS_SCATTER(ID, C, D) hipLaunchKernelGGL((rs_scatter_kernel<ID, C, D>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc, acc_clear)
+    if (acc)
+    {
+        if (small) TS_SCATTER(false, TS_RS_CHUNK_SMALL, true);
+        else TS_SCATTER(false, TS_RS_CHUNK, true);
+    }
+    else if (vin && small) TS_SCATTER(false, TS_RS_CHUNK_SMALL, false);
+    else if (vin) TS_SCATTER(false, TS_RS_CHUNK, false);
+    else if (small) TS_SCATTER(true, TS_RS_CHUNK_SMALL, false);
+    else TS_SCATTER(true, TS_RS_CHUNK, false);
 #undef TS_SCATTER
 }
 void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
@@ -361,6 +436,21 @@ void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32
 {
     radix_hist(kin, n, n_dev, shift, nbits, r, s, nullptr, skip_flag);
     radix_scatter(kin, vin, kout, vout, n, n_dev, shift, nbits, r, s, skip_flag);
+}
+// The ticket-free pass: the histogram adds into slabacc[which] (cleared by whoever ran before), the scatter reads it and clears the other
+// buffer for the pass after this one.  Every block reads the totals of all slabs, so sorts of more than TS_DIRECT_MAX_SLABS slabs (12.6 M
+// pairs at 4096 per chunk) keep the hierarchical pass, whose cost does not grow with the slab count.
+constexpr int TS_DIRECT_MAX_SLABS = 48;
+bool radix_direct_ok(const RadixScratchView &r) { return r.slabs <= TS_DIRECT_MAX_SLABS; }
+void radix_pass_direct(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
+                       int nbits, const RadixScratchView &r, int which, hipStream_t s, const uint32_t *skip_flag = nullptr)
+{
+    const dim3 grid((unsigned)r.chunks);
+    const uint32_t mask = (1u << nbits) - 1u;
+    if (r.chunk == TS_RS_CHUNK_SMALL)
+        hipLaunchKernelGGL((rs_hist_direct_kernel<TS_RS_CHUNK_SMALL>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, r.slabacc[which], skip_flag);
+    else hipLaunchKernelGGL((rs_hist_direct_kernel<TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, r.slabacc[which], skip_flag);
+    radix_scatter(kin, vin, kout, vout, n, n_dev, shift, nbits, r, s, skip_flag, r.slabacc[which], r.slabacc[which ^ 1]);
 }
 
 // ---- step 2: tiles_sorted = tiles_touched[perm], 64-bit block sums, their prefix, N ---------------------------------------
@@ -395,27 +485,36 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
     __shared__ unsigned long long carry;
     if (t == 0) carry = 0;
     __syncthreads();
-    for (int b0 = 0; b0 < nblocks; b0 += 256)
+    for (int b00 = 0; b00 < nblocks; b00 += 256 * 8)
     {
-        const int b = b0 + t;
-        unsigned long long x = 0;
-        if (b < nblocks) x = peer_load((const unsigned long long *)g.blocksum + b);
-        // inclusive scan over the 256 threads: inside the wave by shuffles, across the four waves through LDS
-        unsigned long long inc = x;
-        for (int o = 1; o < 64; o <<= 1)
+        // eight rounds' block sums are requested together (this block is alone on the critical path: one memory round trip, not eight)
+        unsigned long long xs[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) xs[k] = (b00 + 256 * k + t < nblocks) ? peer_load((const unsigned long long *)g.blocksum + b00 + 256 * k + t) : 0ull;
+#pragma unroll
+        for (int k = 0; k < 8; k++)
         {
-            const unsigned long long y = __shfl_up(inc, o);
-            if (lane >= o) inc += y;
+            const int b0 = b00 + 256 * k;
+            if (b0 >= nblocks) break;
+            const int b = b0 + t;
+            const unsigned long long x = xs[k];
+            // inclusive scan over the 256 threads: inside the wave by shuffles, across the four waves through LDS
+            unsigned long long inc = x;
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const unsigned long long y = __shfl_up(inc, o);
+                if (lane >= o) inc += y;
+            }
+            if (lane == 63) wsum[wave] = inc;
+            __syncthreads();
+            unsigned long long wbase = 0;
+            for (int w = 0; w < wave; w++) wbase += wsum[w];
+            const unsigned long long c = carry;
+            if (b < nblocks) g.blocksum[b] = c + wbase + inc - x;
+            __syncthreads();
+            if (t == 255) carry = c + wbase + inc;
+            __syncthreads();
         }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        unsigned long long wbase = 0;
-        for (int w = 0; w < wave; w++) wbase += wsum[w];
-        const unsigned long long c = carry;
-        if (b < nblocks) g.blocksum[b] = c + wbase + inc - x;
-        __syncthreads();
-        if (t == 255) carry = c + wbase + inc;
-        __syncthreads();
     }
     if (t == 0) g.blocksum[nblocks] = carry;
 }
@@ -436,7 +535,10 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     // output clears that used to be three memset launches: tile ranges (rasterizer.cu:223) and the contribution statistics
     for (int k = i; k < ntiles; k += gridDim.x * 256) ranges[k] = make_uint2(0u, 0u);
     if (b.rs.tickets)
+    {
         for (int k = i; k < b.rs.slabs + 8; k += gridDim.x * 256) b.rs.tickets[k] = 0u; // the tile sort's tickets
+        for (int k = i; k < b.rs.slabs * NB; k += gridDim.x * 256) b.rs.slabacc[0][k] = 0u; // ... and its first pass's slab totals
+    }
     if (contrib_sum && i < P)
     {
         contrib_sum[i] = 0.0f;
@@ -562,10 +664,19 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
     if (P <= 0) return;
-    radix_scatter((const uint32_t *)g.depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s);
-    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 8, 8, g.rs, s);
-    radix_pass(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, nullptr, 16, 8, g.rs, s);
-    radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, s, g.top_const);
+    if (!radix_direct_ok(g.rs))
+    {
+        radix_scatter((const uint32_t *)g.depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s);
+        radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 8, 8, g.rs, s);
+        radix_pass(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, nullptr, 16, 8, g.rs, s);
+        radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, s, g.top_const);
+        return;
+    }
+    // the first pass's histogram carried the census and kept its tickets; its scatter clears the totals buffer of the second pass
+    radix_scatter((const uint32_t *)g.depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s, nullptr, nullptr, g.rs.slabacc[1]);
+    radix_pass_direct(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 8, 8, g.rs, 1, s);
+    radix_pass_direct(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, nullptr, 16, 8, g.rs, 0, s);
+    radix_pass_direct(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, 1, s, g.top_const);
 }
 
 // Step 2: tiles_sorted = tiles_touched[perm], block sums -> exclusive prefix, blocksum[nblocks] = N.
@@ -594,7 +705,9 @@ void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long lon
     for (int p = 0; p < b.passes; p++)
     {
         const int nbits = min(8, bits - 8 * p);
-        radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, n_dev, 8 * p, nbits, b.rs, s);
+        // ticket-free passes when the sort is small enough; scan_emit_kernel cleared slabacc[0] for the first one
+        if (radix_direct_ok(b.rs)) radix_pass_direct(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, n_dev, 8 * p, nbits, b.rs, p & 1, s);
+        else radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, n_dev, 8 * p, nbits, b.rs, s);
         src ^= 1;
     }
 }

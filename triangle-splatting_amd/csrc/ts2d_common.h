@@ -41,6 +41,8 @@ struct RadixScratchView
     uint32_t *slabtot; // slabs x 256    per-slab totals, then (in place) their exclusive prefix over the slabs
     uint32_t *binbase; // 256            exclusive prefix of the digit totals
     uint32_t *tickets; // TS_RS_TICKETS  "last block finishes" tickets: [0] pass, [1] scan blocks, [2 + slab] per slab; zero between launches
+    uint32_t *slabacc[2]; // slabs x 256 each: per-slab digit totals of the ticket-free passes (binning.hip, rs_hist_direct_kernel), accumulated
+                          // with atomics; pass p uses [p & 1], and whoever runs before it has cleared that buffer
     int chunks, slabs;
     int chunk; // pairs per chunk: TS_RS_CHUNK or TS_RS_CHUNK_SMALL
 };
@@ -99,6 +101,8 @@ static inline void ts_carve_radix(char *&p, size_t n, RadixScratchView &r, int c
     ts_carve(p, r.slabtot, (size_t)r.slabs * TS_RS_BINS);
     ts_carve(p, r.binbase, (size_t)TS_RS_BINS);
     ts_carve(p, r.tickets, (size_t)r.slabs + 8);
+    ts_carve(p, r.slabacc[0], (size_t)r.slabs * TS_RS_BINS);
+    ts_carve(p, r.slabacc[1], (size_t)r.slabs * TS_RS_BINS);
 }
 
 static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView &v)
