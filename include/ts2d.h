@@ -188,8 +188,8 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t num_render
 
 /* Test hooks for the binning primitives that replace cub::DeviceRadixSort::SortPairs / cub::DeviceScan::InclusiveSum
  * (R2D/src/rasterizer.cu:210-218, 186): the hand-written stable LSD radix sort of (key, value) pairs on bits [0, end_bit)
- * (which = 0; csrc/binning.hip) and AMD's rocPRIM on the same arrays (which = 1; comparator only, never on the product
- * path).  Device pointers, n pairs, synchronous. */
+ * (which = 0; csrc/binning.hip -- which = 2: with the hierarchical passes that sorts of more than 48 slabs take) and AMD's rocPRIM on the
+ * same arrays (which = 1; comparator only, never on the product path).  Device pointers, n pairs, synchronous. */
 int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
                          int32_t end_bit, int32_t which, void *stream);
 int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream);

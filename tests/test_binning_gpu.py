@@ -56,13 +56,16 @@ def test_radix_sort_matches_rocprim_and_numpy(n, end_bit, kind):
         keys = rng.integers(0, 1 << end_bit, n, dtype=np.uint64).astype(np.uint32)
     vals = rng.permutation(n).astype(np.uint32)
     ours = _sort(keys, vals, end_bit, 0)
+    tickets = _sort(keys, vals, end_bit, 2)  # the hierarchical (ticket) passes that sorts of more than 48 slabs fall back to
+    assert np.array_equal(ours[0], tickets[0]) and np.array_equal(ours[1], tickets[1])
     theirs = _sort(keys, vals, end_bit, 1)
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(ours[0], keys[order]) and np.array_equal(ours[1], vals[order])
     assert np.array_equal(ours[0], theirs[0]) and np.array_equal(ours[1], theirs[1])
 
 
-@pytest.mark.parametrize("P,W,H", [(5, 64, 64), (1000, 300, 200), (1025, 128, 128), (300_000, 800, 800), (1_000_000, 1920, 1080)])
+@pytest.mark.parametrize("P,W,H", [(5, 64, 64), (1000, 300, 200), (1025, 128, 128), (300_000, 800, 800), (1_000_000, 1920, 1080),
+                                   (3_000_000, 1920, 1080)])  # > 2048 scan blocks and > 48 slabs of instances: the ticket versions of scan and tile sort
 def test_instance_offsets_match_rocprim_scan(P, W, H):
     """offsets = inclusive prefix sum of tiles_touched in depth order (block sums + DPP wave scans fused into the emission
     kernel) against rocPRIM's inclusive_scan of the same counts; N = the last offset."""
@@ -126,7 +129,7 @@ def test_last_arrival_handoffs_under_uneven_load():
             for _ in range(1 + it % 4):
                 big[: (16 << 20) * (1 + it % 3)].mul_(1.0001)
                 a = (a @ a).clamp_(-1, 1)
-        ko, vo = _sort(keys, vals, end_bit, 0)
+        ko, vo = _sort(keys, vals, end_bit, 2 if it % 2 == 0 else 0)  # the ticket passes and the ticket-free ones (atomics into slab totals)
         order = np.argsort(keys, kind="stable")
         if not (np.array_equal(ko, keys[order]) and np.array_equal(vo, vals[order])):
             bad += 1

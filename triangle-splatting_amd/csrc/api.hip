@@ -809,14 +809,15 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
     return TS2D_OK;
 }
 
-// Test hooks: the hand-written stable radix sort (which = 0) and AMD's rocPRIM (which = 1, the comparator) on device arrays.
+// Test hooks: the hand-written stable radix sort (which = 0; which = 2: its hierarchical passes forced, the ones large sorts take) and
+// AMD's rocPRIM (which = 1, the comparator) on device arrays.
 int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int32_t end_bit,
                          int32_t which, void *stream)
 {
     if (end_bit < 1 || end_bit > 32) return fail(TS2D_ERR_INVALID, "end_bit must be in 1..32");
     if (n && (!keys_in || !vals_in || !keys_out || !vals_out)) return fail(TS2D_ERR_INVALID, "null pointer");
-    const int rc = which ? ts_compare_sort_pairs_rocprim(keys_in, vals_in, keys_out, vals_out, n, end_bit, (hipStream_t)stream)
-                         : ts_test_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, end_bit, (hipStream_t)stream);
+    const int rc = which == 1 ? ts_compare_sort_pairs_rocprim(keys_in, vals_in, keys_out, vals_out, n, end_bit, (hipStream_t)stream)
+                              : ts_test_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, end_bit, which == 2, (hipStream_t)stream);
     return rc ? fail(TS2D_ERR_HIP, "sort_pairs test hook failed") : TS2D_OK;
 }
 int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream)

@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
 // that chain IS the kernel (18 us for 4 MB of keys).  Here a block leaves its 256 counts as a table row and adds them to its slab's totals
 // with fire-and-forget atomics, and that is all; the scatter kernel that follows works out the three prefixes it needs from the rows
 // (<= 63 rows of its slab + the slabs' totals, loaded while its keys are on their way).
+constexpr int TS_DIRECT_MAX_SLABS = 48; // every scatter block reads the totals of all slabs: beyond this the hierarchical pass is cheaper
 template <int CH>
 __global__ void __launch_bounds__(256) rs_hist_direct_kernel(const uint32_t *__restrict__ keys, int64_t n, const unsigned long long *n_dev, int shift,
                                                               uint32_t mask, RadixScratchView r, uint32_t *__restrict__ acc, const uint32_t *skip_flag)
@@ -268,6 +269,87 @@ __global__ void __launch_bounds__(256) rs_hist_direct_kernel(const uint32_t *__r
     if (c) __hip_atomic_fetch_add(acc + (size_t)(chunk >> 6) * NB + t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The depth sort's first histogram, ticket-free like the one above, with the census riding along: a block leaves its part of N and of the
+// key-bit OR / OR-of-complements as three per-chunk words; block 0 of the scatter kernel that follows adds them up and publishes N (device
+// word + pinned host word) and the top-byte verdict (`top_const`).  No ticket at all: electing a publisher HERE costs one same-address
+// atomic per block, and 488 of those in a row take longer (17 us) than the histogram itself.  Large scenes (more than
+// TS_DIRECT_MAX_SLABS slabs) keep rs_hist_kernel<true>.
+template <int CH>
+__global__ void __launch_bounds__(256) rs_hist_census_direct_kernel(const uint32_t *__restrict__ keys, int64_t n, uint32_t mask, RadixScratchView r,
+                                                                     uint32_t *__restrict__ acc, DepthCensus census)
+{
+    __shared__ uint32_t bins[NB];
+    __shared__ unsigned long long csum[4];
+    __shared__ uint32_t cor[4], cnand[4];
+    const int t = threadIdx.x, chunk = blockIdx.x;
+    bins[t] = 0u;
+    __syncthreads();
+    const int64_t base = (int64_t)chunk * CH;
+    unsigned long long tsum = 0;
+    uint32_t kor = 0u, knand = 0u;
+#pragma unroll
+    for (int b = 0; b < CH / 256; b++)
+    {
+        const int64_t i = base + 256 * b + t;
+        if (i < n)
+        {
+            const uint32_t k = keys[i];
+            atomicAdd(&bins[k & mask], 1u);
+            tsum += census.tiles_touched[i];
+            if (k != 0u) { kor |= k; knand |= ~k; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        tsum += __shfl_xor(tsum, o);
+        kor |= __shfl_xor(kor, o);
+        knand |= __shfl_xor(knand, o);
+    }
+    if ((t & 63) == 0) { csum[t >> 6] = tsum; cor[t >> 6] = kor; cnand[t >> 6] = knand; }
+    __syncthreads();
+    const uint32_t c = bins[t];
+    r.table[(size_t)chunk * NB + t] = c;
+    if (c) __hip_atomic_fetch_add(acc + (size_t)(chunk >> 6) * NB + t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0)
+    {
+        census.chunk_sum[chunk] = csum[0] + csum[1] + csum[2] + csum[3];
+        census.chunk_or[chunk] = cor[0] | cor[1] | cor[2] | cor[3];
+        census.chunk_and[chunk] = ~(cnand[0] | cnand[1] | cnand[2] | cnand[3]);
+    }
+}
+
+// Block 0 of the first scatter: the chunks' census words -> N, top_const, the pinned host word (see above).
+__device__ __forceinline__ void publish_census(const DepthCensus &census, int chunks, int t)
+{
+    __shared__ unsigned long long psum[4];
+    __shared__ uint32_t por[4], pand[4];
+    unsigned long long sum = 0;
+    uint32_t o = 0u, a = 0xFFFFFFFFu;
+    for (int c = t; c < chunks; c += 256)
+    {
+        sum += census.chunk_sum[c];
+        o |= census.chunk_or[c];
+        a &= census.chunk_and[c];
+    }
+    for (int d = 32; d > 0; d >>= 1)
+    {
+        sum += __shfl_xor(sum, d);
+        o |= __shfl_xor(o, d);
+        a &= __shfl_xor(a, d);
+    }
+    if ((t & 63) == 0) { psum[t >> 6] = sum; por[t >> 6] = o; pand[t >> 6] = a; }
+    __syncthreads();
+    if (t == 0)
+    {
+        const unsigned long long N = psum[0] + psum[1] + psum[2] + psum[3];
+        const uint32_t varying = (por[0] | por[1] | por[2] | por[3]) ^ (pand[0] & pand[1] & pand[2] & pand[3]);
+        *census.n_out = N;
+        *census.top_const = (varying >> 24) == 0u ? 1u : 0u; // no visible triangle at all: or = 0, and = ~0 -> varying = ~0 -> not set
+        // pinned, device-visible host word: the host reads it after the event recorded behind this kernel (no copy kernel in between)
+        if (census.host_out) __hip_atomic_store(census.host_out, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // One workgroup = one chunk of CH pairs; wave w owns the w-th quarter (KB steps of 64 consecutive pairs, held in registers).
 //   1. wave-local stable ranks: per step the lanes holding equal digits find each other with `nbits` ballots (wave64 match),
 //      rank = v_mbcnt of the match mask on top of the digit's running count in the wave's LDS counters;
@@ -278,17 +360,18 @@ __global__ void __launch_bounds__(256) rs_hist_direct_kernel(const uint32_t *__r
 //      per 4-byte store on this chip: measured 2x slower than rocPRIM; staged, the stores are coalesced runs).
 // DIRECT: the pass's histogram was rs_hist_direct_kernel; `acc` holds the slabs' digit totals and the table rows are raw counts.
 // `acc_clear` (either flavour): the other totals buffer, cleared here for the next pass's histogram (nobody reads it any more).
-template <bool IDENTITY_VALUES, int CH, bool DIRECT>
+template <bool IDENTITY_VALUES, int CH, bool DIRECT, bool CENSUS = false>
 __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
                                                           uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n,
                                                           const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r, const uint32_t *skip_flag,
-                                                          const uint32_t *__restrict__ acc, uint32_t *__restrict__ acc_clear)
+                                                          const uint32_t *__restrict__ acc, uint32_t *__restrict__ acc_clear, DepthCensus census = DepthCensus{})
 {
     constexpr int KB = CH / 256; // steps per wave
     if (!resolve_count<CH>(n_dev, n, r)) return;
     if (pass_skipped(skip_flag)) return;
     if (acc_clear && (int)blockIdx.x < r.slabs) acc_clear[(size_t)blockIdx.x * NB + threadIdx.x] = 0u;
-    __shared__ uint32_t stage_k[CH], stage_v[CH];
+    __shared__ __attribute__((aligned(16))) uint32_t stage_k[CH], stage_v[CH];
+    static_assert(CH >= 8 * NB, "the DIRECT prefix exchange borrows 8 x 256 words of stage_k");
     __shared__ uint32_t wcnt[4][NB]; // per-wave digit counts, then the chunk-local start of the (wave, digit) run
     __shared__ int32_t gdelta[NB];   // global run start of the digit minus its chunk-local start
     __shared__ uint32_t wtot[4], gtot[4];
@@ -305,29 +388,34 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
         val[b] = 0u;
         if (i < n) { key[b] = kin[i]; val[b] = IDENTITY_VALUES ? (uint32_t)i : vin[i]; }
     }
-    // DIRECT, thread t = digit t: how many pairs with digit t sit in earlier chunks of this slab, in earlier slabs, and in all slabs
-    uint32_t d_within = 0u, d_before = 0u, d_total = 0u;
+    // DIRECT: how many pairs of each digit sit in earlier chunks of this slab, in earlier slabs, and in all slabs.  Wave w takes every
+    // fourth row, lane l the digits 4l .. 4l + 3 (one dwordx4 per row: at most 16 + 12 loads per lane, all requested here, behind the keys);
+    // the four waves' partial sums meet in LDS after the ranking (the staging arrays are still free then).
+    uint4 p_within = make_uint4(0u, 0u, 0u, 0u), p_before = p_within, p_total = p_within;
     if (DIRECT)
     {
         const int slab = chunk >> 6, c0 = slab * 64;
-        for (int c = c0; c < chunk; c += 16)
+        const uint4 *tab4 = (const uint4 *)r.table + (size_t)c0 * (NB / 4) + lane;
+        const uint4 *acc4 = (const uint4 *)acc + lane;
+#pragma unroll
+        for (int k = 0; k < 16; k++)
         {
-            uint32_t v[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = (c + k < chunk) ? r.table[(size_t)(c + k) * NB + t] : 0u;
-#pragma unroll
-            for (int k = 0; k < 16; k++) d_within += v[k];
-        }
-        for (int sl = 0; sl < r.slabs; sl += 16)
-        {
-            uint32_t v[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) v[k] = (sl + k < r.slabs) ? acc[(size_t)(sl + k) * NB + t] : 0u;
-#pragma unroll
-            for (int k = 0; k < 16; k++)
+            const int c = wave + 4 * k;
+            if (c0 + c < chunk)
             {
-                d_total += v[k];
-                d_before += (sl + k < slab) ? v[k] : 0u;
+                const uint4 v = tab4[(size_t)c * (NB / 4)];
+                p_within.x += v.x; p_within.y += v.y; p_within.z += v.z; p_within.w += v.w;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < TS_DIRECT_MAX_SLABS / 4; k++)
+        {
+            const int sl = wave + 4 * k;
+            if (sl < r.slabs)
+            {
+                const uint4 v = acc4[(size_t)sl * (NB / 4)];
+                p_total.x += v.x; p_total.y += v.y; p_total.z += v.z; p_total.w += v.w;
+                if (sl < slab) { p_before.x += v.x; p_before.y += v.y; p_before.z += v.z; p_before.w += v.w; }
             }
         }
     }
@@ -356,9 +444,26 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
         wave_lds_order();
         rk[b] = seen + rank;
     }
+    if (DIRECT)
+    {
+        *(uint4 *)(stage_k + wave * NB + 4 * lane) = p_within;
+        *(uint4 *)(stage_k + (4 + wave) * NB + 4 * lane) = p_before;
+        *(uint4 *)(stage_v + wave * NB + 4 * lane) = p_total;
+    }
     __syncthreads();
     {
         // thread t = digit t
+        uint32_t d_within = 0u, d_before = 0u, d_total = 0u;
+        if (DIRECT)
+        {
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+            {
+                d_within += stage_k[w * NB + t];
+                d_before += stage_k[(4 + w) * NB + t];
+                d_total += stage_v[w * NB + t];
+            }
+        }
         const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
         const uint32_t tot = c0 + c1 + c2 + c3;
         const uint32_t inc = wave_inclusive_scan(tot, lane);
@@ -400,6 +505,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
         kout[dst] = k;
         vout[dst] = stage_v[p];
     }
+    if (CENSUS && chunk == 0) publish_census(census, r.chunks, t);
 }
 
 void radix_hist(const uint32_t *kin, int64_t n, const unsigned long long *n_dev, int shift, int nbits, const RadixScratchView &r, hipStream_t s,
@@ -420,10 +526,15 @@ void radix_scatter(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uin
     const dim3 grid((unsigned)r.chunks);
     const bool small = r.chunk == TS_RS_CHUNK_SMALL;
 #define TS_SCATTER(ID, C, D) hipLaunchKernelGGL((rs_scatter_kernel<ID, C, D>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc, acc_clear)
-    if (acc)
+    if (acc && vin)
     {
         if (small) TS_SCATTER(false, TS_RS_CHUNK_SMALL, true);
         else TS_SCATTER(false, TS_RS_CHUNK, true);
+    }
+    else if (acc)
+    {
+        if (small) TS_SCATTER(true, TS_RS_CHUNK_SMALL, true);
+        else TS_SCATTER(true, TS_RS_CHUNK, true);
     }
     else if (vin && small) TS_SCATTER(false, TS_RS_CHUNK_SMALL, false);
     else if (vin) TS_SCATTER(false, TS_RS_CHUNK, false);
@@ -440,7 +551,6 @@ void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32
 // The ticket-free pass: the histogram adds into slabacc[which] (cleared by whoever ran before), the scatter reads it and clears the other
 // buffer for the pass after this one.  Every block reads the totals of all slabs, so sorts of more than TS_DIRECT_MAX_SLABS slabs (12.6 M
 // pairs at 4096 per chunk) keep the hierarchical pass, whose cost does not grow with the slab count.
-constexpr int TS_DIRECT_MAX_SLABS = 48;
 bool radix_direct_ok(const RadixScratchView &r) { return r.slabs <= TS_DIRECT_MAX_SLABS; }
 void radix_pass_direct(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
                        int nbits, const RadixScratchView &r, int which, hipStream_t s, const uint32_t *skip_flag = nullptr)
@@ -456,6 +566,9 @@ void radix_pass_direct(const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
 // ---- step 2: tiles_sorted = tiles_touched[perm], 64-bit block sums, their prefix, N ---------------------------------------
 constexpr int SB = 1024; // triangles per scan block (256 threads x 4)
 
+// DIRECT (round 3): the block sums stay raw and nobody waits for a last block; every emission block adds up the sums in front of it itself
+// (scan_emit_kernel<true>; blocksum[nblocks] = N is already there from the depth sort's census).
+template <bool DIRECT>
 __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometryStateView g, uint32_t *ticket)
 {
     __shared__ unsigned long long wsum[4];
@@ -479,6 +592,11 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
     if (lane == 0) wsum[wave] = sum;
     __syncthreads();
     const int nblocks = gridDim.x;
+    if (DIRECT)
+    {
+        if (t == 0) g.blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        return;
+    }
     if (t == 0) peer_store((unsigned long long *)g.blocksum + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
     if (!last_arrival(ticket, (uint32_t)nblocks)) return;
     // the last block to finish turns the block sums into their exclusive prefix; blocksum[nblocks] = N
@@ -526,17 +644,19 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
 // (rasterizer.cu:63-73); the later sort is by tile id, so only the order BETWEEN triangles matters.
 constexpr uint32_t SMALL = 32;
 
+template <bool DIRECT>
 __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
                                                          float *contrib_sum, float *contrib_max, long long capacity, int32_t *status)
 {
     __shared__ uint32_t wtot[4];
+    __shared__ unsigned long long wpart[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int i = blockIdx.x * 256 + t;
     // output clears that used to be three memset launches: tile ranges (rasterizer.cu:223) and the contribution statistics
     for (int k = i; k < ntiles; k += gridDim.x * 256) ranges[k] = make_uint2(0u, 0u);
     if (b.rs.tickets)
     {
-        for (int k = i; k < b.rs.slabs + 8; k += gridDim.x * 256) b.rs.tickets[k] = 0u; // the tile sort's tickets
+        for (int k = i; k < b.rs.slabs + TS_RS_TICKET_EXTRA; k += gridDim.x * 256) b.rs.tickets[k] = 0u; // the tile sort's tickets
         for (int k = i; k < b.rs.slabs * NB; k += gridDim.x * 256) b.rs.slabacc[0][k] = 0u; // ... and its first pass's slab totals
     }
     if (contrib_sum && i < P)
@@ -546,6 +666,19 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     }
     const bool valid = i < P;
     uint32_t tiles = valid ? g.tiles_sorted[i] : 0u;
+    const uint32_t id_ahead = valid ? sorted_ids(g)[i] : 0u; // wanted after the scan: requested now, one round trip less behind it
+    // Everything in front of this block, requested together and reduced once: the earlier quarters of this scan block (scan blocks are 1024
+    // triangles = four of these 256-lane blocks) and -- DIRECT -- the raw sums of the scan blocks before it.
+    const int sblock = blockIdx.x >> 2, quarter = blockIdx.x & 3;
+    unsigned long long part = 0;
+    const unsigned long long scanned = DIRECT ? 0ull : g.blocksum[sblock]; // ticket path: the exclusive prefix is already there
+    if (DIRECT)
+        for (int k = t; k < sblock; k += 256) part += g.blocksum[k];
+    for (int q = 0; q < quarter; q++)
+    {
+        const int j = (sblock * 4 + q) * 256 + t;
+        part += (j < P) ? g.tiles_sorted[j] : 0u;
+    }
     if (capacity >= 0) // sync-free forward: the instance count is only known here; over capacity nothing is emitted
     {
         const unsigned long long live = g.blocksum[(P + SB - 1) / SB];
@@ -553,26 +686,15 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         if (i == 0 && status) *status = over ? 1 : 0;
         if (over) tiles = 0u;
     }
-    // inclusive prefix inside the block (wave64 DPP scan + the three preceding waves' totals) on top of the block's base;
-    // scan blocks are 1024 triangles = four of these 256-lane blocks, so the three earlier quarters are summed here too
+    // inclusive prefix inside the block (wave64 DPP scan + the three preceding waves' totals) on top of what lies in front of the block
     const uint32_t inc = wave_inclusive_scan(tiles, lane);
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
     if (lane == 63) wtot[wave] = inc;
+    if (lane == 0) wpart[wave] = part;
     __syncthreads();
     uint32_t before = 0;
     for (int w = 0; w < wave; w++) before += wtot[w];
-    const int sblock = blockIdx.x >> 2, quarter = blockIdx.x & 3;
-    unsigned long long qbase = g.blocksum[sblock];
-    for (int q = 0; q < quarter; q++)
-    {
-        // earlier quarters of this scan block: their 256 counts summed by this block's lanes (coalesced, L2-resident)
-        const int j = (sblock * 4 + q) * 256 + t;
-        uint32_t x = (j < P) ? g.tiles_sorted[j] : 0u;
-        for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
-        __syncthreads();
-        if (lane == 0) wtot[wave] = x;
-        __syncthreads();
-        qbase += (unsigned long long)wtot[0] + wtot[1] + wtot[2] + wtot[3];
-    }
+    const unsigned long long qbase = scanned + wpart[0] + wpart[1] + wpart[2] + wpart[3];
     const uint32_t incl = (uint32_t)(qbase + before + inc); // N < 2^31 is checked on the host before anything is emitted
     if (valid) g.offsets[i] = incl;
     uint2 rect = {0u, 0u};
@@ -580,21 +702,40 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     const uint32_t off = incl - tiles; // exclusive prefix
     if (tiles > 0)
     {
-        id = sorted_ids(g)[i];
+        id = id_ahead;
         rect = g.rect[id];
     }
     const uint32_t minx = rect.x & 0xffffu, miny = rect.x >> 16, maxx = rect.y & 0xffffu, maxy = rect.y >> 16;
     uint32_t *tile_out = b.k[0], *val_out = b.v[0];
+    // The block's instances are one contiguous run of the list.  A lane writing its triangle's few slots straight to memory issues 4-byte
+    // stores a few slots apart from its neighbours' (a 32-64 byte fabric write each on this chip); runs of up to STAGE instances are put
+    // together in LDS instead and leave as coalesced rows.
+    constexpr uint32_t STAGE = 3072;
+    __shared__ uint32_t stage_t[STAGE], stage_v[STAGE];
+    const uint32_t run0 = (uint32_t)qbase, run = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    const bool staged = run <= STAGE;
     if (tiles > 0 && tiles <= SMALL)
     {
         uint32_t o = off;
-        for (uint32_t y = miny; y < maxy; y++)
-            for (uint32_t x = minx; x < maxx; x++)
-            {
-                tile_out[o] = y * grid_x + x;
-                val_out[o] = id;
-                o++;
-            }
+        if (staged)
+        {
+            o -= run0;
+            for (uint32_t y = miny; y < maxy; y++)
+                for (uint32_t x = minx; x < maxx; x++)
+                {
+                    stage_t[o] = y * grid_x + x;
+                    stage_v[o] = id;
+                    o++;
+                }
+        }
+        else
+            for (uint32_t y = miny; y < maxy; y++)
+                for (uint32_t x = minx; x < maxx; x++)
+                {
+                    tile_out[o] = y * grid_x + x;
+                    val_out[o] = id;
+                    o++;
+                }
     }
     unsigned long long big = ballot64(tiles > SMALL);
     while (big)
@@ -607,8 +748,25 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         for (uint32_t k = lane; k < t_tiles; k += 64)
         {
             const uint32_t y = t_miny + k / w, x = t_minx + k % w;
-            tile_out[t_off + k] = y * grid_x + x;
-            val_out[t_off + k] = t_id;
+            if (staged)
+            {
+                stage_t[t_off - run0 + k] = y * grid_x + x;
+                stage_v[t_off - run0 + k] = t_id;
+            }
+            else
+            {
+                tile_out[t_off + k] = y * grid_x + x;
+                val_out[t_off + k] = t_id;
+            }
+        }
+    }
+    if (staged)
+    {
+        __syncthreads();
+        for (uint32_t k = t; k < run; k += 256)
+        {
+            tile_out[run0 + k] = stage_t[k];
+            val_out[run0 + k] = stage_v[k];
         }
     }
 }
@@ -645,9 +803,9 @@ __global__ void zero_words_kernel(uint32_t *p, int n)
 } // namespace
 
 // Step 1: (depth bits, id) -> sorted ids.  Depth keys are view-space z of visible triangles (> 0, so the unsigned bit
-// pattern is monotone) and 0 for culled ones, which emit nothing wherever they land.  `begin` = the first histogram, which also
-// produces N (to `host_out` as well when given) and the key-bit census; `finish` = the other launches (the 4th pass returns at once
-// when the census found the top byte constant: then sk[0] / sv[0] hold the order).
+// pattern is monotone) and 0 for culled ones, which emit nothing wherever they land.  `begin` = the launches that produce N (to `host_out`
+// as well when given) and the key-bit census: the first histogram, and on the ticket-free path the first scatter too; `finish` = the other
+// launches (the 4th pass returns at once when the census found the top byte constant: then sk[0] / sv[0] hold the order).
 void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s)
 {
     if (P <= 0) return;
@@ -659,7 +817,29 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
     c.n_out = (unsigned long long *)g.blocksum + (P + SB - 1) / SB;
     c.host_out = host_out;
     c.top_const = g.top_const;
-    radix_hist((const uint32_t *)g.depth, P, nullptr, 0, 8, g.rs, s, &c);
+    if (!radix_direct_ok(g.rs))
+    {
+        radix_hist((const uint32_t *)g.depth, P, nullptr, 0, 8, g.rs, s, &c);
+        return;
+    }
+    // ticket-free: the histogram (with the census) adds into slabacc[0], which the step's first launch cleared (clear_tickets); the first
+    // scatter belongs to `begin` because its block 0 publishes the census
+    const dim3 grid((unsigned)g.rs.chunks);
+    const uint32_t *keys = (const uint32_t *)g.depth;
+    const unsigned long long *no_count = nullptr;
+    const uint32_t *no_vals = nullptr, *no_skip = nullptr;
+    if (g.rs.chunk == TS_RS_CHUNK_SMALL)
+    {
+        hipLaunchKernelGGL((rs_hist_census_direct_kernel<TS_RS_CHUNK_SMALL>), grid, dim3(256), 0, s, keys, (int64_t)P, 0xFFu, g.rs, g.rs.slabacc[0], c);
+        hipLaunchKernelGGL((rs_scatter_kernel<true, TS_RS_CHUNK_SMALL, true, true>), grid, dim3(256), 0, s, keys, no_vals, g.sk[0], g.sv[0], (int64_t)P, no_count,
+                           0, 8, g.rs, no_skip, (const uint32_t *)g.rs.slabacc[0], g.rs.slabacc[1], c);
+    }
+    else
+    {
+        hipLaunchKernelGGL((rs_hist_census_direct_kernel<TS_RS_CHUNK>), grid, dim3(256), 0, s, keys, (int64_t)P, 0xFFu, g.rs, g.rs.slabacc[0], c);
+        hipLaunchKernelGGL((rs_scatter_kernel<true, TS_RS_CHUNK, true, true>), grid, dim3(256), 0, s, keys, no_vals, g.sk[0], g.sv[0], (int64_t)P, no_count, 0, 8,
+                           g.rs, no_skip, (const uint32_t *)g.rs.slabacc[0], g.rs.slabacc[1], c);
+    }
 }
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
@@ -672,27 +852,32 @@ void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t 
         radix_pass(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, s, g.top_const);
         return;
     }
-    // the first pass's histogram carried the census and kept its tickets; its scatter clears the totals buffer of the second pass
-    radix_scatter((const uint32_t *)g.depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s, nullptr, nullptr, g.rs.slabacc[1]);
     radix_pass_direct(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 8, 8, g.rs, 1, s);
     radix_pass_direct(g.sk[1], g.sv[1], g.sk[0], g.sv[0], P, nullptr, 16, 8, g.rs, 0, s);
     radix_pass_direct(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, 1, s, g.top_const);
 }
 
-// Step 2: tiles_sorted = tiles_touched[perm], block sums -> exclusive prefix, blocksum[nblocks] = N.
+// Every emission block adds up the raw block sums in front of it (up to 8 per thread); beyond that the elected-block prefix pays off again.
+static bool scan_direct_ok(int32_t P) { return (P + SB - 1) / SB <= 2048; }
+// Step 2: tiles_sorted = tiles_touched[perm], block sums (-> exclusive prefix on the ticket path), blocksum[nblocks] = N.
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
     if (P <= 0) return;
     const int nblocks = (P + SB - 1) / SB;
-    hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, g.rs.tickets + 1);
+    if (scan_direct_ok(P)) hipLaunchKernelGGL(gather_blocksum_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, g.rs.tickets + 1);
+    else hipLaunchKernelGGL(gather_blocksum_kernel<false>, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, g.rs.tickets + 1);
 }
 
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                          float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s)
 {
     if (P <= 0) return;
-    hipLaunchKernelGGL(scan_emit_kernel, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges,
-                       contrib_sum, contrib_max, (long long)capacity, status);
+    if (scan_direct_ok(P))
+        hipLaunchKernelGGL(scan_emit_kernel<true>, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges,
+                           contrib_sum, contrib_max, (long long)capacity, status);
+    else
+        hipLaunchKernelGGL(scan_emit_kernel<false>, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges,
+                           contrib_sum, contrib_max, (long long)capacity, status);
 }
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P) { return (const unsigned long long *)(g.blocksum + (P + SB - 1) / SB); }
 
@@ -735,12 +920,15 @@ int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, in
     RadixScratchView r{};
     char *p = (char *)ts_align_up((size_t)scratch);
     ts_carve_radix(p, n, r, generic_chunk(n));
-    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((r.slabs + 8 + 255) / 256)), dim3(256), 0, s, r.tickets, r.slabs + 8);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((r.slabs + TS_RS_TICKET_EXTRA + 255) / 256)), dim3(256), 0, s, r.tickets, r.slabs + TS_RS_TICKET_EXTRA);
+    const bool direct = radix_direct_ok(r);
+    if (direct) hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)r.slabs), dim3(256), 0, s, r.slabacc[0], r.slabs * NB);
     const int passes = (end_bit + 7) / 8;
     int src = 0;
     for (int ps = 0; ps < passes; ps++)
     {
-        radix_pass(k[src], v[src], k[src ^ 1], v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), r, s);
+        if (direct) radix_pass_direct(k[src], v[src], k[src ^ 1], v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), r, ps & 1, s);
+        else radix_pass(k[src], v[src], k[src ^ 1], v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), r, s);
         src ^= 1;
     }
     return src;
@@ -774,7 +962,7 @@ int ts_compare_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t 
 
 // Test hook (include/ts2d.h: ts2d_test_sort_pairs): the hand-written passes on caller-provided device arrays, scratch from hipMalloc.
 int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit,
-                       hipStream_t s)
+                       bool force_tickets, hipStream_t s)
 {
     if (n == 0) return 0;
     BinningStateView b{};
@@ -792,11 +980,14 @@ int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_
     if (e == hipSuccess) e = hipMemcpyAsync(b.v[0], vals_in, n * 4, hipMemcpyDeviceToDevice, s);
     if (e == hipSuccess)
     {
-        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((b.rs.slabs + 8 + 255) / 256)), dim3(256), 0, s, b.rs.tickets, b.rs.slabs + 8);
+        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((b.rs.slabs + TS_RS_TICKET_EXTRA + 255) / 256)), dim3(256), 0, s, b.rs.tickets, b.rs.slabs + TS_RS_TICKET_EXTRA);
+        const bool direct = !force_tickets && radix_direct_ok(b.rs);
+        if (direct) hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)b.rs.slabs), dim3(256), 0, s, b.rs.slabacc[0], b.rs.slabs * NB);
         int src = 0;
         for (int ps = 0; ps < b.passes; ps++)
         {
-            radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), b.rs, s);
+            if (direct) radix_pass_direct(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), b.rs, ps & 1, s);
+            else radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), b.rs, s);
             src ^= 1;
         }
         e = hipMemcpyAsync(keys_out, b.k[src], n * 4, hipMemcpyDeviceToDevice, s);

@@ -32,9 +32,12 @@
 // and per-digit prefixes.  One chunk = consecutive pairs handled by one workgroup; one slab = 64 chunks.  The chunk length is a property
 // of the sort: 4096 pairs for the instance sort (millions of pairs: longer digit runs = better coalesced scatter stores), 2048 for the
 // per-triangle depth sort (1 M keys are only 245 workgroups of 4096 -- one per CU; measured 0.103 vs 0.113 ms, profiles/r03_notes.md).
+#ifndef TS_RS_CHUNK
 #define TS_RS_CHUNK 4096
+#endif
 #define TS_RS_CHUNK_SMALL 2048
 #define TS_RS_BINS 256
+#define TS_RS_TICKET_EXTRA 16 /* words behind the per-slab tickets: [slabs + 4] the depth sort's top_const flag, [(slabs + 9) & ~1 ...] its census accumulators */
 struct RadixScratchView
 {
     uint32_t *table;   // chunks x 256   count of digit d in chunk c, then (in place) its exclusive prefix inside the slab
@@ -100,7 +103,7 @@ static inline void ts_carve_radix(char *&p, size_t n, RadixScratchView &r, int c
     ts_carve(p, r.table, (size_t)r.chunks * TS_RS_BINS);
     ts_carve(p, r.slabtot, (size_t)r.slabs * TS_RS_BINS);
     ts_carve(p, r.binbase, (size_t)TS_RS_BINS);
-    ts_carve(p, r.tickets, (size_t)r.slabs + 8);
+    ts_carve(p, r.tickets, (size_t)r.slabs + TS_RS_TICKET_EXTRA);
     ts_carve(p, r.slabacc[0], (size_t)r.slabs * TS_RS_BINS);
     ts_carve(p, r.slabacc[1], (size_t)r.slabs * TS_RS_BINS);
 }
@@ -194,7 +197,7 @@ int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, in
 // rocPRIM comparators (tests only): same contracts as the hand-written steps, results into caller-provided device buffers
 int ts_compare_sort_pairs_rocprim(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
                                   int end_bit, hipStream_t s);
-int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit,
+int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit, bool force_tickets,
                        hipStream_t s);
 int ts_compare_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);
 

@@ -18,10 +18,13 @@
 namespace ts
 {
 // The binning kernels' "last block finishes" tickets (binning.hip) are zeroed by the first launch of the step.  Every grid has at
-// least 64 threads and slabs + 8 <= max(P, 64), so the threads beyond P of a tiny scene take part.
+// least 64 threads and slabs + TS_RS_TICKET_EXTRA <= max(P, 64), so the threads beyond P of a tiny scene take part.  The slab totals of the
+// depth sort's first (ticket-free) histogram are cleared here as well.
 __device__ __forceinline__ void clear_tickets(const GeometryStateView &g, int idx)
 {
-    if (idx < g.rs.slabs + 8) g.rs.tickets[idx] = 0u;
+    if (idx < g.rs.slabs + TS_RS_TICKET_EXTRA) g.rs.tickets[idx] = 0u;
+    const int nthreads = (int)(gridDim.x * blockDim.x);
+    for (int k = idx; k < g.rs.slabs * TS_RS_BINS; k += nthreads) g.rs.slabacc[0][k] = 0u;
 }
 
 template <class Body>
