@@ -94,7 +94,17 @@ __device__ __forceinline__ Cull3 cull3(V3 v1, V3 v2, V3 v3, V3 n, float op, floa
 }
 
 // [19] = the entry's position in its batch; a list entry is the LDS byte offset of its row (render_group.hip, round 3)
-constexpr int BROW3 = ROW + 16; // backward row: constants + the entry's 16 gradient sums
+// backward row: constants, k1 = n x (v3 - v2) and k2 = n x (v1 - v3) (the ray-independent halves of d a1 / d depth = n . ((v3 - v2) x p_ray)
+// = p_ray . k1 and d a2 / d depth = p_ray . k2, backward.cu:389, 395: two dot products per pixel instead of two differences and two cross
+// products), the entry's 16 gradient sums
+constexpr int KROW3 = 8, SOFF3 = ROW + KROW3, BROW3 = SOFF3 + 16;
+__device__ __forceinline__ void publish_k3(float *row, V3 v1, V3 v2, V3 v3, V3 n)
+{
+    const V3 k1 = vcross(n, vsub(v3, v2)), k2 = vcross(n, vsub(v1, v3));
+    float4 *q = (float4 *)(row + ROW);
+    q[0] = make_float4(k1.x, k1.y, k1.z, k2.x);
+    q[1] = make_float4(k2.y, k2.z, 0.0f, 0.0f);
+}
 __device__ __forceinline__ void publish_row3(float *row, V3 v1, V3 v2, V3 v3, V3 n, const Cull3 &c, const float4 &r3, float w18, int jpos)
 {
     float4 *q = (float4 *)row;
@@ -116,6 +126,7 @@ __device__ __forceinline__ void republish_row3(float *row, const uint32_t *__res
     c.inn = 1.0f / vdot(n, n);
     c.d0 = vdot(v1, n);
     publish_row3(row, v1, v2, v3, n, c, r3, with_id ? __uint_as_float(id) : 0.0f, jpos);
+    if (with_id) publish_k3(row, v1, v2, v3, n); // backward rows
 }
 // Row -1: a unit triangle in the plane z = 1, a thousand units off axis, opacity 0: every pixel sees ecc ~ 3000
 __device__ __forceinline__ void write_dummy_row3(float *row, int lane)
@@ -131,7 +142,7 @@ __device__ __forceinline__ void write_dummy_row3(float *row, int lane)
 // The reference's per-pixel geometry (R3D forward.cu:238-256, backward.cu:328-343)
 struct Hit3
 {
-    V3 n, p1, p2, p3, c1, c2, e32, e13; // normal, p_vk = v_k - p_view, c1 = cross(p_v2, p_v3), c2 = cross(p_v3, p_v1), v3 - v2, v1 - v3
+    V3 n, p1, p2, p3, c1, c2; // normal, p_vk = v_k - p_view, c1 = cross(p_v2, p_v3), c2 = cross(p_v3, p_v1)
     float prn, inv_prn, depth, inn, a1, a2, a3, mn, ecc, op, r, g, b;
     bool ok; // |p_ray . n| >= EPS
 };
@@ -165,7 +176,6 @@ __device__ __forceinline__ Hit3 hit3(const float *row, V3 ray)
     }
     const V3 pv = vscale(h.depth, ray);
     h.p1 = vsub(v1, pv); h.p2 = vsub(v2, pv); h.p3 = vsub(v3, pv);
-    h.e32 = vsub(v3, v2); h.e13 = vsub(v1, v3);
     h.c1 = vcross(h.p2, h.p3);
     h.c2 = vcross(h.p3, h.p1);
     h.a1 = vdot(h.c1, h.n) * h.inn; // forward.cu:251-253
@@ -392,9 +402,10 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
     float *rows = rows_all[wave] + BROW3;
     uint32_t *list = list_all[wave];
     write_dummy_row3(rows - BROW3, lane);
+    if (lane < KROW3) (rows - BROW3)[ROW + lane] = 0.0f; // k1, k2 of the dummy row
     char *lds0 = (char *)rows_all;
     const uint32_t row0 = (uint32_t)(wave * (NR + 1) + 1) * (BROW3 * 4), dummy = row0 - BROW3 * 4;
-    const uint32_t accoff = ROW * 4 + 4 * sub;
+    const uint32_t accoff = SOFF3 * 4 + 4 * sub;
 
     float T = inside ? final_T[pix] : 0.0f;
     const int last = inside ? (int)n_contrib[pix] : 0;
@@ -453,13 +464,17 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
         const int lrel = last - base;
         const int r = rank & (NR - 1);
         bool mine = anybit && (rank / NR) == (nact - 1) / NR;
-        if (mine) publish_row3(rows + r * BROW3, v1, v2, v3, n, c, r3, __uint_as_float(id), lane);
+        if (mine)
+        {
+            publish_row3(rows + r * BROW3, v1, v2, v3, n, c, r3, __uint_as_float(id), lane);
+            publish_k3(rows + r * BROW3, v1, v2, v3, n);
+        }
         for (int h = (nact - 1) / NR;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
             if (mine)
             {
-                float4 *z = (float4 *)(rows + r * BROW3 + ROW);
+                float4 *z = (float4 *)(rows + r * BROW3 + SOFF3);
                 z[0] = z[1] = z[2] = z[3] = make_float4(0, 0, 0, 0);
             }
             list[lane] = dummy | (dummy << 16);
@@ -518,7 +533,9 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
                 const float z1 = k1 ? z : 0.0f, z2 = k2 ? z : 0.0f, z3 = z - z1 - z2;
                 const float w1 = (z1 - z3) * h.inn, w2 = (z2 - z3) * h.inn; // 1 / n.n folded in
                 const V3 A1 = vcross(h.p3, h.n), A2 = vcross(h.n, h.p2), A3 = vcross(h.p1, h.n);
-                const float da1_dd = vdot(h.n, vcross(h.e32, ray)), da2_dd = vdot(h.n, vcross(h.e13, ray)); // :389, 395
+                const float4 k0 = *(const float4 *)(row + ROW);
+                const float2 k4 = *(const float2 *)(row + ROW + 4);
+                const float da1_dd = vdot(ray, V3{k0.x, k0.y, k0.z}), da2_dd = vdot(ray, V3{k0.w, k4.x, k4.y}); // :389, 395 (see KROW3)
                 const float dLdd = fmaf(w2, da2_dd, fmaf(w1, da1_dd, RICH ? dd * contrib : 0.0f)) * h.inv_prn; // dL_ddepth / (p_ray.n)
                 float v[16];
                 v[bitrev4(0)] = fmaf(dLdd, h.n.x, -w2 * A1.x); // dL/dv1 = w2 cross(n, p_v3) + dL_ddepth n / prn; cross(n, p_v3) = -A1
@@ -553,7 +570,7 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
                     if (e < nn)
                     {
                         const uint32_t eid = __float_as_uint(rows[e * BROW3 + 18]);
-                        unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, rows[e * BROW3 + ROW + sub]);
+                        unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + sub, rows[e * BROW3 + SOFF3 + sub]);
                     }
                 }
             }

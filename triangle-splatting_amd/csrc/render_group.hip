@@ -368,7 +368,7 @@ __global__ void __launch_bounds__(256, 7) render_fwd_group_kernel(RenderArgs a, 
         for (int k = threadIdx.x; k < min(len, TCAP); k += 256)
         {
             const unsigned long long fx48 = tsum[k];
-            if (fx48 != 0ull) tile_stats_flush(fx48, tmax[k], point_list[range.x + k], contrib_sum, contrib_max);
+            if (TSG_PROBE != 5 && fx48 != 0ull) tile_stats_flush(fx48, tmax[k], point_list[range.x + k], contrib_sum, contrib_max);
         }
     }
     if (inside)
