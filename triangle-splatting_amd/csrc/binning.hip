@@ -886,13 +886,16 @@ void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long lon
 {
     if (N <= 0) return;
     const int bits = ts_higher_msb((uint32_t)ntiles);
+    // the key bits are shared out evenly over the passes (1080p: 13 bits = 7 + 6, not 8 + 5): fewer digits in the first pass mean longer
+    // runs per digit in a chunk (32 pairs instead of 16), i.e. better coalesced stores, and one ballot less per ranking step
+    const int per = (bits + b.passes - 1) / b.passes;
     int src = 0;
     for (int p = 0; p < b.passes; p++)
     {
-        const int nbits = min(8, bits - 8 * p);
+        const int shift = per * p, nbits = min(per, bits - shift);
         // ticket-free passes when the sort is small enough; scan_emit_kernel cleared slabacc[0] for the first one
-        if (radix_direct_ok(b.rs)) radix_pass_direct(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, n_dev, 8 * p, nbits, b.rs, p & 1, s);
-        else radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, n_dev, 8 * p, nbits, b.rs, s);
+        if (radix_direct_ok(b.rs)) radix_pass_direct(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, n_dev, shift, nbits, b.rs, p & 1, s);
+        else radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], N, n_dev, shift, nbits, b.rs, s);
         src ^= 1;
     }
 }
