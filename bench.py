@@ -20,6 +20,7 @@ The oracle is used here only as the timed CPU baseline and to cross-check the im
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -216,13 +217,20 @@ def main():
         _C.profile_reset()
         _C.profile_only(dominant)
     wait_events.clear()
+    stamps = []
+    # a generation-2 garbage collection in the middle of 20 timed steps costs several of them (the interpreter holds the oracle, the
+    # reference loader and torch): collect now, keep the collector out of the timed region like a training loop would
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        stamps.append(time.perf_counter())  # host time at which the step was queued (no synchronisation added): see `host_step_ms`
     if overlap:
         collect(state["step"] - 1)  # the last step's exchange belongs to the timed region
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     exposed_ms = sum(a.elapsed_time(b) for a, b in wait_events) / max(args.steps, 1) if wait_events else None
     if events:
         _C.profile_enable(False)
@@ -238,6 +246,7 @@ def main():
         if over:
             raise SystemExit("sync-free forward overflowed its instance capacity: the timed steps rendered nothing")
     ms_per_step = 1e3 * elapsed / args.steps
+    host_gaps = sorted(1e3 * (b - a) for a, b in zip([t0] + stamps[:-1], stamps))
     mpix_s = world * W * H / (elapsed / args.steps) / 1e6
     N = true_n
     ntiles = ((W + 15) // 16) * ((H + 15) // 16)
@@ -259,6 +268,9 @@ def main():
                                          if overlap else "synchronous: waited for inside the step",
                                  "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
                                  "process_groups": 2} if world > 1 else None),
+                   # spread of the host-side time per queued step: a stalled host (allocator growth, garbage collection, a descheduled thread)
+                   # shows up here as a maximum far above the median, and in `value` (the contract times all K steps, stalls included)
+                   "host_step_ms": {"min": round(host_gaps[0], 3), "median": round(host_gaps[len(host_gaps) // 2], 3), "max": round(host_gaps[-1], 3)},
                    "algorithmic_bytes_per_step": alg["total"],
                    "achieved_hbm_gbs_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9, 2),
                    "hbm_roofline_frac_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
