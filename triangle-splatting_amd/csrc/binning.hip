@@ -6,24 +6,32 @@
 // identifyTileRanges (R2D/src/rasterizer.cu:186, 37-75, 210-218, 79-99).
 //
 // How it is obtained here (same order, ~4.5x less sort traffic; N ~ 4.6 x P for the headline scene):
-//   1. stable radix sort of the P triangles by their 32-bit depth key (values = ascending ids): 4 passes x P pairs;
-//   2. tiles_touched gathered in that order + block sums + their prefix -> N (the one value the host reads back);
-//   3. per block: wave64 prefix scan (DPP) of the tile counts -> instance slots, and (tile, id) instances emitted in depth
-//      order; the same kernel clears the tile ranges and the contribution statistics (no memset launches);
+//   1. stable radix sort of the P triangles by their 32-bit depth key (values = ascending ids): 3-4 passes x P pairs; the first histogram
+//      also produces N = sum(tiles_touched) (the one value the host reads back) and finds out whether the fourth pass can be skipped;
+//   2. tiles_touched gathered in that order + block sums;
+//   3. per block: wave64 prefix scan (DPP) of the tile counts on top of the block sums in front -> instance slots, and (tile, id)
+//      instances emitted in depth order through LDS; the same kernel clears the tile ranges and the contribution statistics;
 //   4. stable radix sort of the N instances by TILE ID ONLY (13 bits at 1080p -> 2 passes x N x 8 B instead of
 //      6 passes x N x 12 B); stability keeps the depth order (and the id order among equal depths) inside a tile;
 //   5. tile ranges from the sorted tile ids.
 //
-// One radix pass (8-bit digit) = two kernels, no look-back spinning:
-//   rs_hist     one workgroup per chunk of 4096 pairs counts its digits in a 1 KB LDS table (ds_add_u32); the workgroup that
-//               arrives LAST in its slab of 64 chunks (one atomic ticket; the counts travel as write-through stores and
-//               L1-bypassing loads, so no L2 write-back fence is needed) turns the slab's rows into exclusive column
-//               prefixes, and the last slab to finish does the same over the slab totals and over the 256 digit totals;
+// One radix pass (digit of up to 8 bits) = two kernels, no look-back spinning.  Two flavours of the first one:
+//   rs_hist_direct  (sorts of up to 48 slabs = 12.6 M pairs: everything the headline runs) one workgroup per chunk of 2048 / 4096 pairs
+//               counts its digits in a 1 KB LDS table (ds_add_u32), stores the 256 counts as a raw table row and adds them to its slab's
+//               totals with fire-and-forget atomics.  Nobody waits for anybody: the scatter kernel works out its prefixes itself
+//               (<= 63 rows of its slab + the slabs' totals, requested while its keys are on their way);
+//   rs_hist     (larger sorts) the workgroup that arrives LAST in its slab of 64 chunks (one atomic ticket; the counts travel as
+//               write-through stores and L1-bypassing loads, so no L2 write-back fence is needed) turns the slab's rows into
+//               exclusive column prefixes, and the last slab to finish does the same over the slab totals and over the 256 digit totals.
+//               Its cost does not grow with the slab count, but the elected block walks seven dependent memory round trips alone:
+//               18 us at 1 M keys, which is why the small sorts left it;
 //   rs_scatter  the workgroup re-reads its chunk (each wave a contiguous quarter, 64 pairs per step): the lanes holding equal
-//               digits find each other with 8 ballots (wave64 match), rank = v_mbcnt of the match mask on top of the digit's
-//               running count; the pairs are parked in LDS in chunk-local sorted order and leave as coalesced runs.  Ranks
+//               digits find each other with one ballot per digit bit (wave64 match), rank = v_mbcnt of the match mask on top of the
+//               digit's running count; the pairs are parked in LDS in chunk-local sorted order and leave as coalesced runs.  Ranks
 //               follow lane order, steps follow list order, waves follow chunk order: stable by construction.
-// The round-1 rocPRIM calls (radix_sort_pairs, inclusive_scan) survive only as the comparators of tests/test_binning_gpu.py.
+// The same rule removed the elected blocks from the scan (raw block sums, added up by the emission blocks) and from the census (published
+// by block 0 of the first scatter).  The round-1 rocPRIM calls (radix_sort_pairs, inclusive_scan) survive only as the comparators of
+// tests/test_binning_gpu.py.
 #include "ts2d_common.h"
 #include "ts2d_wave.h"
 #include <rocprim/device/device_radix_sort.hpp>
