@@ -191,6 +191,7 @@ bool acquire_early_count(EarlyCount &e)
     }
     e.host = ring + (size_t)dev * SLOTS + i;
     e.ev = events[dev][i];
+    __atomic_store_n(e.host, ~0ull, __ATOMIC_RELEASE); // "not there yet": the count is < 2^63, the publishing block overwrites this
     return true;
 }
 } // namespace
@@ -238,8 +239,26 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     unsigned long long n = 0;
     if (have_early)
     {
-        TS_HIP(hipEventSynchronize(early.ev));
-        n = *early.host;
+        // The host watches the pinned word itself: the publishing block stores it (system scope) a few microseconds before its kernel
+        // retires and the event behind it fires, and no runtime call sits between the store and this thread.  The event is only asked
+        // now and then, so that a faulted launch surfaces as an error instead of an endless wait.
+        for (unsigned spin = 1;; spin++)
+        {
+            n = __atomic_load_n(early.host, __ATOMIC_ACQUIRE);
+            if (n != ~0ull) break;
+            if ((spin & 0x3FFFu) == 0)
+            {
+                const hipError_t q = hipEventQuery(early.ev);
+                if (q == hipSuccess)
+                {
+                    n = __atomic_load_n(early.host, __ATOMIC_ACQUIRE);
+                    break;
+                }
+                if (q != hipErrorNotReady) return fail(TS2D_ERR_HIP, "waiting for the instance count: %s", hipGetErrorString(q));
+            }
+            __builtin_ia32_pause();
+        }
+        if (n == ~0ull) return fail(TS2D_ERR_HIP, "the instance count was not published");
     }
     else
     {
