@@ -368,18 +368,23 @@ __device__ __forceinline__ void publish_census(const DepthCensus &census, int ch
 //      per 4-byte store on this chip: measured 2x slower than rocPRIM; staged, the stores are coalesced runs).
 // DIRECT: the pass's histogram was rs_hist_direct_kernel; `acc` holds the slabs' digit totals and the table rows are raw counts.
 // `acc_clear` (either flavour): the other totals buffer, cleared here for the next pass's histogram (nobody reads it any more).
-template <bool IDENTITY_VALUES, int CH, bool DIRECT, bool CENSUS = false>
-__global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
-                                                          uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n,
-                                                          const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r, const uint32_t *skip_flag,
-                                                          const uint32_t *__restrict__ acc, uint32_t *__restrict__ acc_clear, DepthCensus census = DepthCensus{})
+// TWO_PHASE (the 4096-pair chunks of the instance sort): keys and values pass through ONE staging array one after the other, and the values
+// are only loaded once the keys have been ranked.  Half the LDS and 16 registers less at the peak put seven workgroups on a CU instead of
+// four: the 1126 chunks of the headline's instance list are then resident in one round (4 x 256 slots had left 102 of them for a second).
+template <bool IDENTITY_VALUES, int CH, bool DIRECT, bool CENSUS, bool TWO_PHASE>
+__device__ __forceinline__ void rs_scatter_body(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin, uint32_t *__restrict__ kout,
+                                                uint32_t *__restrict__ vout, int64_t n, const unsigned long long *n_dev, int shift, int nbits,
+                                                RadixScratchView r, const uint32_t *skip_flag, const uint32_t *__restrict__ acc,
+                                                uint32_t *__restrict__ acc_clear, const DepthCensus &census)
 {
     constexpr int KB = CH / 256; // steps per wave
     if (!resolve_count<CH>(n_dev, n, r)) return;
     if (pass_skipped(skip_flag)) return;
     if (acc_clear && (int)blockIdx.x < r.slabs) acc_clear[(size_t)blockIdx.x * NB + threadIdx.x] = 0u;
-    __shared__ __attribute__((aligned(16))) uint32_t stage_k[CH], stage_v[CH];
-    static_assert(CH >= 8 * NB, "the DIRECT prefix exchange borrows 8 x 256 words of stage_k");
+    __shared__ __attribute__((aligned(16))) uint32_t stage_k[CH], stage_v[TWO_PHASE ? 4 : CH];
+    static_assert(CH >= (TWO_PHASE ? 12 : 8) * NB, "the DIRECT prefix exchange borrows 8 (TWO_PHASE: 12) x 256 words of stage_k");
+    static_assert(!TWO_PHASE || (!IDENTITY_VALUES && !CENSUS), "TWO_PHASE is the instance sort's flavour");
+    uint32_t *const xtotal = TWO_PHASE ? stage_k + 8 * NB : stage_v; // where the four waves' partial digit totals meet
     __shared__ uint32_t wcnt[4][NB]; // per-wave digit counts, then the chunk-local start of the (wave, digit) run
     __shared__ int32_t gdelta[NB];   // global run start of the digit minus its chunk-local start
     __shared__ uint32_t wtot[4], gtot[4];
@@ -387,14 +392,21 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
     const int chunk = blockIdx.x;
     const uint32_t mask = (1u << nbits) - 1u;
     const int64_t base = (int64_t)chunk * CH + (int64_t)wave * (CH / 4);
+    const int64_t here = n - base;                                        // pairs from this wave's first one to the end of the array
+    const int mine = here >= CH / 4 ? CH / 4 : (here > 0 ? (int)here : 0); // ... of which this wave holds the first `mine`
+    const uint32_t *kin_w = kin + base, *vin_w = IDENTITY_VALUES ? nullptr : vin + base;
     uint32_t key[KB], val[KB], rk[KB];
 #pragma unroll
     for (int b = 0; b < KB; b++)
     {
-        const int64_t i = base + 64 * b + lane;
+        const int i = 64 * b + lane;
         key[b] = 0xFFFFFFFFu;
         val[b] = 0u;
-        if (i < n) { key[b] = kin[i]; val[b] = IDENTITY_VALUES ? (uint32_t)i : vin[i]; }
+        if (i < mine)
+        {
+            key[b] = kin_w[i];
+            if (!TWO_PHASE) val[b] = IDENTITY_VALUES ? (uint32_t)(base + i) : vin_w[i];
+        }
     }
     // DIRECT: how many pairs of each digit sit in earlier chunks of this slab, in earlier slabs, and in all slabs.  Wave w takes every
     // fourth row, lane l the digits 4l .. 4l + 3 (one dwordx4 per row: at most 16 + 12 loads per lane, all requested here, behind the keys);
@@ -405,7 +417,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
         const int slab = chunk >> 6, c0 = slab * 64;
         const uint4 *tab4 = (const uint4 *)r.table + (size_t)c0 * (NB / 4) + lane;
         const uint4 *acc4 = (const uint4 *)acc + lane;
-#pragma unroll
+#pragma unroll 4
         for (int k = 0; k < 16; k++)
         {
             const int c = wave + 4 * k;
@@ -415,7 +427,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
                 p_within.x += v.x; p_within.y += v.y; p_within.z += v.z; p_within.w += v.w;
             }
         }
-#pragma unroll
+#pragma unroll 4
         for (int k = 0; k < TS_DIRECT_MAX_SLABS / 4; k++)
         {
             const int sl = wave + 4 * k;
@@ -434,7 +446,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
 #pragma unroll
     for (int b = 0; b < KB; b++)
     {
-        const bool valid = base + 64 * b + lane < n;
+        const bool valid = 64 * b + lane < mine;
         const uint32_t d = (key[b] >> shift) & mask;
         unsigned long long m = ballot64(valid);
         for (int bit = 0; bit < nbits; bit++)
@@ -456,7 +468,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
     {
         *(uint4 *)(stage_k + wave * NB + 4 * lane) = p_within;
         *(uint4 *)(stage_k + (4 + wave) * NB + 4 * lane) = p_before;
-        *(uint4 *)(stage_v + wave * NB + 4 * lane) = p_total;
+        *(uint4 *)(xtotal + wave * NB + 4 * lane) = p_total;
     }
     __syncthreads();
     {
@@ -469,7 +481,7 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
             {
                 d_within += stage_k[w * NB + t];
                 d_before += stage_k[(4 + w) * NB + t];
-                d_total += stage_v[w * NB + t];
+                d_total += xtotal[w * NB + t];
             }
         }
         const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
@@ -495,17 +507,59 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
         gdelta[t] = (int32_t)(g - dbase);
     }
     __syncthreads();
+    const int64_t left = n - (int64_t)chunk * CH;
+    const int count = left < CH ? (int)left : CH;
+    if (TWO_PHASE)
+    {
+#pragma unroll
+        for (int b = 0; b < KB; b++)
+            if (64 * b + lane < mine)
+            {
+                rk[b] += wcnt[wave][(key[b] >> shift) & mask]; // chunk-local sorted position, kept for the values
+                stage_k[rk[b]] = key[b];
+            }
+#pragma unroll
+        for (int b = 0; b < KB; b++) // the keys' registers are free now; the values arrive while the keys leave
+        {
+            const int i = 64 * b + lane;
+            if (i < mine) val[b] = vin_w[i];
+        }
+        __syncthreads();
+        uint32_t dpack[KB / 4]; // the digits of the KB positions this thread writes out, for the values' turn
+#pragma unroll
+        for (int j = 0; j < KB; j++)
+        {
+            const int p = t + 256 * j;
+            if ((j & 3) == 0) dpack[j >> 2] = 0u;
+            if (p < count)
+            {
+                const uint32_t k = stage_k[p], d = (k >> shift) & mask;
+                dpack[j >> 2] |= d << (8 * (j & 3));
+                kout[(int64_t)gdelta[d] + p] = k;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < KB; b++)
+            if (64 * b + lane < mine) stage_k[rk[b]] = val[b];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < KB; j++)
+        {
+            const int p = t + 256 * j;
+            if (p < count) vout[(int64_t)gdelta[(dpack[j >> 2] >> (8 * (j & 3))) & 0xFFu] + p] = stage_k[p];
+        }
+        return;
+    }
 #pragma unroll
     for (int b = 0; b < KB; b++)
-        if (base + 64 * b + lane < n)
+        if (64 * b + lane < mine)
         {
             const uint32_t p = wcnt[wave][(key[b] >> shift) & mask] + rk[b];
             stage_k[p] = key[b];
             stage_v[p] = val[b];
         }
     __syncthreads();
-    const int64_t left = n - (int64_t)chunk * CH;
-    const int count = left < CH ? (int)left : CH;
     for (int p = t; p < count; p += 256)
     {
         const uint32_t k = stage_k[p];
@@ -514,6 +568,23 @@ __global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restr
         vout[dst] = stage_v[p];
     }
     if (CENSUS && chunk == 0) publish_census(census, r.chunks, t);
+}
+template <bool IDENTITY_VALUES, int CH, bool DIRECT, bool CENSUS = false>
+__global__ void __launch_bounds__(256) rs_scatter_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                          uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n,
+                                                          const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r, const uint32_t *skip_flag,
+                                                          const uint32_t *__restrict__ acc, uint32_t *__restrict__ acc_clear, DepthCensus census = DepthCensus{})
+{
+    rs_scatter_body<IDENTITY_VALUES, CH, DIRECT, CENSUS, false>(kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc, acc_clear, census);
+}
+// the TWO_PHASE flavour with the register budget of five workgroups per CU (1280 resident chunks = 5.2 M pairs)
+template <int CH>
+__global__ void __launch_bounds__(256, 5) rs_scatter_two_phase_kernel(const uint32_t *__restrict__ kin, const uint32_t *__restrict__ vin,
+                                                                       uint32_t *__restrict__ kout, uint32_t *__restrict__ vout, int64_t n,
+                                                                       const unsigned long long *n_dev, int shift, int nbits, RadixScratchView r,
+                                                                       const uint32_t *skip_flag, const uint32_t *__restrict__ acc, uint32_t *__restrict__ acc_clear)
+{
+    rs_scatter_body<false, CH, true, false, true>(kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc, acc_clear, DepthCensus{});
 }
 
 void radix_hist(const uint32_t *kin, int64_t n, const unsigned long long *n_dev, int shift, int nbits, const RadixScratchView &r, hipStream_t s,
@@ -537,7 +608,9 @@ void radix_scatter(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uin
     if (acc && vin)
     {
         if (small) TS_SCATTER(false, TS_RS_CHUNK_SMALL, true);
-        else TS_SCATTER(false, TS_RS_CHUNK, true);
+        else
+            hipLaunchKernelGGL((rs_scatter_two_phase_kernel<TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc,
+                               acc_clear);
     }
     else if (acc)
     {
