@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     // The block's instances are one contiguous run of the list.  A lane writing its triangle's few slots straight to memory issues 4-byte
     // stores a few slots apart from its neighbours' (a 32-64 byte fabric write each on this chip); runs of up to STAGE instances are put
     // together in LDS instead and leave as coalesced rows.
-    constexpr uint32_t STAGE = 3072;
+    constexpr uint32_t STAGE = 2048;
     __shared__ uint32_t stage_t[STAGE], stage_v[STAGE];
     const uint32_t run0 = (uint32_t)qbase, run = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     const bool staged = run <= STAGE;
