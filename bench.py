@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--settle-ms", type=float, default=150.0, help="untimed steps for this long before the warm-up steps (0 = none)")
+    ap.add_argument("--settle-steps", type=int, default=80, help="untimed steps in front of the W warm-up steps (0 = none): device clocks / power state")
     ap.add_argument("--rasterizer", default="2D", choices=["2D", "3D"],
                     help="2D = the headline path (BASELINE.json); 3D = the ray/plane variant (SURVEY.md 8f rank 1), not the headline")
     ap.add_argument("--dense-exchange", action="store_true",
@@ -200,20 +200,19 @@ def main():
     events = not args.no_kernel_events
     step()  # cold step (library initialisation, allocator growth) -- never timed
     barrier()
-    # The first tens of milliseconds of load on a fresh process contain one multi-millisecond stall of the device (seen as a single
-    # 2 - 5 ms step among 20: clock / power-state ramp); with few warm-up steps it lands in the timed region.  Untimed steps until the
-    # device has been busy for `--settle-ms` put it behind us; the W warm-up steps and the K timed ones follow unchanged.
-    t_settle = time.perf_counter()
-    settle_steps = 0
-    while 1e3 * (time.perf_counter() - t_settle) < args.settle_ms:
-        step()
-        settle_steps += 1
-    barrier()
     if args.sync_free:
         import diff_triangle_rasterization_2D as _pkg
         _pkg.set_instance_capacity(int(1.25 * int(state["num_rendered"])) + 1024)
         step()
         barrier()
+    # The first tens of milliseconds of load on a fresh process contain one multi-millisecond stall of the device (seen as a single
+    # 2 - 5 ms step among 20: clock / power-state ramp); with few warm-up steps it lands in the timed region.  Untimed steps until the
+    # device has been busy for ~0.15 s put it behind us; the W warm-up steps and the K timed ones follow unchanged.  A fixed COUNT, not a
+    # duration: with N > 1 every step contains collectives, so all ranks must run the same number of them.
+    settle_steps = max(args.settle_steps, 0)
+    for _ in range(settle_steps):
+        step()
+    barrier()
     if events:
         _C.profile_reset()
         _C.profile_only("")
