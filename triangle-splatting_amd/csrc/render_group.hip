@@ -214,7 +214,6 @@ __global__ void __launch_bounds__(256, 7) render_fwd_group_kernel(RenderArgs a, 
     const char *lds0 = (const char *)cst_all;                                      // list entries are byte offsets from here
     const uint32_t row0 = (uint32_t)(wave * (NR + 1) + 1) * (ROW * 4), dummy = row0 - ROW * 4; // row r of this wave: row0 + r * 80
     const RowSel rsel(lane);
-    const int my_slot = (lane >> 3 & 1) + ((lane >> 2 & 1) << 1) + ((lane >> 1 & 1) << 2); // which of a window's 8 steps this lane reports
 
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, anx = 0.0f, any_ = 0.0f, anz = 0.0f, ad = 0.0f;
     bool done = !inside;
