@@ -9,7 +9,12 @@ One "step" = one forward + one backward of the rasterizer over one view of the s
 S(P=1M, 1920x1080, SH degree 3, rich_info=True) (SURVEY.md 8d / BASELINE.md 4), through the drop-in Python
 package, i.e. through the C ABI of libts2d.so.  Inputs are resident in HBM before the timed region.  With N > 1
 every rank renders its own view of the same triangles (image-parallel, weak scaling) and the per-triangle
-gradients are summed with one RCCL all-reduce inside the step.  Rank 0 prints ONE JSON line.
+gradients are exchanged over RCCL (reduce-scatter + all-gather of one bucket, double-buffered and collected one step later unless
+--sync-exchange).  Rank 0 prints ONE JSON line.
+
+Sequence: one cold step, --settle-steps untimed steps (device clocks / power state; reported as config.settle_steps_untimed), the W
+warm-up steps (every kernel bracketed by HIP events: kernels_avg_ms_warmup), then exactly K steps between barriers + synchronize, the
+garbage collector kept out of them; config.host_step_ms is the spread of the host time per queued step inside the timed region.
 
 Extra objects in the JSON line:
   roofline     -- the dominant kernel's algorithmic bytes / its average duration (HIP events on the launch stream,
