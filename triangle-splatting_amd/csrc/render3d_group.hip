@@ -326,15 +326,7 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
             if (mine) republish_row3(cst + r * ROW, point_list, rec, range.x + base + lane, false, lane);
         }
     }
-    if (RICH)
-    {
-        __syncthreads();
-        for (int k = threadIdx.x; k < min(len, TCAP); k += 256)
-        {
-            const unsigned long long fx48 = tsum[k];
-            if (fx48 != 0ull) tile_stats_flush(fx48, tmax[k], point_list[range.x + k], contrib_sum, contrib_max);
-        }
-    }
+    // the wave's pixels leave first; their stores and the ids of the flush are in flight while the wave waits for the others (render_group.hip)
     if (inside)
     {
         const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
@@ -349,6 +341,29 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
             out_normal[pix] = anx;
             out_normal[HW + pix] = any_;
             out_normal[2 * HW + pix] = anz;
+        }
+    }
+    if (RICH)
+    {
+        constexpr int NF = (TCAP + 255) / 256;
+        const int nflush = min(len, TCAP);
+        uint32_t ids[NF];
+#pragma unroll
+        for (int j = 0; j < NF; j++)
+        {
+            const int k = (int)threadIdx.x + 256 * j;
+            ids[j] = k < nflush ? point_list[range.x + k] : 0u;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NF; j++)
+        {
+            const int k = (int)threadIdx.x + 256 * j;
+            if (k < nflush)
+            {
+                const unsigned long long fx48 = tsum[k];
+                if (fx48 != 0ull) tile_stats_flush(fx48, tmax[k], ids[j], contrib_sum, contrib_max);
+            }
         }
     }
 }

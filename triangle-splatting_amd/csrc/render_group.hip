@@ -361,15 +361,7 @@ __global__ void __launch_bounds__(256, 7) render_fwd_group_kernel(RenderArgs a, 
     if (lane == 0)
         for (int i = 0; i < 12; i++) atomicAdd(&g_stats_group[i], stat_acc[i]);
 #endif
-    if (RICH)
-    {
-        __syncthreads(); // the only rendezvous of the four quadrant waves: the tile's merged contribution statistics leave
-        for (int k = threadIdx.x; k < min(len, TCAP); k += 256)
-        {
-            const unsigned long long fx48 = tsum[k];
-            if (TSG_PROBE != 5 && fx48 != 0ull) tile_stats_flush(fx48, tmax[k], point_list[range.x + k], contrib_sum, contrib_max);
-        }
-    }
+    // the wave's pixels leave first: their stores, and the ids the flush below needs, are in flight while the wave waits for the others
     if (inside)
     {
         const size_t pix = (size_t)py * a.W + px, HW = (size_t)a.H * a.W;
@@ -384,6 +376,29 @@ __global__ void __launch_bounds__(256, 7) render_fwd_group_kernel(RenderArgs a, 
             out_normal[pix] = anx;
             out_normal[HW + pix] = any_;
             out_normal[2 * HW + pix] = anz;
+        }
+    }
+    if (RICH)
+    {
+        constexpr int NF = (TCAP + 255) / 256;
+        const int nflush = min(len, TCAP);
+        uint32_t ids[NF];
+#pragma unroll
+        for (int j = 0; j < NF; j++)
+        {
+            const int k = (int)threadIdx.x + 256 * j;
+            ids[j] = k < nflush ? point_list[range.x + k] : 0u;
+        }
+        __syncthreads(); // the only rendezvous of the four quadrant waves: the tile's merged contribution statistics leave
+#pragma unroll
+        for (int j = 0; j < NF; j++)
+        {
+            const int k = (int)threadIdx.x + 256 * j;
+            if (k < nflush)
+            {
+                const unsigned long long fx48 = tsum[k];
+                if (TSG_PROBE != 5 && fx48 != 0ull) tile_stats_flush(fx48, tmax[k], ids[j], contrib_sum, contrib_max);
+            }
         }
     }
 }
