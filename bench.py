@@ -9,12 +9,17 @@ One "step" = one forward + one backward of the rasterizer over one view of the s
 S(P=1M, 1920x1080, SH degree 3, rich_info=True) (SURVEY.md 8d / BASELINE.md 4), through the drop-in Python
 package, i.e. through the C ABI of libts2d.so.  Inputs are resident in HBM before the timed region.  With N > 1
 every rank renders its own view of the same triangles (image-parallel, weak scaling) and the per-triangle
-gradients are exchanged over RCCL (reduce-scatter + all-gather of one bucket, double-buffered and collected one step later unless
---sync-exchange).  Rank 0 prints ONE JSON line.
+gradients are exchanged over RCCL (reduce-scatter + all-gather of one bucket on a side stream, waited for INSIDE the step that produced
+them -- north_star's all-reduce semantics; --delayed-exchange collects them one step later instead).  Rank 0 prints
+ONE JSON line.
 
-Sequence: one cold step, --settle-steps untimed steps (device clocks / power state; reported as config.settle_steps_untimed), the W
-warm-up steps (every kernel bracketed by HIP events: kernels_avg_ms_warmup), then exactly K steps between barriers + synchronize, the
-garbage collector kept out of them; config.host_step_ms is the spread of the host time per queued step inside the timed region.
+Sequence: one cold step, two steps that find the dominant kernel, garbage collection (then off), --settle-steps + W untimed steps identical
+to the timed ones with NOTHING between the last of them and the barrier that opens the timed region (the device needs ~25 ms of load to
+bring its clocks back after an idle gap; config.settle_steps_untimed), exactly K steps between barriers + synchronize, then ten steps with
+every kernel bracketed by HIP events (kernels_avg_ms).  Every timed step leaves ONE event on the launch stream: config.device_step_ms is the
+spread of the time between consecutive events (what the GPU saw), config.host_step_ms the spread of the host time per queued step,
+config.gpu_idle_ms_per_step the mean device step minus the sum of the kernels' own durations -- a stall is attributable to the host or to
+the device from these.
 
 Extra objects in the JSON line:
   roofline     -- the dominant kernel's algorithmic bytes / its average duration (HIP events on the launch stream,
@@ -80,15 +85,26 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--settle-steps", type=int, default=80, help="untimed steps in front of the W warm-up steps (0 = none): device clocks / power state")
+    ap.add_argument("--settle-steps", type=int, default=40,
+                    help="untimed steps in front of the W warm-up steps (0 = none): ~70 ms of load bring the device's clocks up; what matters is that "
+                         "NOTHING sits between the last warm-up step and the timed region (see the sequence comment in main)")
     ap.add_argument("--rasterizer", default="2D", choices=["2D", "3D"],
                     help="2D = the headline path (BASELINE.json); 3D = the ray/plane variant (SURVEY.md 8f rank 1), not the headline")
     ap.add_argument("--dense-exchange", action="store_true",
                     help="N > 1: all-reduce the dense dL_dshs (60 floats/triangle) instead of the factored exchange (15 + 3 per view)")
-    ap.add_argument("--sync-exchange", action="store_true",
-                    help="N > 1: wait for the gradient exchange inside the step that produced it (round 2 behaviour); default: double-buffered "
-                         "buckets, the exchange of step i is waited for after step i+1's kernels are queued (one-step-delayed application)")
+    ap.add_argument("--delayed-exchange", action="store_true",
+                    help="N > 1: double-buffered buckets, the exchange of step i is waited for after step i+1's kernels are queued (one-step-delayed "
+                         "application of the gradients -- NOT north_star's semantics); default: synchronous, step i's reduced gradients are waited "
+                         "for before step i+1's forward is queued")
+    ap.add_argument("--sync-exchange", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--exchange-compare", action="store_true",
+                    help="N > 1: after the timed region, time K more steps in the OTHER exchange mode and report its exposed_ms_per_step and "
+                         "ms_per_step beside the headline mode's (config.exchange.other_mode)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--timed-kernel-events", default="dominant", choices=["dominant", "all"],
+                    help="which kernels are bracketed by HIP events INSIDE the timed region: the dominant one (2 events per step; default) or "
+                         "every kernel (measurement of the kernels under sustained load; costs a few per cent of `value`)")
+    ap.add_argument("--dump-steps", action="store_true", help="config.device_step_ms_all / host_step_ms_all: the per-step sequences, in order")
     ap.add_argument("--sync-free", action="store_true",
                     help="use the sync-free forward (ts2d_forward, capacity = 1.25 x the instance count of the cold step) instead of the "
                          "reference's sequence with its blocking read of num_rendered; overflow is checked after the timed region")
@@ -141,19 +157,20 @@ def main():
     factored = world > 1 and not args.dense_exchange
     M = shs.shape[1]
     buckets, shx, wait_events = [], [], []
-    overlap = world > 1 and not args.sync_exchange
+    overlap = world > 1 and args.delayed_exchange
+    two_buckets = world > 1 and (overlap or args.exchange_compare)
     if world > 1:
         shapes = [vertex.shape, opacity.shape, torch.Size((P, 2))] + ([] if factored else [shs.shape])
         # two process groups = two RCCL communicators / streams: the bucket's reduce-scatter + all-gather and the SH-gradient all-gather
         # are in flight together; two buckets: the exchange of step i has the whole of step i + 1 to finish
         bucket_group, sh_group = parallel.exchange_groups()
-        for _ in range(2 if overlap else 1):
+        for _ in range(2 if two_buckets else 1):
             buckets.append(GradBucket(shapes, dev, group=bucket_group, names=["vertex", "opacity", "center2D"] + ([] if factored else ["color"])))
             shx.append(parallel.FactoredShExchange(sh_group, dev))
         bucket = buckets[0]
     sink = parallel.ShGradSink()
 
-    state = {"step": 0}
+    state = {"step": 0, "overlap": overlap, "pending": None}
 
     def collect(i):
         """Waits (on the compute stream) for the exchange that step i started; the wait is bracketed by events = the EXPOSED exchange time."""
@@ -179,10 +196,12 @@ def main():
             b.reduce_async()
             if factored:
                 x.start(sink, vertex, D, M, uniform=True)
-            if not overlap:
-                collect(i)       # synchronous: this step's gradients, now
-            elif i > 0:
-                collect(i - 1)   # one-step-delayed application: the previous step's gradients arrive while this step's exchange is in flight
+            prev, state["pending"] = state["pending"], i
+            if not state["overlap"]:
+                collect(i)       # synchronous (default): this step's reduced gradients before anything of the next step is queued
+                state["pending"] = None
+            elif prev is not None:
+                collect(prev)    # one-step-delayed application: the previous step's gradients arrive while this step's exchange is in flight
             state["step"] = i + 1
         else:
             out = raster(vertex, center2D, opacity, shs=shs)
@@ -199,60 +218,100 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # Warm-up steps are also used to time EVERY kernel with HIP events (the per-kernel table, and to find the
-    # dominant kernel).  In the timed region only the dominant kernel is bracketed by events (2 events per step on
-    # the launch stream) so that the measurement does not perturb `value` (all-kernel events cost ~2.7 %).
+    # Sequence (round 4; profiles/r04_notes.md has the per-step device times behind it):
+    #   1. one cold step (library initialisation, allocator growth), then two steps with EVERY kernel bracketed by HIP events -- only to
+    #      find the dominant kernel, the one the timed region brackets (2 events per step; all-kernel events cost a few per cent);
+    #   2. garbage collection now, the collector off until the timed region is over (like a training loop would);
+    #   3. --settle-steps untimed steps + the W warm-up steps, identical to the timed ones, and NOTHING between the last of them and the
+    #      barrier that opens the timed region.  The MI355X takes ~25 ms of load (~15 steps) to bring its clocks back after an idle gap of
+    #      some tens of milliseconds (1.62 ms/step steady, 2.2 ms for the first step after such a gap): rounds 2 and 3 ran their warm-up
+    #      steps, then read event tables and collected garbage, and started the clock on a device that had just dropped its clocks;
+    #   4. the K timed steps between barriers; 5. ten more steps with every kernel bracketed = the per-kernel table, device still warm.
+    # A fixed COUNT of settle steps, not a duration: with N > 1 every step contains collectives, so all ranks run the same number.
     events = not args.no_kernel_events
-    step()  # cold step (library initialisation, allocator growth) -- never timed
+    step()  # cold step -- never timed
     barrier()
     if args.sync_free:
         import diff_triangle_rasterization_2D as _pkg
         _pkg.set_instance_capacity(int(1.25 * int(state["num_rendered"])) + 1024)
         step()
         barrier()
-    # The first tens of milliseconds of load on a fresh process contain one multi-millisecond stall of the device (seen as a single
-    # 2 - 5 ms step among 20: clock / power-state ramp); with few warm-up steps it lands in the timed region.  Untimed steps until the
-    # device has been busy for ~0.15 s put it behind us; the W warm-up steps and the K timed ones follow unchanged.  A fixed COUNT, not a
-    # duration: with N > 1 every step contains collectives, so all ranks must run the same number of them.
-    settle_steps = max(args.settle_steps, 0)
-    for _ in range(settle_steps):
-        step()
-    barrier()
+    dominant = ""
     if events:
         _C.profile_reset()
         _C.profile_only("")
         _C.profile_enable(True)
-    for _ in range(max(args.warmup - 1, 1)):
-        step()
-    barrier()
-    warm_rows = _C.profile_read() if events else []
-    dominant = max(warm_rows, key=lambda r: r[1] / max(r[2], 1))[0] if warm_rows else ""
-    if events:
+        for _ in range(2):
+            step()
+        barrier()
+        rows0 = _C.profile_read()
+        dominant = max(rows0, key=lambda r: r[1] / max(r[2], 1))[0] if rows0 else ""
         _C.profile_reset()
-        _C.profile_only(dominant)
-    wait_events.clear()
-    stamps = []
-    # a generation-2 garbage collection in the middle of 20 timed steps costs several of them (the interpreter holds the oracle, the
-    # reference loader and torch): collect now, keep the collector out of the timed region like a training loop would
+        _C.profile_only(dominant if args.timed_kernel_events == "dominant" else "")
     gc.collect()
     gc.disable()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    settle_steps = max(args.settle_steps, 0)
+    for _ in range(settle_steps + max(args.warmup, 0)):
         step()
-        stamps.append(time.perf_counter())  # host time at which the step was queued (no synchronisation added): see `host_step_ms`
-    if overlap:
-        collect(state["step"] - 1)  # the last step's exchange belongs to the timed region
-    barrier()
-    elapsed = time.perf_counter() - t0
+    if events:
+        _C.profile_reset()  # drains the pending events: the device idles for microseconds, not for a table read
+
+    def timed_region(delayed):
+        """Exactly K steps between barriers; returns (elapsed s, host stamps, per-step device events, exposed exchange ms per step)."""
+        if state["pending"] is not None:  # delayed mode: the exchange of the last step before this region is still out
+            collect(state["pending"])
+            state["pending"] = None
+        state["overlap"] = delayed
+        wait_events.clear()
+        stamps, marks = [], [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+        barrier()
+        t_start = time.perf_counter()
+        marks[0].record()
+        for k in range(args.steps):
+            step()
+            marks[k + 1].record()               # ONE event per step on the launch stream: see `device_step_ms`
+            stamps.append(time.perf_counter())  # host time at which the step was queued (no synchronisation added): see `host_step_ms`
+        if state["pending"] is not None:
+            collect(state["pending"])  # delayed mode: the last step's exchange belongs to the timed region
+            state["pending"] = None
+        barrier()
+        took = time.perf_counter() - t_start
+        exposed = sum(a.elapsed_time(b) for a, b in wait_events) / max(args.steps, 1) if wait_events else None
+        return took, [t_start] + stamps, marks, exposed
+
+    elapsed, stamps, marks, exposed_ms = timed_region(overlap)
+    timed_rows = _C.profile_read() if events else []
+    other = None
+    if world > 1 and args.exchange_compare:
+        if events:
+            _C.profile_enable(False)
+        o_elapsed, _, _, o_exposed = timed_region(not overlap)
+        other = {"mode": "delayed" if not overlap else "synchronous", "ms_per_step": o_elapsed, "exposed_ms_per_step": o_exposed}
+    warm_rows = []
+    if events and world == 1:
+        # the per-kernel table: ten more steps with every kernel bracketed, right behind the timed region (device warm)
+        _C.profile_reset()
+        _C.profile_only("")
+        _C.profile_enable(True)
+        for _ in range(10):
+            step()
+        barrier()
+        warm_rows = _C.profile_read()
     gc.enable()
-    exposed_ms = sum(a.elapsed_time(b) for a, b in wait_events) / max(args.steps, 1) if wait_events else None
+    t0 = stamps[0]
+    stamps = stamps[1:]
+    device_seq = [a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])]
+    device_steps = sorted(device_seq)
     if events:
         _C.profile_enable(False)
         _C.profile_only("")
     if world > 1:
-        tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([elapsed, other["ms_per_step"] if other else 0.0], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed = float(tmax[0].item())
+        if other:
+            other["ms_per_step"] = round(1e3 * float(tmax[1].item()) / args.steps, 4)
+            other["exposed_ms_per_step"] = None if other["exposed_ms_per_step"] is None else round(other["exposed_ms_per_step"], 4)
 
     true_n = int(state["num_rendered"])
     if args.sync_free:
@@ -275,27 +334,44 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
                    "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N,
-                   "forward": "sync-free (ts2d_forward, device-side instance count)" if args.sync_free else "reference sequence (blocking read of num_rendered)",
+                   "forward": ("sync-free (ts2d_forward, device-side instance count)" if args.sync_free else
+                               "speculative (ts2d_forward_speculative: queued for 1.25 x the recent instance count, exact num_rendered read back "
+                               "behind the queue; the package default)"),
                    "parallelism": f"image-parallel x{world}" + ((", RCCL reduce-scatter + all-gather of one 12-float/triangle bucket the backward writes into (GradBucket.capture) + all-gather of factored SH grads (3 floats/triangle/view)" if factored
                                        else ", RCCL all-reduce of dense per-triangle grads (60 floats/triangle)") if world > 1 else ""),
-                   "exchange": ({"mode": "overlapped: double-buffered buckets, step i's exchange is waited for behind step i+1's kernels (one-step-delayed application)"
-                                         if overlap else "synchronous: waited for inside the step",
+                   "exchange": ({"mode": "delayed: double-buffered buckets, step i's exchange is waited for behind step i+1's kernels (one-step-delayed application)"
+                                         if overlap else "synchronous: step i's reduced gradients are waited for inside step i (north_star's all-reduce semantics)",
                                  "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
-                                 "process_groups": 2} if world > 1 else None),
+                                 "other_mode": other, "process_groups": 2} if world > 1 else None),
                    # spread of the host-side time per queued step: a stalled host (allocator growth, garbage collection, a descheduled thread)
                    # shows up here as a maximum far above the median, and in `value` (the contract times all K steps, stalls included)
                    "settle_steps_untimed": settle_steps,
                    "host_step_ms": {"min": round(host_gaps[0], 3), "median": round(host_gaps[len(host_gaps) // 2], 3), "max": round(host_gaps[-1], 3)},
+                   # time between the per-step events on the launch stream: what the GPU saw.  A device step far above the median with an
+                   # unremarkable host step is a device-side stall; both high together = the host starved the queue
+                   "device_step_ms": {"min": round(device_steps[0], 3), "median": round(device_steps[len(device_steps) // 2], 3),
+                                      "max": round(device_steps[-1], 3), "mean": round(sum(device_steps) / len(device_steps), 4)},
                    "algorithmic_bytes_per_step": alg["total"],
                    "achieved_hbm_gbs_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9, 2),
                    "hbm_roofline_frac_whole_step": round(alg["total"] / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 5)},
     }
 
+    if args.dump_steps:
+        result["config"]["device_step_ms_all"] = [round(x, 3) for x in device_seq]
+        result["config"]["host_step_ms_all"] = [round(1e3 * (b - a), 3) for a, b in zip([t0] + stamps[:-1], stamps)]
     if rank == 0:
         if events:
-            rows = _C.profile_read()  # the dominant kernel, timed inside the timed region
+            rows = timed_rows  # the dominant kernel (or, with --timed-kernel-events all, every kernel), timed inside the timed region
+            if args.timed_kernel_events == "all":
+                result["kernels_avg_ms_timed_region"] = {name: round(ms / max(n, 1), 4) for name, ms, n in rows}
+                result["config"]["gpu_busy_ms_per_step_timed_region"] = round(sum(ms / max(n, 1) for _, ms, n in rows), 4)
+                rows = [r for r in rows if r[0] == dominant]
             kernels = {name: ms / max(n, 1) for name, ms, n in warm_rows}
-            result["kernels_avg_ms_warmup"] = {k: round(v, 4) for k, v in kernels.items()}
+            result["kernels_avg_ms"] = {k: round(v, 4) for k, v in kernels.items()}  # ten steps right behind the timed region
+            if world == 1:
+                busy = sum(kernels.values())
+                result["config"]["gpu_busy_ms_per_step"] = round(busy, 4)  # sum of the kernels' own durations
+                result["config"]["gpu_idle_ms_per_step"] = round(sum(device_steps) / len(device_steps) - busy, 4)
             dom, dom_ms, dom_n = rows[0]
             dom_avg = dom_ms / max(dom_n, 1)
             ach = alg[dom] / (dom_avg * 1e-3) / 1e9

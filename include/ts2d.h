@@ -18,6 +18,8 @@
  *   ts2d_backward         -> Rasterizer::backward: BACKWARD::renderCUDA + BACKWARD::preprocessCUDA
  *                                                             (R2D/src/rasterizer.cu:269-358)
  *   ts2d_*_state_bytes    -> BaseDataBuffer::requiredSize     (R2D/src/param_struct.h:36-40)
+ *   ts2d_forward_speculative -> the whole of Rasterizer::forward with its num_rendered read-back taken off the GPU's critical path
+ *                            (R2D/src/rasterizer.cu:101-267; what the Python package calls)
  *
  * Together, forward_bin + forward_render are what `rasterizeTrianglesForward`
  * (R2D/src/extension_interface.cu:19-152, pybind name `rasterize_triangles`, R2D/ext.cpp:6) calls, and
@@ -134,6 +136,10 @@ size_t ts2d_geometry_state_bytes(int32_t P);
 size_t ts2d_binning_state_bytes(int64_t num_rendered, int32_t width, int32_t height);
 size_t ts2d_image_state_bytes(int32_t width, int32_t height);
 size_t ts2d_backward_scratch_bytes(int32_t P);
+/* The instance capacity of a binning buffer of `bytes` bytes (the largest N with ts2d_binning_state_bytes(N, W, H) <= bytes).  The library
+ * ALWAYS lays the binning state out for this capacity, so ts2d_backward finds the layout of the forward that filled the buffer from the
+ * buffer's size alone: a buffer may be larger than the count needs (speculative and sync-free forwards), never smaller. */
+int64_t ts2d_binning_capacity(size_t bytes, int32_t width, int32_t height);
 
 /* Per-triangle preprocess, depth order and prefix sum.  Writes radii[P] and the geometry state and returns num_rendered (the
  * reference's blocking cudaMemcpy, rasterizer.cu:191).  The count is summed right after the per-triangle kernel and handed to the
@@ -161,6 +167,19 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
  * after the optimizer has been queued) and re-run with a larger capacity.  Everything else as ts2d_forward_bin + ts2d_forward_render. */
 int ts2d_forward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state,
                  int64_t instance_capacity, const ts2d_forward_out *out, void *stream);
+/* Speculative forward: the reference's interface (num_rendered comes back to the host, R2D/src/rasterizer.cu:189-191) without its stall.
+ * Everything -- preprocess, depth order, count, emission, tile sort, ranges, blend -- is enqueued for the CAPACITY of the binning buffer the
+ * caller guessed (ts2d_binning_capacity of state->binning_bytes; ts2d_instance_capacity_hint proposes one), and only then does the host
+ * wait for the instance count, which the GPU publishes ~0.1 ms into the forward through a pinned word: the GPU never idles for the host's
+ * round trip, the host is back while the blend kernel still runs, and *num_rendered is exact.  If *num_rendered exceeds the capacity the
+ * speculative launches emitted nothing (the image is the background): the caller allocates ts2d_binning_state_bytes(*num_rendered, W, H)
+ * and calls ts2d_forward_render(*num_rendered) -- the per-triangle half is done and valid.  state->binning may be NULL / 0 bytes: then only
+ * that half runs (== ts2d_forward_bin).  ts2d_backward takes the exact *num_rendered. */
+int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state,
+                             const ts2d_forward_out *out, int64_t *num_rendered, void *stream);
+/* A capacity for the next forward of P triangles at this image size on the current device: 1.25 x the recent maximum of instances per
+ * triangle that forwards of the same variant (flags & TS2D_FLAG_3D) and size returned here, or 0 when there is no history yet. */
+int64_t ts2d_instance_capacity_hint(int32_t P, int32_t width, int32_t height, uint32_t flags);
 /* overflowed = 1 when the last ts2d_forward on this state exceeded its capacity; num_rendered = the true instance count. */
 int ts2d_forward_status(const ts2d_state *state, int32_t P, int32_t width, int32_t height, int32_t *overflowed, int64_t *num_rendered,
                         void *stream);
@@ -173,26 +192,6 @@ int ts2d_forward_status(const ts2d_state *state, int32_t P, int32_t width, int32
  * vertex: P*9, campos: num_views*3, dL_dcolor: num_views*P*3, dL_dshs: P*M*3 (fully written).  Asynchronous. */
 int ts2d_sh_grad_expand(int32_t P, int32_t sh_degree, int32_t M, int32_t num_views, const float *vertex, const float *campos,
                         const float *dL_dcolor, float *dL_dshs, void *stream);
-
-/* Test/diagnostic access to the private state: copies field `field` into host memory `dst`
- * (dst_bytes must be large enough), synchronising `stream`.  Fields:
- *   0 screen verts (P*6 f32: v1.xy v2.xy v3.xy)   1 area2 (P f32)       2 normal_view (P*3 f32)
- *   3 v_depth (P*3 f32)   4 depth key (P f32)      5 rgb (P*3 f32)       6 clamped (P u8, bits 0..2)
- *   7 instance offsets in depth order (P u32)  8 tiles_touched (P u32)  9 rect (P*4 u32: minx miny maxx maxy)
- *   10 sorted keys (N u64)   11 sorted triangle ids (N u32)   12 ranges (T*2 u32)
- *   13 n_contrib (H*W u32)   14 final_T (H*W f32)   15 / 16 the ping-pong partner of the sorted instance list (N u32 each)
- *   17 triangle ids in (depth, id) order (P u32)   18 raw render records (P*16 f32; with TS2D_FLAG_3D: v1_view v2_view
- *   v3_view normal_view opacity rgb -- fields 0-3 and 5 decode the 2D record layout only) */
-int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t num_rendered, int32_t width, int32_t height,
-                          int32_t field, void *dst, size_t dst_bytes, void *stream);
-
-/* Test hooks for the binning primitives that replace cub::DeviceRadixSort::SortPairs / cub::DeviceScan::InclusiveSum
- * (R2D/src/rasterizer.cu:210-218, 186): the hand-written stable LSD radix sort of (key, value) pairs on bits [0, end_bit)
- * (which = 0; csrc/binning.hip -- which = 2: with the hierarchical passes that sorts of more than 48 slabs take) and AMD's rocPRIM on the
- * same arrays (which = 1; comparator only, never on the product path).  Device pointers, n pairs, synchronous. */
-int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
-                         int32_t end_bit, int32_t which, void *stream);
-int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream);
 
 /* Timing hook used by bench.py: when enabled, ts2d_forward_render / ts2d_backward bracket each kernel
  * with HIP events on `stream`; ts2d_profile_read copies out (name, total_ms, launches) rows. */

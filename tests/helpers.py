@@ -2,6 +2,8 @@
 (via the drop-in Python package, i.e. through the C ABI), and compare."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 import synthetic
@@ -91,11 +93,74 @@ def hip_forward_backward(s, rich_info=True, back_culling=False, use_feature=Fals
     return res
 
 
+# ---- private-state reader: tools/bin/libts2d_lab.so (csrc/ts2d_lab.h) ---------------------------------------------------------
+# The product library exports no diagnostics.  The lab library contains the product's objects (same layout code), so its reader
+# decodes the state buffers of a forward that the PRODUCT library ran in this process.
+LAB_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libts2d_lab.so")
+_lab = None
+
+
+def lab_library():
+    global _lab
+    if _lab is None:
+        import ctypes as C
+        if not os.path.exists(LAB_LIB):
+            raise RuntimeError(f"{LAB_LIB} not found: build it with `python triangle-splatting_amd/build.py --lab`")
+        L = C.CDLL(LAB_LIB)
+        L.ts2d_last_error.restype = C.c_char_p
+        L.ts2d_debug_read_state.restype = C.c_int
+        L.ts2d_debug_read_state.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ts2d_test_sort_pairs.restype = C.c_int
+        L.ts2d_test_sort_pairs.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_int32, C.c_int32, C.c_void_p]
+        L.ts2d_test_inclusive_scan_rocprim.restype = C.c_int
+        L.ts2d_test_inclusive_scan_rocprim.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.ts2d_lab_force_ticket_passes.argtypes = [C.c_int]
+        _lab = L
+    return _lab
+
+
+def _field_spec():
+    import torch
+    return {
+        "v_2D": (0, torch.float32, lambda P, N, T, HW: (P, 6)), "area2": (1, torch.float32, lambda P, N, T, HW: (P,)),
+        "normal_view": (2, torch.float32, lambda P, N, T, HW: (P, 3)), "v_depth": (3, torch.float32, lambda P, N, T, HW: (P, 3)),
+        "depth": (4, torch.float32, lambda P, N, T, HW: (P,)), "rgb": (5, torch.float32, lambda P, N, T, HW: (P, 3)),
+        "clamped": (6, torch.uint8, lambda P, N, T, HW: (P,)), "point_offsets": (7, torch.int32, lambda P, N, T, HW: (P,)),
+        "tiles_touched": (8, torch.int32, lambda P, N, T, HW: (P,)), "rect": (9, torch.int32, lambda P, N, T, HW: (P, 4)),
+        "keys": (10, torch.int64, lambda P, N, T, HW: (N,)), "vals": (11, torch.int32, lambda P, N, T, HW: (N,)),
+        "ranges": (12, torch.int32, lambda P, N, T, HW: (T, 2)), "n_contrib": (13, torch.int32, lambda P, N, T, HW: HW),
+        "final_T": (14, torch.float32, lambda P, N, T, HW: HW), "tile_unsorted": (15, torch.int32, lambda P, N, T, HW: (N,)),
+        "vals_unsorted": (16, torch.int32, lambda P, N, T, HW: (N,)), "depth_perm": (17, torch.int32, lambda P, N, T, HW: (P,)),
+        "records": (18, torch.float32, lambda P, N, T, HW: (P, 16)),
+    }
+
+
+def debug_read_state(name, P, num_rendered, W, H, geometryBuffer, binningBuffer, imageBuffer):
+    """Copies one private state array to a CPU tensor (ts2d_debug_read_state of the lab library, csrc/ts2d_lab.h)."""
+    import ctypes as C
+    import torch
+    L = lab_library()
+    field, dtype, shape = _field_spec()[name]
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    out = torch.empty(shape(P, num_rendered, T, (H, W)), dtype=dtype)
+
+    class State(C.Structure):  # ts2d_state, include/ts2d.h
+        _fields_ = [("geometry", C.c_void_p), ("geometry_bytes", C.c_size_t), ("binning", C.c_void_p), ("binning_bytes", C.c_size_t),
+                    ("image", C.c_void_p), ("image_bytes", C.c_size_t)]
+    ptr = lambda t: t.data_ptr() if t.numel() else None
+    st = State(ptr(geometryBuffer), geometryBuffer.numel(), ptr(binningBuffer), binningBuffer.numel(), ptr(imageBuffer), imageBuffer.numel())
+    with torch.cuda.device(geometryBuffer.device):
+        rc = L.ts2d_debug_read_state(C.byref(st), P, num_rendered, W, H, field, out.data_ptr(), out.numel() * out.element_size(),
+                                     torch.cuda.current_stream().cuda_stream)
+    if rc != 0:
+        raise RuntimeError(f"debug_read_state: {L.ts2d_last_error().decode()} (ts2d error {rc})")
+    return out
+
+
 def hip_state(res, s, name):
-    from diff_triangle_rasterization_2D import _C
     g, b, im = res["buffers"]
     P = s["vertex"].shape[0]
-    return _C.debug_read_state(name, P, res["num_rendered"], s["image_width"], s["image_height"], g, b, im).numpy()
+    return debug_read_state(name, P, res["num_rendered"], s["image_width"], s["image_height"], g, b, im).numpy()
 
 
 def grazing_mask(of, cos_limit):

@@ -13,13 +13,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _lib():
-    from diff_triangle_rasterization_2D import _C
-    L = _C._lib
-    L.ts2d_test_sort_pairs.restype = C.c_int
-    L.ts2d_test_sort_pairs.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_int32, C.c_int32, C.c_void_p]
-    L.ts2d_test_inclusive_scan_rocprim.restype = C.c_int
-    L.ts2d_test_inclusive_scan_rocprim.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
-    return L
+    return helpers.lab_library()  # the sort / scan hooks and the rocPRIM comparators live in tools/bin/libts2d_lab.so (csrc/ts2d_lab.h)
 
 
 def _sort(keys, vals, end_bit, which):

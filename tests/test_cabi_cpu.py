@@ -29,7 +29,7 @@ def test_header_declares_the_expected_entry_points():
     names = _declared_functions()
     for must in ("ts2d_forward_bin", "ts2d_forward_render", "ts2d_backward", "ts2d_geometry_state_bytes",
                  "ts2d_binning_state_bytes", "ts2d_image_state_bytes", "ts2d_backward_scratch_bytes", "ts2d_last_error",
-                 "ts2d_version", "ts2d_debug_read_state", "ts2d_sh_grad_expand", "tsl_workspace_bytes",
+                 "ts2d_version", "ts2d_forward_speculative", "ts2d_binning_capacity", "ts2d_instance_capacity_hint", "ts2d_sh_grad_expand", "tsl_workspace_bytes",
                  "tsl_photometric_forward", "tsl_photometric_backward", "tsk_workspace_bytes", "tsk_mean_dist3",
                  "tsk_nearest_other", "tsm_training_statistic"):
         assert must in names
@@ -47,10 +47,42 @@ def test_product_library_reads_no_environment_and_has_one_blend_path(hip_lib_bui
     blob = open(hip_lib_built, "rb").read()
     for name in (b"TS2D_BLEND", b"TS2D_BWD", b"TS2D_ABLATE"):
         assert name not in blob, name
-    syms = subprocess.run(["nm", "-D", "--defined-only", hip_lib_built], capture_output=True, text=True).stdout
+    syms = subprocess.run(["nm", "--defined-only", hip_lib_built], capture_output=True, text=True).stdout  # static table: the launchers are not exported
     launchers = sorted(set(re.findall(r"ts_launch_render\w*?(?=RK)", syms)))
     assert launchers, "nm found no blend launchers"
     assert all("group" in n for n in launchers), launchers
+
+
+def test_product_library_exports_only_the_declared_c_abi(hip_lib_built):
+    """libts2d.so is built with -fvisibility=hidden: its dynamic symbol table holds the entry points that include/*.h declares and nothing
+    else of ours -- no internal ts_* C++ symbol, no test hook (ts2d_test_*, ts2d_debug_*, ts2d_lab_*: csrc/ts2d_lab.h, lab library only),
+    no rocPRIM."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", hip_lib_built], capture_output=True, text=True).stdout
+    exported = [l.split()[-1] for l in out.splitlines() if l.split()[-2:-1] and l.split()[-2] in ("T", "D", "B", "R")]
+    ours = [n for n in exported if not n.startswith("__hip_")]  # __hip_cuid_*: the toolchain's per-object markers
+    declared = set(_declared_functions())
+    assert set(ours) == declared, (sorted(set(ours) - declared), sorted(declared - set(ours)))
+    everything = subprocess.run(["nm", "-D", hip_lib_built], capture_output=True, text=True).stdout
+    assert "rocprim" not in everything.lower()
+    assert not re.search(r"ts2d_(test|debug|lab)_", everything)
+
+
+def test_binning_capacity_inverts_the_size_query(lib):
+    """The layout of a binning buffer follows from its size: capacity(bytes(N)) >= N, bytes(capacity(b)) <= b, monotone."""
+    lib.ts2d_binning_state_bytes.restype = ctypes.c_size_t
+    lib.ts2d_binning_state_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+    lib.ts2d_binning_capacity.restype = ctypes.c_int64
+    lib.ts2d_binning_capacity.argtypes = [ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32]
+    last = -1
+    for n in (0, 1, 63, 4096, 4097, 262_145, 4_610_735, 50_000_000):
+        b = lib.ts2d_binning_state_bytes(n, 1920, 1080)
+        c = lib.ts2d_binning_capacity(b, 1920, 1080)
+        assert c >= n and lib.ts2d_binning_state_bytes(c, 1920, 1080) <= b
+        assert lib.ts2d_binning_state_bytes(c + 1, 1920, 1080) > b  # the LARGEST count that fits
+        assert c >= last
+        last = c
+    assert lib.ts2d_binning_capacity(0, 1920, 1080) == 0 and lib.ts2d_binning_capacity(100, 64, 64) == 0
 
 
 def test_state_size_queries_are_monotone_and_aligned(lib):

@@ -193,19 +193,19 @@ def test_full_size_properties(P, W, H, D, variant):
     N = node.num_rendered
     g, b, im = node.saved_tensors[5:8]
     from diff_triangle_rasterization_2D import _C
-    keys = _C.debug_read_state("keys", P, N, W, H, g, b, im).numpy()
+    keys = helpers.debug_read_state("keys", P, N, W, H, g, b, im).numpy()
     assert np.all(np.diff(keys) >= 0)                       # sorted by (tile, depth)
-    ranges = _C.debug_read_state("ranges", P, N, W, H, g, b, im).numpy().astype(np.int64)
+    ranges = helpers.debug_read_state("ranges", P, N, W, H, g, b, im).numpy().astype(np.int64)
     tiles = keys >> 32
     counts = np.bincount(tiles, minlength=ranges.shape[0])
     assert np.array_equal(ranges[:, 1] - ranges[:, 0], counts)
     assert int(counts.sum()) == N
-    tt = _C.debug_read_state("tiles_touched", P, N, W, H, g, b, im).numpy().astype(np.int64)
+    tt = helpers.debug_read_state("tiles_touched", P, N, W, H, g, b, im).numpy().astype(np.int64)
     assert int(tt.sum()) == N
     # unit "colour" via the feature path: out = sum_i contrib_i, and final_T = prod(1 - alpha_i) => out + T == 1
     ones = torch.ones((P, 3), device="cuda")
     out1 = TriangleRasterizer(rs)(vertex.detach(), c2d.detach(), opacity.detach(), feature=ones)
-    final_T = _C.debug_read_state("final_T", P, N, W, H, g, b, im)  # same geometry/opacity => same transmittance
+    final_T = helpers.debug_read_state("final_T", P, N, W, H, g, b, im)  # same geometry/opacity => same transmittance
     resid = (out1[0][0].cpu() + final_T - 1.0).abs().max()
     assert float(resid) < 2e-4
     # linearity of the backward in the upstream gradient
@@ -241,6 +241,27 @@ def test_lab_library_variants_match(env):
     for case in res:
         for k, v in case.items():
             assert v < (grad_tol if k.startswith("dL_") else IMG_TOL), (env, k, v)
+
+
+def test_forced_ticket_passes_match_oracle():
+    """The hierarchical (ticket) radix passes, the elected-block scan and the ticket-path depth census -- which otherwise only scenes of
+    more than ~6 M triangles / 12.6 M instances reach, and which produce num_rendered there -- forced on a small scene through the lab
+    library's switch (csrc/ts2d_lab.h: ts2d_lab_force_ticket_passes), once with a constant top key byte of the depths and once with
+    a varying one: num_rendered, radii, sorted keys and ids bit-exact against the oracle, images and gradients within the bars."""
+    import json
+    import subprocess
+    import sys
+    if not os.path.exists(LAB_LIB):
+        pytest.skip("tools/bin/libts2d_lab.so not built")
+    e = dict(os.environ, TS2D_LIBRARY_PATH=LAB_LIB, LAB_FORCE_TICKETS="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab_worker.py")], env=e, capture_output=True,
+                       text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("LAB_RESULT ")][-1][len("LAB_RESULT "):])
+    assert len(res) == 2
+    for case in res:
+        for k, v in case.items():
+            assert v < (1.0 if k.startswith("int_") else GRAD_TOL if k.startswith("dL_") else IMG_TOL), (k, v)
 
 
 @pytest.mark.parametrize("P,W,H,D,variant", [

@@ -5,7 +5,7 @@ for i in 1 2; do
   for L in "" "$OTHER"; do
     TS2D_LIBRARY_PATH=$L timeout 200 python $R/bench.py --no-cpu-baseline "$@" 2>/dev/null | python -c "
 import json,sys
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=j['kernels_avg_ms_warmup']
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=j['kernels_avg_ms']
 print('${L:-product}'.split('/')[-1], j['ms_per_step'], ' '.join(f'{a}={b:.4f}' for a,b in k.items()))"
   done
 done

@@ -83,13 +83,22 @@ rasterizeTrianglesForward(const int image_width, const int image_height, const f
                                (debug ? TS2D_FLAG_DEBUG : 0u) | (s.use_shs ? TS2D_FLAG_USE_SHS : 0u);
         geometryBuffer = torch::empty({(int64_t)ts2d_geometry_state_bytes(P)}, u8);
         imageBuffer = torch::empty({(int64_t)ts2d_image_state_bytes(W, H)}, u8);
-        ts2d_state st{geometryBuffer.data_ptr(), (size_t)geometryBuffer.numel(), nullptr, 0, imageBuffer.data_ptr(), (size_t)imageBuffer.numel()};
-        check(ts2d_forward_bin(&cam, &geom, flags, radii.data_ptr<int>(), &st, &num_rendered, stream), "rasterize_triangles"); // rasterizer.cu:116-193
-        binningBuffer = torch::empty({(int64_t)ts2d_binning_state_bytes(num_rendered, W, H)}, u8);                           // rasterizer.cu:195
-        st.binning = binningBuffer.data_ptr();
-        st.binning_bytes = (size_t)binningBuffer.numel();
+        // Rasterizer::forward (rasterizer.cu:101-267) with its num_rendered read-back off the GPU's critical path: the binning buffer is sized
+        // from what recent forwards rendered, everything is queued for that capacity, then the host waits for the exact count only
+        const int64_t guess = ts2d_instance_capacity_hint(P, W, H, flags);
+        if (guess > 0) binningBuffer = torch::empty({(int64_t)ts2d_binning_state_bytes(guess, W, H)}, u8);
+        ts2d_state st{geometryBuffer.data_ptr(), (size_t)geometryBuffer.numel(), guess > 0 ? binningBuffer.data_ptr() : nullptr,
+                      (size_t)binningBuffer.numel(), imageBuffer.data_ptr(), (size_t)imageBuffer.numel()};
         ts2d_forward_out out{fptr_mut(out_feature), fptr_mut(depth), fptr_mut(normal), fptr_mut(contrib_sum), fptr_mut(contrib_max)};
-        check(ts2d_forward_render(&cam, &geom, flags, num_rendered, &st, &out, stream), "rasterize_triangles"); // rasterizer.cu:199-266
+        check(ts2d_forward_speculative(&cam, &geom, flags, radii.data_ptr<int>(), &st, &out, &num_rendered, stream), "rasterize_triangles");
+        if (guess <= 0 || num_rendered > ts2d_binning_capacity(st.binning_bytes, W, H))
+        {
+            // no history yet, or the guess was too small (nothing was emitted): the second half with the exact size (rasterizer.cu:195-266)
+            binningBuffer = torch::empty({(int64_t)ts2d_binning_state_bytes(num_rendered, W, H)}, u8);
+            st.binning = binningBuffer.data_ptr();
+            st.binning_bytes = (size_t)binningBuffer.numel();
+            check(ts2d_forward_render(&cam, &geom, flags, num_rendered, &st, &out, stream), "rasterize_triangles");
+        }
     }
     return std::make_tuple((int)num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max, geometryBuffer, binningBuffer, imageBuffer);
 }

@@ -28,7 +28,7 @@ LIB = os.path.join(OUT_DIR, "libts2d.so")
 ARCH = "gfx950"
 
 COMMON = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-munsafe-fp-atomics", "-Wall", "-Wno-unused-function",
-          "-Wno-unused-result", "-DNDEBUG"]
+          "-Wno-unused-result", "-DNDEBUG", "-fvisibility=hidden"]  # exports = what include/*.h declares (api.hip), nothing else
 COMMON += os.environ.get("TS2D_EXTRA_FLAGS", "").split()  # profiling builds: -DTS2D_ABLATION, -DTS2D_STATS (use --force)
 SOURCES = {
     "preprocess.hip": ["-ffp-contract=off"],
@@ -47,10 +47,11 @@ LAB_SOURCES = {  # measurement kernels: libts2d_lab.so only
     "render.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render3d.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render_q8.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
+    "lab_hooks.hip": [],  # sort / scan test hooks + their rocPRIM comparators (csrc/ts2d_lab.h)
     "api.hip": ["-DTS2D_LAB"],
 }
 LAB_LIB = os.path.join(os.path.dirname(HERE), "tools", "bin", "libts2d_lab.so")
-HEADERS = ["ts2d_common.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
+HEADERS = ["ts2d_common.h", "ts2d_lab.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
            os.path.join("..", "..", "include", "ts_knn.h"),
            os.path.join("..", "..", "include", "ts_model.h")]

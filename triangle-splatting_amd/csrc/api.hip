@@ -5,10 +5,16 @@
 // Differences by design: everything is enqueued on the caller's stream (the reference uses the legacy default
 // stream), the only host synchronisation is the num_rendered read-back, outputs need no pre-zeroing, and the
 // zero-filled scratch of the backward is one 64-byte-per-triangle gradient record array.
+// The library is built with -fvisibility=hidden: only what include/*.h declares (and, in the lab build, csrc/ts2d_lab.h) is exported.
+#pragma GCC visibility push(default)
 #include "../../include/ts2d.h"
 #include "../../include/ts_loss.h"
 #include "../../include/ts_knn.h"
 #include "../../include/ts_model.h"
+#ifdef TS2D_LAB
+#include "ts2d_lab.h"
+#endif
+#pragma GCC visibility pop
 #include "ts2d_common.h"
 #include <atomic>
 
@@ -176,7 +182,7 @@ bool acquire_early_count(EarlyCount &e)
     constexpr int SLOTS = 64, MAXDEV = 16; // calls that may be between their launch and their wait at the same time, per device
     static unsigned long long *ring = [] {
         void *p = nullptr; // pinned and mapped into every device's address space
-        return hipHostMalloc(&p, (size_t)MAXDEV * SLOTS * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped) == hipSuccess
+        return hipHostMalloc(&p, (size_t)MAXDEV * SLOTS * sizeof(unsigned long long), hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess
                    ? (unsigned long long *)p : nullptr;
     }();
     static hipEvent_t events[MAXDEV][SLOTS] = {}; // an event belongs to the device it was created on
@@ -193,6 +199,71 @@ bool acquire_early_count(EarlyCount &e)
     e.ev = events[dev][i];
     __atomic_store_n(e.host, ~0ull, __ATOMIC_RELEASE); // "not there yet": the count is < 2^63, the publishing block overwrites this
     return true;
+}
+
+inline void cpu_relax()
+{
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#endif
+}
+
+// Waits for the instance count of ONE forward: the publishing block stores it (system scope, fine-grained pinned memory) a few microseconds
+// before its kernel retires.  The host watches the word itself for a bounded time (no runtime call between the store and this thread: this is
+// the case when the GPU is already past the publishing kernel, or about to be) and then sleeps on the event recorded behind that kernel -- it
+// does not burn a core while the GPU works through a queue of earlier launches, and a faulted launch surfaces as an error.
+int wait_early_count(const EarlyCount &early, unsigned long long *n_out)
+{
+    unsigned long long n = ~0ull;
+    for (unsigned spin = 0; spin < 20000u; spin++) // ~20-60 us
+    {
+        n = __atomic_load_n(early.host, __ATOMIC_ACQUIRE);
+        if (n != ~0ull) break;
+        cpu_relax();
+    }
+    if (n == ~0ull)
+    {
+        const hipError_t q = hipEventSynchronize(early.ev);
+        if (q != hipSuccess) return fail(TS2D_ERR_HIP, "waiting for the instance count: %s", hipGetErrorString(q));
+        n = __atomic_load_n(early.host, __ATOMIC_ACQUIRE);
+        if (n == ~0ull) return fail(TS2D_ERR_HIP, "the instance count was not published");
+    }
+    *n_out = n;
+    return TS2D_OK;
+}
+
+// ---- capacity hints for the speculative forward ------------------------------------------------------------------------------------
+// What the last forwards of a given (device, variant, image size) rendered, per triangle: the next call's binning buffer is sized for 1.25 x
+// the recent maximum.  A wrong guess costs one cheap overflow (nothing is emitted) and the reference's sequence for that call, never a result.
+struct CapacityHint { int dev, variant, W, H; double per_triangle; unsigned long long stamp; };
+std::mutex g_hint_mu;
+std::vector<CapacityHint> g_hints;
+unsigned long long g_hint_clock = 0;
+
+void record_instance_count(int variant, int W, int H, int P, unsigned long long n)
+{
+    int dev = 0;
+    if (P <= 0 || hipGetDevice(&dev) != hipSuccess) return;
+    const double per = (double)n / (double)P;
+    std::lock_guard<std::mutex> lk(g_hint_mu);
+    CapacityHint *slot = nullptr;
+    for (auto &h : g_hints)
+        if (h.dev == dev && h.variant == variant && h.W == W && h.H == H) slot = &h;
+    if (!slot)
+    {
+        if (g_hints.size() < 32) { g_hints.push_back({dev, variant, W, H, 0.0, 0}); slot = &g_hints.back(); }
+        else // recycle the entry that was used longest ago
+        {
+            slot = &g_hints[0];
+            for (auto &h : g_hints)
+                if (h.stamp < slot->stamp) slot = &h;
+            *slot = {dev, variant, W, H, 0.0, 0};
+        }
+    }
+    slot->per_triangle = per > 0.97 * slot->per_triangle ? per : 0.97 * slot->per_triangle; // a decaying maximum over the recent views
+    slot->stamp = ++g_hint_clock;
 }
 } // namespace
 
@@ -217,6 +288,31 @@ size_t ts2d_image_state_bytes(int32_t W, int32_t H)
     return ts_carve_image(nullptr, W, H, v);
 }
 size_t ts2d_backward_scratch_bytes(int32_t P) { return (size_t)(P > 0 ? P : 0) * TS_GRAD_FLOATS * sizeof(float) + TS_ALIGN; }
+int64_t ts2d_binning_capacity(size_t bytes, int32_t W, int32_t H)
+{
+    const int64_t c = ts_binning_capacity(bytes, W, H);
+    return c < 0 ? 0 : c;
+}
+int64_t ts2d_instance_capacity_hint(int32_t P, int32_t W, int32_t H, uint32_t flags)
+{
+    int dev = 0;
+    if (P <= 0 || hipGetDevice(&dev) != hipSuccess) return 0;
+    const int variant = (flags & TS2D_FLAG_3D) ? 3 : 2;
+    std::lock_guard<std::mutex> lk(g_hint_mu);
+    for (auto &h : g_hints)
+        if (h.dev == dev && h.variant == variant && h.W == W && h.H == H)
+        {
+            h.stamp = ++g_hint_clock;
+            const double want = 1.25 * h.per_triangle * (double)P + 4096.0;
+            if (want >= 2147483647.0) return 0x7fffffffll;
+            // eight sizes per octave: views whose counts differ by a few per cent ask the caller's allocator for the SAME block
+            int64_t w = (int64_t)want, step = 1;
+            while ((step << 4) <= w) step <<= 1;
+            w = (w + step - 1) / step * step;
+            return w > 0x7fffffffll ? 0x7fffffffll : w;
+        }
+    return 0;
+}
 
 int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii,
                      const ts2d_state *state, int64_t *num_rendered, void *stream)
@@ -239,26 +335,7 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     unsigned long long n = 0;
     if (have_early)
     {
-        // The host watches the pinned word itself: the publishing block stores it (system scope) a few microseconds before its kernel
-        // retires and the event behind it fires, and no runtime call sits between the store and this thread.  The event is only asked
-        // now and then, so that a faulted launch surfaces as an error instead of an endless wait.
-        for (unsigned spin = 1;; spin++)
-        {
-            n = __atomic_load_n(early.host, __ATOMIC_ACQUIRE);
-            if (n != ~0ull) break;
-            if ((spin & 0x3FFFu) == 0)
-            {
-                const hipError_t q = hipEventQuery(early.ev);
-                if (q == hipSuccess)
-                {
-                    n = __atomic_load_n(early.host, __ATOMIC_ACQUIRE);
-                    break;
-                }
-                if (q != hipErrorNotReady) return fail(TS2D_ERR_HIP, "waiting for the instance count: %s", hipGetErrorString(q));
-            }
-            __builtin_ia32_pause();
-        }
-        if (n == ~0ull) return fail(TS2D_ERR_HIP, "the instance count was not published");
+        if (int rc = wait_early_count(early, &n)) return rc;
     }
     else
     {
@@ -270,6 +347,7 @@ int ts2d_forward_bin(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     if (n > 0x7fffffffull) // the reference's int num_rendered wraps here; instance slots are 32-bit
         return fail(TS2D_ERR_CAPACITY, "%llu tile instances exceed the 2^31 - 1 the instance list can address", n);
     *num_rendered = (int64_t)n;
+    record_instance_count((flags & TS2D_FLAG_3D) ? 3 : 2, cam->width, cam->height, P, n);
     return TS2D_OK;
 }
 
@@ -288,7 +366,12 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     BinningStateView b{};
     ImageStateView im{};
     if (P > 0) ts_carve_geometry((char *)state->geometry, P, g);
-    if (N > 0) ts_carve_binning((char *)state->binning, N, W, H, b);
+    if (N > 0)
+    {
+        // the layout follows from the buffer's size (ts_binning_capacity): the backward finds it again without being told the capacity
+        ts_carve_binning((char *)state->binning, ts_binning_capacity(state->binning_bytes, W, H), W, H, b);
+        if (!n_dev) ts_binning_set_count(b, N); // the host knows the count: no launch covers more than it
+    }
     ts_carve_image((char *)state->image, W, H, im);
     const RenderArgs r = make_render(cam, geom, flags);
     const int ntiles = r.grid_x * r.grid_y;
@@ -352,7 +435,7 @@ int check_forward_args(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     if (N < 0) return fail(TS2D_ERR_INVALID, "num_rendered < 0");
     if (N > 0x7fffffffll) return fail(TS2D_ERR_CAPACITY, "the instance list addresses at most 2^31 - 1 instances");
     if (!state->image || state->image_bytes < ts2d_image_state_bytes(W, H)) return fail(TS2D_ERR_CAPACITY, "image state buffer too small");
-    if (N > 0 && (!state->binning || state->binning_bytes < ts2d_binning_state_bytes(N, W, H)))
+    if (N > 0 && (!state->binning || ts_binning_capacity(state->binning_bytes, W, H) < N))
         return fail(TS2D_ERR_CAPACITY, "binning state buffer too small");
     if (P > 0 && (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P)))
         return fail(TS2D_ERR_CAPACITY, "geometry state buffer too small");
@@ -416,6 +499,36 @@ int ts2d_forward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fla
     return forward_render_impl(cam, geom, flags, instance_capacity, &on_device, state, out, s);
 }
 
+int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state,
+                             const ts2d_forward_out *out, int64_t *num_rendered, void *stream)
+{
+    if (!num_rendered) return fail(TS2D_ERR_INVALID, "null num_rendered");
+    *num_rendered = 0;
+    if (int rc = check_forward_args(cam, geom, flags, 0, state, out)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int P = geom->P, W = cam->width, H = cam->height;
+    if (P == 0) return forward_render_impl(cam, geom, flags, 0, nullptr, state, out, s); // extension_interface.cu:130: background only
+    if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
+    int64_t cap = state->binning ? ts_binning_capacity(state->binning_bytes, W, H) : 0;
+    if (cap < 0) cap = 0;
+    EarlyCount early;
+    if (!acquire_early_count(early)) return fail(TS2D_ERR_HIP, "no pinned word for the instance count");
+    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, &early)) return rc;
+    if (cap > 0)
+    {
+        // everything behind the count is queued for the CAPACITY before the host has seen the count: the GPU never waits for the host
+        static const unsigned long long on_device = 0; // any non-null marker: forward_render_impl resolves the real address
+        if (int rc = forward_render_impl(cam, geom, flags, cap, &on_device, state, out, s)) return rc;
+    }
+    unsigned long long n = 0;
+    if (int rc = wait_early_count(early, &n)) return rc;
+    if (n > 0x7fffffffull) // the reference's int num_rendered wraps here; instance slots are 32-bit
+        return fail(TS2D_ERR_CAPACITY, "%llu tile instances exceed the 2^31 - 1 the instance list can address", n);
+    *num_rendered = (int64_t)n;
+    record_instance_count((flags & TS2D_FLAG_3D) ? 3 : 2, W, H, P, n);
+    return TS2D_OK;
+}
+
 int ts2d_forward_status(const ts2d_state *state, int32_t P, int32_t width, int32_t height, int32_t *overflowed, int64_t *num_rendered,
                         void *stream)
 {
@@ -456,13 +569,13 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     if (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P)) return fail(TS2D_ERR_CAPACITY, "backward scratch too small");
     if (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P) || !state->image ||
         state->image_bytes < ts2d_image_state_bytes(W, H) ||
-        (N > 0 && (!state->binning || state->binning_bytes < ts2d_binning_state_bytes(N, W, H))))
+        (N > 0 && (!state->binning || ts_binning_capacity(state->binning_bytes, W, H) < N)))
         return fail(TS2D_ERR_CAPACITY, "state buffers too small");
     GeometryStateView g{};
     BinningStateView b{};
     ImageStateView im{};
     ts_carve_geometry((char *)state->geometry, P, g);
-    if (N > 0) ts_carve_binning((char *)state->binning, N, W, H, b);
+    if (N > 0) ts_carve_binning((char *)state->binning, ts_binning_capacity(state->binning_bytes, W, H), W, H, b); // as the forward carved it
     ts_carve_image((char *)state->image, W, H, im);
     const RenderArgs r = make_render(cam, geom, flags);
     float *grad_rec = (float *)ts_align_up((size_t)scratch);
@@ -720,6 +833,7 @@ int tsm_opacity_reset(int32_t P, float reset_value, float *opacity, float *exp_a
     return TS2D_OK;
 }
 
+#ifdef TS2D_LAB // csrc/ts2d_lab.h: diagnostics and comparators that only tools/bin/libts2d_lab.so carries
 int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t W, int32_t H, int32_t field, void *dst,
                           size_t dst_bytes, void *stream)
 {
@@ -729,7 +843,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
     BinningStateView b{};
     ImageStateView im{};
     if (P > 0 && state->geometry) ts_carve_geometry((char *)state->geometry, P, g);
-    if (N > 0 && state->binning) ts_carve_binning((char *)state->binning, N, W, H, b);
+    if (N > 0 && state->binning) ts_carve_binning((char *)state->binning, ts_binning_capacity(state->binning_bytes, W, H), W, H, b);
     if (state->image) ts_carve_image((char *)state->image, W, H, im);
     const int gx = (W + TS_TILE - 1) / TS_TILE, gy = (H + TS_TILE - 1) / TS_TILE;
     const void *src = nullptr;
@@ -828,21 +942,9 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
     return TS2D_OK;
 }
 
-// Test hooks: the hand-written stable radix sort (which = 0; which = 2: its hierarchical passes forced, the ones large sorts take) and
-// AMD's rocPRIM (which = 1, the comparator) on device arrays.
-int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int32_t end_bit,
-                         int32_t which, void *stream)
-{
-    if (end_bit < 1 || end_bit > 32) return fail(TS2D_ERR_INVALID, "end_bit must be in 1..32");
-    if (n && (!keys_in || !vals_in || !keys_out || !vals_out)) return fail(TS2D_ERR_INVALID, "null pointer");
-    const int rc = which == 1 ? ts_compare_sort_pairs_rocprim(keys_in, vals_in, keys_out, vals_out, n, end_bit, (hipStream_t)stream)
-                              : ts_test_sort_pairs(keys_in, vals_in, keys_out, vals_out, n, end_bit, which == 2, (hipStream_t)stream);
-    return rc ? fail(TS2D_ERR_HIP, "sort_pairs test hook failed") : TS2D_OK;
-}
-int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream)
-{
-    return ts_compare_inclusive_scan_rocprim(in, out, n, (hipStream_t)stream) ? fail(TS2D_ERR_HIP, "scan comparator failed") : TS2D_OK;
-}
+// ts2d_test_sort_pairs / ts2d_test_inclusive_scan_rocprim: csrc/lab_hooks.hip (the rocPRIM comparators live there, outside the product's objects)
+void ts2d_lab_force_ticket_passes(int on) { ts_force_ticket_passes(on != 0); }
+#endif // TS2D_LAB
 
 void ts2d_profile_enable(int on)
 {

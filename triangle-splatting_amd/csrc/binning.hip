@@ -34,8 +34,6 @@
 // tests/test_binning_gpu.py.
 #include "ts2d_common.h"
 #include "ts2d_wave.h"
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
 
 namespace
 {
@@ -632,7 +630,11 @@ void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32
 // The ticket-free pass: the histogram adds into slabacc[which] (cleared by whoever ran before), the scatter reads it and clears the other
 // buffer for the pass after this one.  Every block reads the totals of all slabs, so sorts of more than TS_DIRECT_MAX_SLABS slabs (12.6 M
 // pairs at 4096 per chunk) keep the hierarchical pass, whose cost does not grow with the slab count.
-bool radix_direct_ok(const RadixScratchView &r) { return r.slabs <= TS_DIRECT_MAX_SLABS; }
+// g_force_tickets: a lab-library switch (csrc/ts2d_lab.h, ts2d_lab_force_ticket_passes; the symbol is not exported and nothing in the product
+// library sets it): every sort and the scan take the hierarchical passes that otherwise only scenes of more than ~6 M triangles reach, so that
+// the suite executes them -- including the ticket-path census that produces num_rendered there.
+bool g_force_tickets = false;
+bool radix_direct_ok(const RadixScratchView &r) { return !g_force_tickets && r.slabs <= TS_DIRECT_MAX_SLABS; }
 void radix_pass_direct(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
                        int nbits, const RadixScratchView &r, int which, hipStream_t s, const uint32_t *skip_flag = nullptr)
 {
@@ -767,6 +769,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         if (i == 0 && status) *status = over ? 1 : 0;
         if (over) tiles = 0u;
     }
+    else if (i == 0 && status) *status = 0; // the host knows the count (the reference's sequence, or the exact re-run after an overflow)
     // inclusive prefix inside the block (wave64 DPP scan + the three preceding waves' totals) on top of what lies in front of the block
     const uint32_t inc = wave_inclusive_scan(tiles, lane);
     for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
@@ -939,7 +942,7 @@ void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t 
 }
 
 // Every emission block adds up the raw block sums in front of it (up to 8 per thread); beyond that the elected-block prefix pays off again.
-static bool scan_direct_ok(int32_t P) { return (P + SB - 1) / SB <= 2048; }
+static bool scan_direct_ok(int32_t P) { return !g_force_tickets && (P + SB - 1) / SB <= 2048; }
 // Step 2: tiles_sorted = tiles_touched[perm], block sums (-> exclusive prefix on the ticket path), blocksum[nblocks] = N.
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
@@ -998,14 +1001,14 @@ size_t ts_radix_scratch_bytes(size_t n)
 }
 // Stable LSD sort of (key, value) pairs by key bits [0, end_bit).  k[0] / v[0] hold the input, k[1] / v[1] are the ping-pong partners;
 // returns which pair holds the result (passes & 1).
-int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s)
+int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s, bool force_tickets)
 {
     if (n == 0) return 0;
     RadixScratchView r{};
     char *p = (char *)ts_align_up((size_t)scratch);
     ts_carve_radix(p, n, r, generic_chunk(n));
     hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((r.slabs + TS_RS_TICKET_EXTRA + 255) / 256)), dim3(256), 0, s, r.tickets, r.slabs + TS_RS_TICKET_EXTRA);
-    const bool direct = radix_direct_ok(r);
+    const bool direct = !force_tickets && radix_direct_ok(r);
     if (direct) hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)r.slabs), dim3(256), 0, s, r.slabacc[0], r.slabs * NB);
     const int passes = (end_bit + 7) / 8;
     int src = 0;
@@ -1018,67 +1021,4 @@ int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, in
     return src;
 }
 
-// ---- rocPRIM comparators (tests/test_binning_gpu.py; never on the product path) --------------------------------------------------
-int ts_compare_sort_pairs_rocprim(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
-                                  int end_bit, hipStream_t s)
-{
-    size_t bytes = 0;
-    if (rocprim::radix_sort_pairs(nullptr, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s) != hipSuccess) return 2;
-    void *tmp = nullptr;
-    if (hipMalloc(&tmp, bytes ? bytes : 1) != hipSuccess) return 2;
-    hipError_t e = rocprim::radix_sort_pairs(tmp, bytes, keys_in, keys_out, vals_in, vals_out, n, 0u, (unsigned)end_bit, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
-    return e == hipSuccess ? 0 : 2;
-}
-
-int ts_compare_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s)
-{
-    size_t bytes = 0;
-    if (rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<uint32_t>(), s) != hipSuccess) return 2;
-    void *tmp = nullptr;
-    if (hipMalloc(&tmp, bytes ? bytes : 1) != hipSuccess) return 2;
-    hipError_t e = rocprim::inclusive_scan(tmp, bytes, in, out, n, rocprim::plus<uint32_t>(), s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(tmp);
-    return e == hipSuccess ? 0 : 2;
-}
-
-// Test hook (include/ts2d.h: ts2d_test_sort_pairs): the hand-written passes on caller-provided device arrays, scratch from hipMalloc.
-int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit,
-                       bool force_tickets, hipStream_t s)
-{
-    if (n == 0) return 0;
-    BinningStateView b{};
-    RadixScratchView r{};
-    char *p = nullptr;
-    ts_carve_radix(p, n, r, generic_chunk(n)); // <= 2.5 M pairs exercise the 2048-pair kernels, more the 4096-pair ones
-    const size_t scratch = (size_t)p + TS_ALIGN, bytes = scratch + 4 * (n * 4 + TS_ALIGN);
-    char *base = nullptr;
-    if (hipMalloc((void **)&base, bytes) != hipSuccess) return 2;
-    p = base;
-    ts_carve_radix(p, n, b.rs, generic_chunk(n));
-    for (int i = 0; i < 2; i++) { ts_carve(p, b.k[i], n); ts_carve(p, b.v[i], n); }
-    b.passes = (end_bit + 7) / 8;
-    hipError_t e = hipMemcpyAsync(b.k[0], keys_in, n * 4, hipMemcpyDeviceToDevice, s);
-    if (e == hipSuccess) e = hipMemcpyAsync(b.v[0], vals_in, n * 4, hipMemcpyDeviceToDevice, s);
-    if (e == hipSuccess)
-    {
-        hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((b.rs.slabs + TS_RS_TICKET_EXTRA + 255) / 256)), dim3(256), 0, s, b.rs.tickets, b.rs.slabs + TS_RS_TICKET_EXTRA);
-        const bool direct = !force_tickets && radix_direct_ok(b.rs);
-        if (direct) hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)b.rs.slabs), dim3(256), 0, s, b.rs.slabacc[0], b.rs.slabs * NB);
-        int src = 0;
-        for (int ps = 0; ps < b.passes; ps++)
-        {
-            if (direct) radix_pass_direct(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), b.rs, ps & 1, s);
-            else radix_pass(b.k[src], b.v[src], b.k[src ^ 1], b.v[src ^ 1], (int64_t)n, nullptr, 8 * ps, min(8, end_bit - 8 * ps), b.rs, s);
-            src ^= 1;
-        }
-        e = hipMemcpyAsync(keys_out, b.k[src], n * 4, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) e = hipMemcpyAsync(vals_out, b.v[src], n * 4, hipMemcpyDeviceToDevice, s);
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
-        if (e == hipSuccess) e = hipGetLastError();
-    }
-    (void)hipFree(base);
-    return e == hipSuccess ? 0 : 2;
-}
+void ts_force_ticket_passes(bool on) { g_force_tickets = on; }

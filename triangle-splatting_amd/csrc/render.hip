@@ -713,7 +713,7 @@ void ts_launch_render_bwd(const RenderArgs &a, const GeometryStateView &g, const
 }
 
 #ifdef TS2D_STATS
-extern "C" int ts2d_stats_read(unsigned long long *out, int reset)
+extern "C" __attribute__((visibility("default"))) int ts2d_stats_read(unsigned long long *out, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats), sizeof(unsigned long long) * 8);
     if (e == hipSuccess && reset)

@@ -695,7 +695,7 @@ void ts_launch_render_fwd_group(const RenderArgs &a, const GeometryStateView &g,
 }
 
 #ifdef TS2D_STATS
-extern "C" int ts2d_stats_read_group(unsigned long long *out, int reset)
+extern "C" __attribute__((visibility("default"))) int ts2d_stats_read_group(unsigned long long *out, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats_group), sizeof(unsigned long long) * 12);
     if (e == hipSuccess && reset)

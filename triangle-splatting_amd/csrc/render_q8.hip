@@ -874,7 +874,7 @@ void ts_launch_render_bwd_q8(const RenderArgs &a, const GeometryStateView &g, co
 }
 
 #ifdef TS2D_STATS
-extern "C" int ts2d_stats_read_q8(unsigned long long *out, int reset)
+extern "C" __attribute__((visibility("default"))) int ts2d_stats_read_q8(unsigned long long *out, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats_q8), sizeof(unsigned long long) * 12);
     if (e == hipSuccess && reset)

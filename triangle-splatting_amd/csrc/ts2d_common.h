@@ -37,7 +37,9 @@
 #endif
 #define TS_RS_CHUNK_SMALL 2048
 #define TS_RS_BINS 256
-#define TS_RS_TICKET_EXTRA 16 /* words behind the per-slab tickets: [slabs + 4] the depth sort's top_const flag, [(slabs + 9) & ~1 ...] its census accumulators */
+#define TS_RS_TICKET_EXTRA 8 /* words behind the per-slab tickets; [slabs + 4] = the depth sort's top_const flag.  (The census of the depth sort's
+                                first histogram needs no words here: its per-chunk sums / key-bit ORs / ANDs borrow g.blocksum, g.tiles_sorted and
+                                g.offsets, which the scan rewrites afterwards -- binning.hip, ts_sort_by_depth_begin.) */
 struct RadixScratchView
 {
     uint32_t *table;   // chunks x 256   count of digit d in chunk c, then (in place) its exclusive prefix inside the slab
@@ -160,6 +162,33 @@ static inline size_t ts_carve_binning(char *base, int64_t N, int32_t W, int32_t 
     return (size_t)(p - base) + TS_ALIGN;
 }
 
+// The capacity (in tile instances) of a binning buffer of `bytes` bytes: the largest N whose carving fits.  The binning state is ALWAYS carved
+// for this capacity, so the forward that filled a buffer and the backward that reads it agree on the layout from the buffer's size alone --
+// whatever instance count the one or the other was told (the exact count of the reference's sequence, or less than the capacity of a
+// speculative / sync-free forward).
+static inline int64_t ts_binning_capacity(size_t bytes, int32_t W, int32_t H)
+{
+    BinningStateView v;
+    if (bytes < ts_carve_binning(nullptr, 0, W, H, v)) return -1; // not even an empty state fits
+    int64_t lo = 0, hi = (int64_t)(bytes / 16) + 1;                // four u32 arrays per instance: bytes(N) >= 16 N
+    if (hi > 0x7fffffffll) hi = 0x7fffffffll;
+    while (lo < hi)
+    {
+        const int64_t mid = lo + (hi - lo + 1) / 2;
+        if (ts_carve_binning(nullptr, mid, W, H, v) <= bytes) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
+// Narrows the radix scratch of a binning state carved for a larger capacity to the `n` instances the host knows are there (pointers stay where the
+// capacity put them; every launch of the forward must see the same view).
+static inline void ts_binning_set_count(BinningStateView &v, int64_t n)
+{
+    v.rs.chunks = (int)((n + v.rs.chunk - 1) / v.rs.chunk);
+    v.rs.slabs = (v.rs.chunks + 63) / 64;
+}
+
 static inline size_t ts_carve_image(char *base, int32_t W, int32_t H, ImageStateView &v)
 {
     char *p = base;
@@ -193,13 +222,8 @@ const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int 
 void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s); // stable, tile bits only
 void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
 size_t ts_radix_scratch_bytes(size_t n);                                                          // the same sort for other callers (knn.hip)
-int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s);
-// rocPRIM comparators (tests only): same contracts as the hand-written steps, results into caller-provided device buffers
-int ts_compare_sort_pairs_rocprim(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
-                                  int end_bit, hipStream_t s);
-int ts_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n, int end_bit, bool force_tickets,
-                       hipStream_t s);
-int ts_compare_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s);
+int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s, bool force_tickets = false);
+void ts_force_ticket_passes(bool on); // lab library only (csrc/ts2d_lab.h): no exported entry point of the product library reaches it
 
 struct RenderArgs
 {
@@ -224,7 +248,7 @@ void ts_launch_render_fwd_group(const RenderArgs &a, const GeometryStateView &g,
 void ts_launch_render_bwd_group(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                                 const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
                                 const float *dL_dout_normal, float *grad_rec, hipStream_t s);
-// queue kernels (render_q8.hip): eight 4x2 pixel blocks per wave, each walking its own queue of triangles; the default
+// queue kernels (render_q8.hip; lab library only, selected with TS2D_BLEND=q8): eight 4x2 pixel blocks per wave, each walking its own queue of triangles
 void ts_launch_render_fwd_q8(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                              float *out_feature, float *out_depth, float *out_normal, float *contrib_sum, float *contrib_max, hipStream_t s);
 void ts_launch_render_bwd_q8(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,

@@ -1,0 +1,42 @@
+/*
+ * ts2d_lab.h -- entry points that exist ONLY in tools/bin/libts2d_lab.so (python triangle-splatting_amd/build.py --lab): diagnostics and
+ * comparators for tests/ and tools/.  The product library libts2d.so exports nothing of this (tests/test_cabi_cpu.py checks its export
+ * table against include/*.h) and links no rocPRIM.  The lab library contains the product's objects, so it reads the private state of a
+ * forward that the PRODUCT library ran in the same process (same layout code, device pointers are process-wide).
+ */
+#ifndef TS2D_LAB_H
+#define TS2D_LAB_H
+
+#include "../../include/ts2d.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Copies field `field` of the private state into host memory `dst` (dst_bytes must be large enough), synchronising `stream`.  Fields:
+ *   0 screen verts (P*6 f32: v1.xy v2.xy v3.xy)   1 area2 (P f32)       2 normal_view (P*3 f32)
+ *   3 v_depth (P*3 f32)   4 depth key (P f32)      5 rgb (P*3 f32)       6 clamped (P u8, bits 0..2)
+ *   7 instance offsets in depth order (P u32)  8 tiles_touched (P u32)  9 rect (P*4 u32: minx miny maxx maxy)
+ *   10 sorted keys (N u64)   11 sorted triangle ids (N u32)   12 ranges (T*2 u32)
+ *   13 n_contrib (H*W u32)   14 final_T (H*W f32)   15 / 16 the ping-pong partner of the sorted instance list (N u32 each)
+ *   17 triangle ids in (depth, id) order (P u32)   18 raw render records (P*16 f32; with TS2D_FLAG_3D: v1_view v2_view
+ *   v3_view normal_view opacity rgb -- fields 0-3 and 5 decode the 2D record layout only) */
+int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t num_rendered, int32_t width, int32_t height,
+                          int32_t field, void *dst, size_t dst_bytes, void *stream);
+
+/* The binning primitives that replace cub::DeviceRadixSort::SortPairs / cub::DeviceScan::InclusiveSum (R2D/src/rasterizer.cu:210-218, 186)
+ * on caller-provided device arrays: the hand-written stable LSD radix sort of (key, value) pairs on bits [0, end_bit) (which = 0;
+ * csrc/binning.hip -- which = 2: with the hierarchical passes that sorts of more than 48 slabs take) and AMD's rocPRIM on the same arrays
+ * (which = 1; the comparator).  n pairs, synchronous. */
+int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint32_t *keys_out, uint32_t *vals_out, size_t n,
+                         int32_t end_bit, int32_t which, void *stream);
+int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream);
+
+/* on != 0: every sort and scan of later forwards IN THIS LIBRARY takes the hierarchical (ticket) passes that scenes of more than ~6 M
+ * triangles / 12.6 M instances take, whatever their size -- so that the suite executes them (ticket-path depth census included). */
+void ts2d_lab_force_ticket_passes(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TS2D_LAB_H */

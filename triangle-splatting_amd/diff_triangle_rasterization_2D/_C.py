@@ -99,9 +99,13 @@ _lib.ts2d_backward.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uin
                                C.POINTER(_State), C.POINTER(_LossGrads), _fp, C.c_size_t, C.POINTER(_BackwardOut), _fp]
 _lib.ts2d_sh_grad_expand.restype = C.c_int
 _lib.ts2d_sh_grad_expand.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp]
-_lib.ts2d_debug_read_state.restype = C.c_int
-_lib.ts2d_debug_read_state.argtypes = [C.POINTER(_State), C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _fp,
-                                       C.c_size_t, _fp]
+_lib.ts2d_binning_capacity.restype = C.c_int64
+_lib.ts2d_binning_capacity.argtypes = [C.c_size_t, C.c_int32, C.c_int32]
+_lib.ts2d_instance_capacity_hint.restype = C.c_int64
+_lib.ts2d_instance_capacity_hint.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint32]
+_lib.ts2d_forward_speculative.restype = C.c_int
+_lib.ts2d_forward_speculative.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, _fp, C.POINTER(_State), C.POINTER(_ForwardOut),
+                                          C.POINTER(C.c_int64), _fp]
 _lib.ts2d_profile_enable.argtypes = [C.c_int]
 _lib.ts2d_profile_only.argtypes = [C.c_char_p]
 _lib.ts2d_profile_read.restype = C.c_int
@@ -239,17 +243,23 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
             _check(_lib.ts2d_forward(C.byref(cam), C.byref(geom), flags, _ptr(radii), C.byref(st), cap, C.byref(out), stream),
                    "rasterize_triangles")
             return (cap, out_feature, radii, depth, normal, contrib_sum, contrib_max, geometryBuffer, binningBuffer, imageBuffer)
-        binningBuffer = torch.empty((0,), **u8)
-        st = _state(geometryBuffer, binningBuffer, imageBuffer)
-        n = C.c_int64(0)
-        _check(_lib.ts2d_forward_bin(C.byref(cam), C.byref(geom), flags, _ptr(radii), C.byref(st), C.byref(n), stream),
-               "rasterize_triangles")
-        num_rendered = int(n.value)
-        binningBuffer = torch.empty((_lib.ts2d_binning_state_bytes(num_rendered, W, H),), **u8)
+        # The reference's sequence (num_rendered comes back to the host, rasterizer.cu:189-191) without its stall: the binning buffer is
+        # sized from what recent forwards of this image size rendered (x 1.25), EVERYTHING is queued for that capacity, and only then does
+        # the host wait for the exact count, which the GPU publishes ~0.1 ms into the forward (ts2d_forward_speculative).  Without a
+        # history (first call) or when the guess was too small (nothing was emitted then), the second half runs again with the exact size.
+        cap_guess = int(_lib.ts2d_instance_capacity_hint(P, W, H, flags))
+        binningBuffer = torch.empty((_lib.ts2d_binning_state_bytes(cap_guess, W, H) if cap_guess > 0 else 0,), **u8)
         st = _state(geometryBuffer, binningBuffer, imageBuffer)
         out = _ForwardOut(_ptr(out_feature), _ptr(depth), _ptr(normal), _ptr(contrib_sum), _ptr(contrib_max))
-        _check(_lib.ts2d_forward_render(C.byref(cam), C.byref(geom), flags, num_rendered, C.byref(st), C.byref(out), stream),
+        n = C.c_int64(0)
+        _check(_lib.ts2d_forward_speculative(C.byref(cam), C.byref(geom), flags, _ptr(radii), C.byref(st), C.byref(out), C.byref(n), stream),
                "rasterize_triangles")
+        num_rendered = int(n.value)
+        if cap_guess <= 0 or num_rendered > _lib.ts2d_binning_capacity(binningBuffer.numel(), W, H):
+            binningBuffer = torch.empty((_lib.ts2d_binning_state_bytes(num_rendered, W, H),), **u8)
+            st = _state(geometryBuffer, binningBuffer, imageBuffer)
+            _check(_lib.ts2d_forward_render(C.byref(cam), C.byref(geom), flags, num_rendered, C.byref(st), C.byref(out), stream),
+                   "rasterize_triangles")
     return (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max, geometryBuffer, binningBuffer,
             imageBuffer)
 
@@ -346,34 +356,7 @@ def sh_grad_expand(vertex, campos, dL_dcolor, sh_degree, M, out=None):
     return out
 
 
-# ---- diagnostics used by tests and bench.py (not part of the reference's surface) ---------------------------
-_FIELD_SPEC = {
-    "v_2D": (0, torch.float32, lambda P, N, T, HW: (P, 6)), "area2": (1, torch.float32, lambda P, N, T, HW: (P,)),
-    "normal_view": (2, torch.float32, lambda P, N, T, HW: (P, 3)), "v_depth": (3, torch.float32, lambda P, N, T, HW: (P, 3)),
-    "depth": (4, torch.float32, lambda P, N, T, HW: (P,)), "rgb": (5, torch.float32, lambda P, N, T, HW: (P, 3)),
-    "clamped": (6, torch.uint8, lambda P, N, T, HW: (P,)), "point_offsets": (7, torch.int32, lambda P, N, T, HW: (P,)),
-    "tiles_touched": (8, torch.int32, lambda P, N, T, HW: (P,)), "rect": (9, torch.int32, lambda P, N, T, HW: (P, 4)),
-    "keys": (10, torch.int64, lambda P, N, T, HW: (N,)), "vals": (11, torch.int32, lambda P, N, T, HW: (N,)),
-    "ranges": (12, torch.int32, lambda P, N, T, HW: (T, 2)), "n_contrib": (13, torch.int32, lambda P, N, T, HW: HW),
-    "final_T": (14, torch.float32, lambda P, N, T, HW: HW), "tile_unsorted": (15, torch.int32, lambda P, N, T, HW: (N,)),
-    "vals_unsorted": (16, torch.int32, lambda P, N, T, HW: (N,)), "depth_perm": (17, torch.int32, lambda P, N, T, HW: (P,)),
-    "records": (18, torch.float32, lambda P, N, T, HW: (P, 16)),
-}
-
-
-def debug_read_state(name, P, num_rendered, W, H, geometryBuffer, binningBuffer, imageBuffer) -> torch.Tensor:
-    """Copies one private state array to a CPU tensor (see ts2d_debug_read_state in include/ts2d.h)."""
-    field, dtype, shape = _FIELD_SPEC[name]
-    T = ((W + 15) // 16) * ((H + 15) // 16)
-    out = torch.empty(shape(P, num_rendered, T, (H, W)), dtype=dtype)
-    st = _state(geometryBuffer, binningBuffer, imageBuffer)
-    with torch.cuda.device(geometryBuffer.device):
-        stream = torch.cuda.current_stream().cuda_stream
-        _check(_lib.ts2d_debug_read_state(C.byref(st), P, num_rendered, W, H, field, out.data_ptr(),
-                                          out.numel() * out.element_size(), stream), "debug_read_state")
-    return out
-
-
+# ---- timing hooks used by bench.py (not part of the reference's surface) ----------------------------------------
 def profile_enable(on: bool):
     _lib.ts2d_profile_enable(1 if on else 0)
 

@@ -143,6 +143,10 @@ class _RasterizeTriangles(torch.autograd.Function):
         # autograd would otherwise materialise a zero tensor for every output without an incoming gradient (radii, contrib_sum,
         # contrib_max: three fill kernels per step that nothing reads); backward() makes its own zeros where it needs them
         ctx.set_materialize_grads(False)
+        # which differentiable inputs are outputs of autograd operations rather than leaf parameters (sigmoid(raw_opacity), cat(f_dc,
+        # f_rest), rescaled vertices: diff_recon_hip/model_forward.py): under GradBucket.capture() those still need their gradient
+        # handed to autograd, or the chain rule stops at the rasterizer
+        ctx.input_is_leaf = tuple(t.grad_fn is None for t in (vertex, shs, feature, opacity))
         ctx.raster_settings = rs
         ctx.num_rendered = num_rendered
         ctx.bg_depth = bg_depth
@@ -190,15 +194,20 @@ class _RasterizeTriangles(torch.autograd.Function):
                 # until bucket.wait() (handing out the bucket's own views would let AccumulateGrad alias `param.grad` to the bucket, and a
                 # second view would then be added twice: once above, once by autograd) -- and a PRIVATE tensor for dL_dcenter2D, which
                 # is a per-view statistic (each render call owns its center2D, VanillaTS_model.py:347-363), not a parameter gradient.
+                # That holds for LEAF parameters only.  An input that is itself the output of autograd operations (sigmoid(raw_opacity), a
+                # rescaled vertex tensor, cat(f_dc, f_rest)) gets a private copy, so that the operations upstream of the rasterizer still
+                # differentiate; the bucket then holds the gradient with respect to the rasterizer's input, which is what it is asked for.
+                leaf_vertex, leaf_shs, leaf_feature, leaf_opacity = ctx.input_is_leaf
+                private = (lambda g: g.clone()) if place is not None else (lambda g: g)  # a later view's tensors are not the bucket's
                 if "vertex" in nv:
-                    g_vertex = None
+                    g_vertex = None if leaf_vertex else private(g_vertex)
                 if "opacity" in nv:
-                    g_opacity = None
+                    g_opacity = None if leaf_opacity else private(g_opacity)
                 if "color" in nv and sink is None:
                     if use_shs:
-                        g_shs = None
+                        g_shs = None if leaf_shs else private(g_shs)
                     else:
-                        g_feat = None
+                        g_feat = None if leaf_feature else private(g_feat)
                 if "center2D" in nv and place is not None:
                     g_center2D = g_center2D.clone()
                 bucket._filled = True

@@ -276,36 +276,37 @@ def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree
         expand_fn = _C.sh_grad_expand
     P = vertex.shape[0]
     V = len(sink.colors)
-    # one flat message per rank: V * (3 P colour floats + 3 camera floats, padded to 4)
-    local = torch.empty((V, 3 * P + 4), device=sink.colors[0].device, dtype=torch.float32)
+    # Two messages per rank: the colour factors (V, P, 3) and the camera centres (V, 4: xyz + padding).  They travel separately so that the
+    # gathered colours ARE the contiguous (world * V, P, 3) array the expansion kernel reads -- one message with the camera appended to every
+    # row made the rows 3 P + 4 floats wide, and slicing the colours out of it was a hidden copy of 12 P V world bytes per step (96 MB at 8
+    # ranks and 1 M triangles).
+    dev = sink.colors[0].device
+    local = torch.empty((V, P, 3), device=dev, dtype=torch.float32)
+    local_cam = torch.zeros((V, 4), device=dev, dtype=torch.float32)
     for v, (c, cp) in enumerate(zip(sink.colors, sink.campos)):
-        local[v, :3 * P] = c.reshape(-1)
-        local[v, 3 * P:3 * P + 3] = cp
-        local[v, 3 * P + 3] = 0.0
+        local[v].copy_(c.reshape(P, 3))
+        local_cam[v, :3] = cp
     world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    if world > 1 and uniform:
-        gathered = torch.empty((world * V, 3 * P + 4), device=local.device, dtype=torch.float32)
-        dist.all_gather_into_tensor(gathered, local, group=group)
-    elif world > 1:
+    if world > 1 and not uniform:
         # ranks may hold different numbers of views (shard_views with num_views % world != 0): agree on the largest count
         # and pad with zero-colour rows, which add nothing to the sum; a different triangle count is a caller error
-        meta = torch.tensor([V, -V, P, -P], device=local.device, dtype=torch.int64)
+        meta = torch.tensor([V, -V, P, -P], device=dev, dtype=torch.int64)
         dist.all_reduce(meta, op=dist.ReduceOp.MAX, group=group)
         vmax, pmax, pmin = int(meta[0]), int(meta[2]), -int(meta[3])
         if pmax != pmin:
             raise RuntimeError(f"exchange_factored_sh_grads: ranks disagree on the number of triangles ({pmin} .. {pmax})")
         if vmax != V:
-            pad = torch.zeros((vmax - V, 3 * P + 4), device=local.device, dtype=torch.float32)
-            local = torch.cat([local, pad], dim=0)
+            local = torch.cat([local, torch.zeros((vmax - V, P, 3), device=dev, dtype=torch.float32)], dim=0)
+            local_cam = torch.cat([local_cam, torch.zeros((vmax - V, 4), device=dev, dtype=torch.float32)], dim=0)
             V = vmax
-        gathered = torch.empty((world * V, 3 * P + 4), device=local.device, dtype=torch.float32)
-        dist.all_gather_into_tensor(gathered, local, group=group)
+    if world > 1:
+        colors = torch.empty((world * V, P, 3), device=dev, dtype=torch.float32)
+        cams = torch.empty((world * V, 4), device=dev, dtype=torch.float32)
+        dist.all_gather_into_tensor(colors, local, group=group)
+        dist.all_gather_into_tensor(cams, local_cam, group=group)
     else:
-        gathered = local
-    colors = gathered[:, :3 * P].reshape(world * V, P, 3)
-    campos = gathered[:, 3 * P:3 * P + 3]
-    if not colors.is_contiguous() or not campos.is_contiguous():
-        colors, campos = colors.contiguous(), campos.contiguous()
+        colors, cams = local, local_cam
+    campos = cams[:, :3].contiguous()  # world * V * 12 bytes
     out = expand_fn(vertex.detach(), campos, colors, sh_degree, M)
     if mean and world > 1:
         out.div_(world)
