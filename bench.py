@@ -100,6 +100,10 @@ def main():
     ap.add_argument("--exchange-compare", action="store_true",
                     help="N > 1: after the timed region, time K more steps in the OTHER exchange mode and report its exposed_ms_per_step and "
                          "ms_per_step beside the headline mode's (config.exchange.other_mode)")
+    ap.add_argument("--with-optimizer", action="store_true",
+                    help="NOT the headline metric: every step also runs the fused Adam step (diff_recon_hip.FusedAdam: vertex, opacity and the SH tensor "
+                         "with the reference's f_dc / f_rest learning-rate split, one launch) on the step's gradients, with all learning rates 0 so that "
+                         "the scene stays the one BASELINE.json names; reported as config.optimizer")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--timed-kernel-events", default="dominant", choices=["dominant", "all"],
                     help="which kernels are bracketed by HIP events INSIDE the timed region: the dominant one (2 events per step; default) or "
@@ -171,6 +175,13 @@ def main():
     sink = parallel.ShGradSink()
 
     state = {"step": 0, "overlap": overlap, "pending": None}
+    optimizer = None
+    if args.with_optimizer:
+        if world > 1:
+            raise SystemExit("--with-optimizer is a single-GPU measurement (the sharded form is diff_recon_hip.ShardedAdam)")
+        from diff_recon_hip import FusedAdam
+        optimizer = FusedAdam([{"params": [vertex], "lr": 0.0, "name": "vertex"}, {"params": [opacity], "lr": 0.0, "name": "opacity"},
+                               {"params": [shs], "lr": 0.0, "lr_tail": 0.0, "tail_period": 3 * M, "tail_split": 3, "name": "shs"}], lr=0.0, eps=1e-15)
 
     def collect(i):
         """Waits (on the compute stream) for the exchange that step i started; the wait is bracketed by events = the EXPOSED exchange time."""
@@ -206,6 +217,8 @@ def main():
         else:
             out = raster(vertex, center2D, opacity, shs=shs)
             torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
+        if optimizer is not None:
+            optimizer.step()
         state["num_rendered"] = out[0].grad_fn.num_rendered
         state["image"] = out[0]
         vertex.grad = None
@@ -346,6 +359,8 @@ def main():
                    # spread of the host-side time per queued step: a stalled host (allocator growth, garbage collection, a descheduled thread)
                    # shows up here as a maximum far above the median, and in `value` (the contract times all K steps, stalls included)
                    "settle_steps_untimed": settle_steps,
+                   "optimizer": ("fused Adam step inside every step (vertex, opacity, SH with two learning rates; learning rates 0): NOT the headline metric"
+                                 if optimizer is not None else None),
                    "host_step_ms": {"min": round(host_gaps[0], 3), "median": round(host_gaps[len(host_gaps) // 2], 3), "max": round(host_gaps[-1], 3)},
                    # time between the per-step events on the launch stream: what the GPU saw.  A device step far above the median with an
                    # unremarkable host step is a device-side stall; both high together = the host starved the queue

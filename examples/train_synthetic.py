@@ -2,7 +2,7 @@
 trainer + model use their own (src/diff_recon/trainers/VanillaTS_trainer.py:60-130, src/diff_recon/models/VanillaTS_model.py:560-694):
 
     render_view (argument construction of VanillaTSModel.forward)  ->  TriangleRenderer  ->  2D or 3D HIP rasterizer
-    photometric_loss (fused L1 + SSIM)  ->  backward through the rasterizer  ->  Adam
+    photometric_loss (fused L1 + SSIM)  ->  backward through the rasterizer  ->  Adam (diff_recon_hip.FusedAdam: one fused launch)
     model_update(iteration) in the reference's order (:560-575): training statistic, densification, opacity pruning / clipping,
     scale pruning / clipping, contribution pruning, opacity reset, gamma schedule, SH-degree schedule
     -- every structural update through the native row operators of include/ts_model.h (diff_recon_hip/model_update.py).
@@ -60,7 +60,8 @@ class SyntheticModel(DensificationStats):
         super().__init__(vertex.shape[0], vertex.device)
         self._vertex, self._opacity = torch.nn.Parameter(vertex), torch.nn.Parameter(raw_opacity)
         self._f_dc, self._f_rest = torch.nn.Parameter(f_dc), torch.nn.Parameter(f_rest)
-        self.optimizer = torch.optim.Adam([{"params": [self._vertex], "lr": 0.03, "name": "vertex"}, {"params": [self._opacity], "lr": 0.05, "name": "opacity"},
+        # the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15) (VanillaTS_model.py:108-124) as one fused launch per step (include/ts_optim.h)
+        self.optimizer = D.FusedAdam([{"params": [self._vertex], "lr": 0.03, "name": "vertex"}, {"params": [self._opacity], "lr": 0.05, "name": "opacity"},
                                            {"params": [self._f_dc], "lr": 0.01, "name": "f_dc"}, {"params": [self._f_rest], "lr": 0.0005, "name": "f_rest"}],
                                           lr=0.0, eps=1e-15)
         self.max_sh_degree, self.active_sh_degree, self.gamma = max_sh_degree, 0, 1.0

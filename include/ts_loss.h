@@ -43,17 +43,18 @@ int tsl_photometric_backward(const float *image, const float *gt, int32_t channe
  *     d = bilinear(depth, scale_factor);  (gx, gy) = Scharr(d);  raw normal from (gx, gy) / d and the pinhole (tan_fovx, tan_fovy);
  *     Dn = normalize(bilinear(raw normal, (H, W)));  mask = bilinear(|(gx, gy)|) < quantile(.., depth_grad_filter_quantile);
  *     loss = mean((1 - <normalize(normal, eps 1e-8), Dn>) * mask)
- * scale_factor <= 0 or == 1 means "no resampling" (the reference's scale_factor = None). */
-size_t tsl_depth_normal_workspace_bytes(int32_t height, int32_t width, float scale_factor);
+ * scale_factor <= 0 or == 1 means "no resampling" (the reference's scale_factor = None); it is a double, like the Python float
+ * F.interpolate receives: the low-resolution size floor(H * s) and the coordinate ratio (float)(1 / s) are formed from it in double. */
+size_t tsl_depth_normal_workspace_bytes(int32_t height, int32_t width, double scale_factor);
 
 /* Forward: out[0] = loss (one float in device memory).  The workspace keeps what the backward needs. */
 int tsl_depth_normal_forward(const float *depth, const float *normal, int32_t height, int32_t width, float tan_fovx, float tan_fovy,
-                             float scale_factor, float quantile, void *workspace, size_t workspace_bytes, float *out, void *stream);
+                             double scale_factor, float quantile, void *workspace, size_t workspace_bytes, float *out, void *stream);
 
 /* Backward of out[0]: dL_ddepth (H, W) and / or dL_dnormal (3, H, W), fully written; either may be NULL (the reference's depth_grad /
  * normal_grad = False).  `grad_out`: device scalar or NULL for 1.  `workspace`: the buffer the matching forward filled. */
 int tsl_depth_normal_backward(const float *depth, const float *normal, int32_t height, int32_t width, float tan_fovx, float tan_fovy,
-                              float scale_factor, const void *workspace, size_t workspace_bytes, const float *grad_out, float *dL_ddepth,
+                              double scale_factor, const void *workspace, size_t workspace_bytes, const float *grad_out, float *dL_ddepth,
                               float *dL_dnormal, void *stream);
 
 #ifdef __cplusplus

@@ -1,0 +1,58 @@
+/* ts_optim.h -- C ABI of the optimizer step of the training loop, exported by libts2d.so ("reduce-scatter + sharded Adam +
+ * all-gather"; VERDICT r3: the next-largest cost of a step after the rasterizer once the loss is fused).
+ *
+ * Replaces `self.model.optimizer.step()` of the reference's trainer (src/diff_recon/trainers/VanillaTS_trainer.py:119-122), where the
+ * optimizer is torch.optim.Adam over four per-triangle parameter groups -- vertex (P,3,3), opacity (P,1), f_dc (P,1,3), f_rest (P,M-1,3) --
+ * with per-group learning rates set every iteration, betas (0.9, 0.999), eps = 1e-15, no weight decay, no amsgrad
+ * (src/diff_recon/models/VanillaTS_model.py:108-124, update_learning_rate :583).  torch runs that as ~10 multi-tensor launches per step;
+ * here it is ONE launch over any number of flat ranges ("slices"): all four groups of a single-GPU step, or the parts of the groups that
+ * fall into the 1 / world slice of a flat parameter buffer that a rank owns after the gradients' reduce-scatter (sharded Adam).
+ *
+ * Arithmetic per element, fp32, in torch's operation order (torch/optim/adam.py, _single_tensor_adam):
+ *     g            = grad * grad_scale                      (grad_scale = 1, or 1 / world for mean-reduced gradients)
+ *     exp_avg      = exp_avg + (g - exp_avg) * (1 - beta1)                                  (lerp_)
+ *     exp_avg_sq   = exp_avg_sq * beta2 + (1 - beta2) * g * g                               (mul_, addcmul_)
+ *     denom        = sqrt(exp_avg_sq) / bias2_sqrt + eps        bias2_sqrt = sqrt(1 - beta2^t)
+ *     param        = param - step_size * (exp_avg / denom)      step_size  = lr / (1 - beta1^t)
+ * The two bias corrections are formed by the caller in double, like torch forms them in Python, and handed over as floats.  Built without
+ * FMA contraction; torch's own kernels may contract a product into the following sum, so results agree with torch.optim.Adam to 1 ulp per
+ * operation, not bit for bit (tests/test_optim_gpu.py states the bound).  HBM-bound: 16 bytes read + 12 written per element.
+ * All pointers are device pointers; `count` floats each; asynchronous on `stream`. */
+#ifndef TS_OPTIM_H
+#define TS_OPTIM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tso_adam_slice
+{
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int64_t count;     /* floats in this slice */
+    float step_size;   /* lr / (1 - beta1^t) */
+    float bias2_sqrt;  /* sqrt(1 - beta2^t) */
+    float grad_scale;  /* multiplies the gradient (1 = as is) */
+    /* optional second learning rate inside ONE tensor: elements whose index (index0 + i) % period >= split use step_size_tail.  period = 0
+     * switches it off.  This is how a single (P, M, 3) SH tensor carries the reference's two groups f_dc (first 3 floats of every triangle's
+     * 3 M) and f_rest (the other 3 M - 3) without the torch.cat of VanillaTS_model.py:79-80 in every forward. */
+    float step_size_tail;
+    int64_t index0;    /* index of this slice's first element inside its tensor (a rank's slice starts in the middle of one) */
+    int32_t period, split;
+} tso_adam_slice;
+
+#define TSO_MAX_SLICES 16 /* per call */
+
+/* beta1, beta2, eps are doubles like the Python floats torch receives: 1 - beta is formed in double and THEN rounded to fp32 (1 - 0.999f is
+ * 1.3e-5 off 0.001). */
+int tso_adam_step(const tso_adam_slice *slices, int32_t num_slices, double beta1, double beta2, double eps, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TS_OPTIM_H */

@@ -339,7 +339,10 @@ def depth_normal():
     tu = load_trainer_utils()
     rng = np.random.default_rng(11)
     out = {}
-    cases = [(47, 64, 0.5, 0.9, 0.31, 0.23), (64, 48, 0.5, 0.9, 0.5, 0.66), (33, 41, None, 0.9, 0.4, 0.3), (40, 56, 0.25, 0.7, 0.31, 0.2)]
+    cases = [(47, 64, 0.5, 0.9, 0.31, 0.23), (64, 48, 0.5, 0.9, 0.5, 0.66), (33, 41, None, 0.9, 0.4, 0.3), (40, 56, 0.25, 0.7, 0.31, 0.2),
+             # non-dyadic factors on sizes divisible by 10: floor(H * s) and 1 / s must be formed in double like F.interpolate does (H = 40,
+             # s = 0.7: 28 rows; a float32 0.7 gives 27)
+             (40, 50, 0.7, 0.9, 0.35, 0.28), (30, 60, 0.3, 0.8, 0.3, 0.15)]
     out["cases"] = np.array([[H, W, -1.0 if s is None else s, q, tx, ty] for H, W, s, q, tx, ty in cases], np.float64)
     for i, (H, W, s, q, tx, ty) in enumerate(cases):
         # a smooth depth map with a few discontinuities (what a rendered scene looks like), strictly positive

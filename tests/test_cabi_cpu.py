@@ -21,7 +21,7 @@ def _declared_functions():
     names = set()
     for h in HEADERS:  # every header under include/: ts2d.h (rasterizer), ts_loss.h (photometric loss), ts_knn.h (nearest neighbours)
         src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
-        names |= set(re.findall(r"\b((?:ts2d|tsl|tsk|tsm)_[a-z0-9_]+)\s*\(", src))
+        names |= set(re.findall(r"\b((?:ts2d|tsl|tsk|tsm|tso)_[a-z0-9_]+)\s*\(", src))
     return sorted(names)
 
 
@@ -31,7 +31,7 @@ def test_header_declares_the_expected_entry_points():
                  "ts2d_binning_state_bytes", "ts2d_image_state_bytes", "ts2d_backward_scratch_bytes", "ts2d_last_error",
                  "ts2d_version", "ts2d_forward_speculative", "ts2d_binning_capacity", "ts2d_instance_capacity_hint", "ts2d_sh_grad_expand", "tsl_workspace_bytes",
                  "tsl_photometric_forward", "tsl_photometric_backward", "tsk_workspace_bytes", "tsk_mean_dist3",
-                 "tsk_nearest_other", "tsm_training_statistic"):
+                 "tsk_nearest_other", "tsm_training_statistic", "tso_adam_step"):
         assert must in names
 
 

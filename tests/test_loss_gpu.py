@@ -181,7 +181,7 @@ def _dn_golden():
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "depth_normal.npz"))
 
 
-@pytest.mark.parametrize("i", range(4))
+@pytest.mark.parametrize("i", range(6))
 def test_depth_normal_loss_matches_reference_golden(i):
     """The fused DepthNormalLoss (csrc/depth_normal.hip through include/ts_loss.h) against the reference's own class + autograd
     (tests/golden/depth_normal.npz): loss to 1e-5 relative, gradients to 1e-4 relative L2 (float32 on both sides)."""

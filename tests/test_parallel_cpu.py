@@ -325,3 +325,65 @@ def test_exchange_protocol_world_4_and_8_uneven_views(hip_lib_built, world):
         p.join(300)
         assert p.exitcode == 0
     assert dict(q.get(timeout=5) for _ in range(world)) == {r: True for r in range(world)}
+
+
+# ---- sharded Adam: reduce-scatter of the gradient bucket -> the rank's slice -> all-gather of the parameters (protocol over gloo) --------
+def _sharded_adam_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from diff_recon_hip.optim import ShardedAdam, _torch_step_fn
+
+        P, M = 41, 4  # 41 * 9 + 41 + 41 * 12 = 902 floats: the slice boundaries cut through the tensors
+        g0 = torch.Generator().manual_seed(3)
+        init = {"vertex": torch.rand((P, 3, 3), generator=g0), "opacity": torch.rand((P, 1), generator=g0), "shs": torch.rand((P, M, 3), generator=g0)}
+        lrs = {"vertex": 3e-2, "opacity": 5e-2, "shs": 1e-2}
+        tails = {"shs": (5e-4, 3 * M, 3)}  # f_dc / f_rest learning rates inside one SH tensor
+        opt = ShardedAdam({k: v.clone() for k, v in init.items()}, lrs, eps=1e-15, mean=True, tails=tails, step_fn=_torch_step_fn)
+        # replicated reference: torch.optim.Adam on every rank over the MEAN of all ranks' gradients, f_dc / f_rest as separate tensors
+        ref = {"vertex": init["vertex"].clone().requires_grad_(), "opacity": init["opacity"].clone().requires_grad_(),
+               "f_dc": init["shs"][:, :1].clone().requires_grad_(), "f_rest": init["shs"][:, 1:].clone().requires_grad_()}
+        ropt = torch.optim.Adam([{"params": [ref["vertex"]], "lr": 3e-2}, {"params": [ref["opacity"]], "lr": 5e-2},
+                                 {"params": [ref["f_dc"]], "lr": 1e-2}, {"params": [ref["f_rest"]], "lr": 5e-4}], lr=0.0, eps=1e-15)
+        ok = True
+        for it in range(4):
+            grads = {r: {k: torch.rand(v.shape, generator=torch.Generator().manual_seed(1000 * it + 10 * r + j)) - 0.5
+                         for j, (k, v) in enumerate(init.items())} for r in range(world)}
+            if it == 2:  # the model rewrites the learning rates every iteration (VanillaTS_model.py:583)
+                opt.set_lr("vertex", 1e-2)
+                opt.set_lr("shs", 5e-3, lr_tail=2.5e-4)
+                ropt.param_groups[0]["lr"], ropt.param_groups[2]["lr"], ropt.param_groups[3]["lr"] = 1e-2, 5e-3, 2.5e-4
+            for v, gview in zip(grads[rank].values(), opt.bucket.views()):  # what the backward kernels do under bucket.capture()
+                gview.copy_(v)
+            opt.step()
+            params = opt.wait()
+            mean = {k: sum(grads[r][k] for r in range(world)) / world for k in init}
+            ref["vertex"].grad, ref["opacity"].grad = mean["vertex"], mean["opacity"]
+            ref["f_dc"].grad, ref["f_rest"].grad = mean["shs"][:, :1].contiguous(), mean["shs"][:, 1:].contiguous()
+            ropt.step()
+            want = {"vertex": ref["vertex"], "opacity": ref["opacity"], "shs": torch.cat([ref["f_dc"], ref["f_rest"]], 1)}
+            for k in init:
+                ok = ok and torch.allclose(params[k].detach(), want[k].detach(), rtol=2e-6, atol=1e-7)
+        ok = ok and opt.exp_avg.numel() == opt.bucket.padded // world  # moments exist for the own slice only
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_adam_equals_replicated_adam(world, hip_lib_built):
+    """ShardedAdam (diff_recon_hip/optim.py) over gloo with the eager step function injected: after every step all ranks hold the parameters
+    that torch.optim.Adam produces on the mean gradient -- including the two learning rates inside one SH tensor and slices whose
+    boundaries cut through tensors."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_adam_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    res = dict(q.get(timeout=5) for _ in range(world))
+    assert res == {r: True for r in range(world)}

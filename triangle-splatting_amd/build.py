@@ -38,6 +38,7 @@ SOURCES = {
     "depth_normal.hip": ["-ffp-contract=off"],
     "knn.hip": [],
     "model_update.hip": [],
+    "optim.hip": ["-ffp-contract=off"],
     "binning.hip": [],
     "render_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "render3d_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
@@ -54,7 +55,8 @@ LAB_LIB = os.path.join(os.path.dirname(HERE), "tools", "bin", "libts2d_lab.so")
 HEADERS = ["ts2d_common.h", "ts2d_lab.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
            os.path.join("..", "..", "include", "ts_knn.h"),
-           os.path.join("..", "..", "include", "ts_model.h")]
+           os.path.join("..", "..", "include", "ts_model.h"),
+           os.path.join("..", "..", "include", "ts_optim.h")]
 
 
 def hipcc() -> str:

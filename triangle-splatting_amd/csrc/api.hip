@@ -11,6 +11,7 @@
 #include "../../include/ts_loss.h"
 #include "../../include/ts_knn.h"
 #include "../../include/ts_model.h"
+#include "../../include/ts_optim.h"
 #ifdef TS2D_LAB
 #include "ts2d_lab.h"
 #endif
@@ -671,18 +672,18 @@ int tsl_photometric_backward(const float *image, const float *gt, int32_t channe
     return TS2D_OK;
 }
 
-size_t tsl_depth_normal_workspace_bytes(int32_t height, int32_t width, float scale_factor)
+size_t tsl_depth_normal_workspace_bytes(int32_t height, int32_t width, double scale_factor)
 {
     return ts_depth_normal_workspace_bytes(height, width, scale_factor);
 }
 
-static int depth_normal_args_ok(const float *depth, const float *normal, int32_t H, int32_t W, float tan_fovx, float tan_fovy, float scale,
+static int depth_normal_args_ok(const float *depth, const float *normal, int32_t H, int32_t W, float tan_fovx, float tan_fovy, double scale,
                                 const void *ws, size_t ws_bytes)
 {
     if (H <= 0 || W <= 0) return fail(TS2D_ERR_INVALID, "height and width must be positive");
     if ((int64_t)H * W > (int64_t)16 * 1000 * 1000) return fail(TS2D_ERR_INVALID, "quantile() input tensor is too large"); // torch.quantile's own limit
     if (!(tan_fovx > 0.0f) || !(tan_fovy > 0.0f)) return fail(TS2D_ERR_INVALID, "tan_fovx / tan_fovy must be positive");
-    if (scale > 0.0f && scale != 1.0f && ((int)floor((double)H * scale) < 1 || (int)floor((double)W * scale) < 1))
+    if (scale > 0.0 && scale != 1.0 && ((int)floor((double)H * scale) < 1 || (int)floor((double)W * scale) < 1))
         return fail(TS2D_ERR_INVALID, "scale_factor leaves no pixel");
     if (!depth || !normal || !ws) return fail(TS2D_ERR_INVALID, "null pointer");
     if (ws_bytes < ts_depth_normal_workspace_bytes(H, W, scale)) return fail(TS2D_ERR_CAPACITY, "workspace too small");
@@ -690,7 +691,7 @@ static int depth_normal_args_ok(const float *depth, const float *normal, int32_t
 }
 
 int tsl_depth_normal_forward(const float *depth, const float *normal, int32_t height, int32_t width, float tan_fovx, float tan_fovy,
-                             float scale_factor, float quantile, void *workspace, size_t workspace_bytes, float *out, void *stream)
+                             double scale_factor, float quantile, void *workspace, size_t workspace_bytes, float *out, void *stream)
 {
     if (int rc = depth_normal_args_ok(depth, normal, height, width, tan_fovx, tan_fovy, scale_factor, workspace, workspace_bytes)) return rc;
     if (!out) return fail(TS2D_ERR_INVALID, "null output");
@@ -702,7 +703,7 @@ int tsl_depth_normal_forward(const float *depth, const float *normal, int32_t he
 }
 
 int tsl_depth_normal_backward(const float *depth, const float *normal, int32_t height, int32_t width, float tan_fovx, float tan_fovy,
-                              float scale_factor, const void *workspace, size_t workspace_bytes, const float *grad_out, float *dL_ddepth,
+                              double scale_factor, const void *workspace, size_t workspace_bytes, const float *grad_out, float *dL_ddepth,
                               float *dL_dnormal, void *stream)
 {
     if (int rc = depth_normal_args_ok(depth, normal, height, width, tan_fovx, tan_fovy, scale_factor, workspace, workspace_bytes)) return rc;
@@ -740,6 +741,27 @@ int tsk_nearest_other(int32_t P, int32_t batch_size, const float *points, uint32
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps("knn_nearest_other", s);
     TS_HIP(ts_knn_nearest_other(P, batch_size, points, nearest, workspace, s));
+    return TS2D_OK;
+}
+
+// ---- include/ts_optim.h -----------------------------------------------------------------------------------------------
+int tso_adam_step(const tso_adam_slice *slices, int32_t num_slices, double beta1, double beta2, double eps, void *stream)
+{
+    if (num_slices < 0 || num_slices > TSO_MAX_SLICES) return fail(TS2D_ERR_INVALID, "num_slices must be in 0..%d", TSO_MAX_SLICES);
+    if (num_slices > 0 && !slices) return fail(TS2D_ERR_INVALID, "null slices");
+    if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return fail(TS2D_ERR_INVALID, "betas must be in [0, 1)"); // torch/optim/adam.py
+    if (!(eps >= 0.0)) return fail(TS2D_ERR_INVALID, "Invalid epsilon value");
+    for (int i = 0; i < num_slices; i++)
+    {
+        const tso_adam_slice &s = slices[i];
+        if (s.count < 0) return fail(TS2D_ERR_INVALID, "slice %d: count < 0", i);
+        if (s.count > 0 && (!s.param || !s.grad || !s.exp_avg || !s.exp_avg_sq)) return fail(TS2D_ERR_INVALID, "slice %d: null pointer", i);
+        if (s.period < 0 || s.split < 0 || (s.period > 0 && s.split > s.period) || s.index0 < 0) return fail(TS2D_ERR_INVALID, "slice %d: bad period / split / index0", i);
+        if (!(s.bias2_sqrt > 0.0f)) return fail(TS2D_ERR_INVALID, "slice %d: bias2_sqrt must be positive (step >= 1)", i);
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("adam_step", st);
+    TS_HIP(ts_optim_adam_step(slices, num_slices, beta1, beta2, eps, st));
     return TS2D_OK;
 }
 

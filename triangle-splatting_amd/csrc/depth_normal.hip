@@ -287,14 +287,16 @@ struct Carve
     size_t bytes;
 };
 constexpr int SUM_BLOCKS = 1024;
-Dims make_dims(int H, int W, float tan_fovx, float tan_fovy, float scale)
+Dims make_dims(int H, int W, float tan_fovx, float tan_fovy, double scale)
 {
     Dims m;
     m.H = H; m.W = W;
-    const bool same = !(scale > 0.0f) || scale == 1.0f;
-    m.h = same ? H : (int)floor((double)H * (double)scale);
-    m.w = same ? W : (int)floor((double)W * (double)scale);
-    m.r_down = same ? 1.0f : 1.0f / scale;   // interpolate(scale_factor = s): the given factor maps coordinates
+    // scale_factor travels as a double, like the Python float torch receives: the output size floor(H * s) and the coordinate ratio
+    // (float)(1.0 / s) are formed in double exactly as F.interpolate forms them (H = 10, s = 0.7 gives 7 rows; the float 0.69999999 gave 6)
+    const bool same = !(scale > 0.0) || scale == 1.0;
+    m.h = same ? H : (int)floor((double)H * scale);
+    m.w = same ? W : (int)floor((double)W * scale);
+    m.r_down = same ? 1.0f : (float)(1.0 / scale);   // interpolate(scale_factor = s): the given factor maps coordinates
     m.r_up_y = (float)m.h / (float)H;        // interpolate(size = ...): the size ratio does
     m.r_up_x = (float)m.w / (float)W;
     m.A = (float)m.w / (2.0f * tan_fovx);
@@ -325,13 +327,13 @@ Carve carve(void *ws, const Dims &m)
 }
 } // namespace
 
-size_t ts_depth_normal_workspace_bytes(int H, int W, float scale)
+size_t ts_depth_normal_workspace_bytes(int H, int W, double scale)
 {
     if (H <= 0 || W <= 0) return TS_ALIGN;
     return carve(nullptr, make_dims(H, W, 1.0f, 1.0f, scale)).bytes;
 }
 
-hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, float scale, float quantile,
+hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, double scale, float quantile,
                                    void *workspace, float *out, hipStream_t s)
 {
     const Dims m = make_dims(H, W, tan_fovx, tan_fovy, scale);
@@ -349,7 +351,7 @@ hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int 
     return hipGetLastError();
 }
 
-hipError_t ts_depth_normal_backward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, float scale,
+hipError_t ts_depth_normal_backward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, double scale,
                                     const void *workspace, const float *grad_out, float *dL_ddepth, float *dL_dnormal, hipStream_t s)
 {
     (void)depth;

@@ -291,16 +291,20 @@ hipError_t ts_loss_backward(const float *image, const float *gt, int C, int H, i
                             const float *grad_out, float *dL_dimage, hipStream_t s);
 
 // ---- fused depth / normal consistency loss (depth_normal.hip, include/ts_loss.h) --------------------------------------------------
-size_t ts_depth_normal_workspace_bytes(int H, int W, float scale);
-hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, float scale, float quantile,
+size_t ts_depth_normal_workspace_bytes(int H, int W, double scale);
+hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, double scale, float quantile,
                                    void *workspace, float *out, hipStream_t s);
-hipError_t ts_depth_normal_backward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, float scale,
+hipError_t ts_depth_normal_backward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, double scale,
                                     const void *workspace, const float *grad_out, float *dL_ddepth, float *dL_dnormal, hipStream_t s);
 
 // ---- exact nearest-neighbour helpers (knn.hip, include/ts_knn.h) -------------------------------------------------------
 size_t ts_knn_workspace_bytes(int P);
 hipError_t ts_knn_mean_dist3(int P, const float *points, float *mean_dist2, void *ws, hipStream_t s);
 hipError_t ts_knn_nearest_other(int P, int group, const float *points, uint32_t *nearest, void *ws, hipStream_t s);
+
+// ---- fused Adam step (optim.hip, include/ts_optim.h) -------------------------------------------------------------------
+struct tso_adam_slice;
+hipError_t ts_optim_adam_step(const tso_adam_slice *slices, int n, double beta1, double beta2, double eps, hipStream_t s);
 
 // ---- per-iteration model-update statistics (model_update.hip, include/ts_model.h) --------------------------------------
 hipError_t ts_model_training_statistic(int P, int V, const int32_t *radii, const float *c2d_grad, const float *csum, const float *cmax,

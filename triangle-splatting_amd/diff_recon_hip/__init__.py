@@ -12,10 +12,13 @@
                           (reference: src/diff_recon/utils/scheduler.py:5-45, VanillaTS_model.py:548-565; pinned by tests/golden/schedules.npz)
     raw_triangle.py       RawTriangle with loadPLY / savePLY / saveGLB / loadGLB: the on-disk formats of a triangle model, numpy only
                           (reference: src/diff_recon/models/raw_triangle.py:12-33, 124-223)
+    optim.py              FusedAdam (the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15) as ONE fused launch, same param_groups / state) and
+                          ShardedAdam (reduce-scatter of the gradient bucket -> Adam on the rank's slice -> all-gather of the parameters)
+                          (reference: src/diff_recon/models/VanillaTS_model.py:108-124, src/diff_recon/trainers/VanillaTS_trainer.py:119-122)
     model_forward.py      render_view = the argument construction of VanillaTSModel.forward
                           (reference: src/diff_recon/models/VanillaTS_model.py:585-694)
 
-Native code: libts2d.so (include/ts_loss.h, include/ts_model.h, include/ts2d.h).  No CPU / eager fallback anywhere.
+Native code: libts2d.so (include/ts_loss.h, include/ts_model.h, include/ts_optim.h, include/ts2d.h).  No CPU / eager fallback anywhere.
 """
 from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss, DepthNormalLoss  # noqa: F401
 from .triangle_renderer import TriangleRenderer  # noqa: F401
@@ -24,3 +27,4 @@ from .model_update import (DensificationStats, prune_points, densification, opac
                            scale_clipping, opacity_reset, contribution_pruning, set_gamma, set_sh_degree, run_model_update)
 from . import schedulers  # noqa: F401
 from .raw_triangle import RawTriangle  # noqa: F401
+from .optim import FusedAdam, ShardedAdam  # noqa: F401

@@ -127,11 +127,11 @@ class PhotometricLoss(nn.Module):
 
 # ---- depth / normal consistency loss (trainer_utils.py:204-257) -------------------------------------------------------------------
 _lib.tsl_depth_normal_workspace_bytes.restype = C.c_size_t
-_lib.tsl_depth_normal_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_float]
+_lib.tsl_depth_normal_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_double]
 _lib.tsl_depth_normal_forward.restype = C.c_int
-_lib.tsl_depth_normal_forward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_float, _fp, C.c_size_t, _fp, _fp]
+_lib.tsl_depth_normal_forward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_double, C.c_float, _fp, C.c_size_t, _fp, _fp]
 _lib.tsl_depth_normal_backward.restype = C.c_int
-_lib.tsl_depth_normal_backward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, _fp, C.c_size_t, _fp, _fp, _fp, _fp]
+_lib.tsl_depth_normal_backward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_double, _fp, C.c_size_t, _fp, _fp, _fp, _fp]
 
 
 class _DepthNormal(torch.autograd.Function):
