@@ -104,6 +104,10 @@ def main():
                     help="NOT the headline metric: every step also runs the fused Adam step (diff_recon_hip.FusedAdam: vertex, opacity and the SH tensor "
                          "with the reference's f_dc / f_rest learning-rate split, one launch) on the step's gradients, with all learning rates 0 so that "
                          "the scene stays the one BASELINE.json names; reported as config.optimizer")
+    ap.add_argument("--force-depth-pass4", action="store_true",
+                    help="NOT the headline: the depth sort runs its fourth pass although every depth of the synthetic scene shares the top key byte "
+                         "(what a scene spanning more than a factor of four in depth costs).  Needs the lab library: "
+                         "TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so (the product library has no switch)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--timed-kernel-events", default="dominant", choices=["dominant", "all"],
                     help="which kernels are bracketed by HIP events INSIDE the timed region: the dominant one (2 events per step; default) or "
@@ -136,6 +140,10 @@ def main():
     from diff_triangle_rasterization_2D import parallel
     from diff_triangle_rasterization_2D.parallel import GradBucket
 
+    if args.force_depth_pass4:
+        if not hasattr(_C._lib, "ts2d_lab_force_depth_pass4"):
+            raise SystemExit("--force-depth-pass4 needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
+        _C._lib.ts2d_lab_force_depth_pass4(1)
     P, W, H, D = args.triangles, args.width, args.height, args.sh_degree
     s = synthetic.scene(P, W, H, D, seed=42)
     # one view per rank: same triangles, camera shifted sideways by a few world units per rank
@@ -359,6 +367,7 @@ def main():
                    # spread of the host-side time per queued step: a stalled host (allocator growth, garbage collection, a descheduled thread)
                    # shows up here as a maximum far above the median, and in `value` (the contract times all K steps, stalls included)
                    "settle_steps_untimed": settle_steps,
+                   "depth_sort_passes": "4 (forced, lab library)" if args.force_depth_pass4 else "3 or 4, decided on the device by the key-bit census (3 on this scene)",
                    "optimizer": ("fused Adam step inside every step (vertex, opacity, SH with two learning rates; learning rates 0): NOT the headline metric"
                                  if optimizer is not None else None),
                    "host_step_ms": {"min": round(host_gaps[0], 3), "median": round(host_gaps[len(host_gaps) // 2], 3), "max": round(host_gaps[-1], 3)},

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 
 IMG_TOL = 1e-4   # north_star: image relative L2
 GRAD_TOL = 1e-3  # north_star: gradient relative L2
-OUTLIER_FRAC = 1e-4  # pixels allowed to differ in n_contrib (threshold flips at T <= 1e-4, alpha >= 1/255)
+OUTLIER_FRAC = 1e-5  # pixels allowed to differ in n_contrib (threshold flips at T <= 1e-4, alpha >= 1/255); at least 2
 
 
 def _check_state(s, hf, of):
@@ -297,7 +297,10 @@ def test_full_size_against_oracle(P, W, H, D, variant):
         assert np.array_equal(helpers.hip_state(hf, s, name).astype(np.int64).reshape(-1),
                               of["state"].field(name).astype(np.int64).reshape(-1)), name
     nc_h = helpers.hip_state(hf, s, "n_contrib").astype(np.int64)
-    assert (nc_h != of["state"].field("n_contrib").astype(np.int64)).mean() <= OUTLIER_FRAC
+    differ = int((nc_h != of["state"].field("n_contrib").astype(np.int64)).sum())
+    print(f"n_contrib differs on {differ} of {nc_h.size} pixels")
+    # 2D: SURVEY 8c's 1e-5; the 3D variant's ray / plane depth is ill-conditioned at grazing angles (tests/test_parity3d_gpu.py: 2e-4)
+    assert differ <= max(2, (OUTLIER_FRAC if variant == 2 else 2e-4) * nc_h.size)
     if variant == 2:
         for k in ("out_feature", "depth", "normal"):
             assert helpers.rel_l2(hf[k], of[k]) < IMG_TOL, k

@@ -307,4 +307,22 @@ def test_random_configurations_against_the_reference_build(seed):
     ob = helpers.oracle_backward(s, of, rich, use_feature=use_feature)
     for k in ("dL_dvertex", "dL_dcenter2D"):
         d_hr, d_or = helpers.rel_l2(hf[k], rf[k]), helpers.rel_l2(ob[k], rf[k])
+        branch = "bar" if d_hr < GRAD_TOL else "three-way"
+        _FUZZ_BRANCHES[(seed, k)] = (branch, d_hr, d_or)
+        print(f"seed {seed} {k}: product vs reference {d_hr:.3e} (oracle vs reference {d_or:.3e}) -> {branch}")
         assert d_hr < GRAD_TOL or d_hr <= 1.5 * d_or, (k, d_hr, d_or)
+
+
+_FUZZ_BRANCHES = {}  # (seed, output) -> (which branch of the criterion above passed, product-reference distance, oracle-reference distance)
+
+
+def test_three_way_escape_is_the_exception():
+    """The random-configuration sweep above accepts a geometry gradient that misses the 1e-3 bar against the reference when the oracle
+    misses it by as much (one flipped discrete decision on a scene of a few thousand triangles).  That escape must stay the exception:
+    at most a quarter of the comparisons may need it.  Runs after the sweep (file order); on its own it has nothing to
+    judge."""
+    if not _FUZZ_BRANCHES:
+        pytest.skip("the sweep did not run in this process")
+    escaped = sorted(k for k, v in _FUZZ_BRANCHES.items() if v[0] == "three-way")
+    print(f"{len(escaped)} of {len(_FUZZ_BRANCHES)} comparisons took the three-way branch: {escaped}")
+    assert len(escaped) * 4 <= len(_FUZZ_BRANCHES), {k: _FUZZ_BRANCHES[k] for k in escaped}

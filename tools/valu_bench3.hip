@@ -65,6 +65,24 @@ KERNEL(k_readlane, "", "v_readlane_b32 %9, %0, 5\n v_readlane_b32 %9, %3, 7\n")
 KERNEL(k_salu, "", "s_add_u32 %9, %9, 5\n s_lshl_b32 %9, %9, 1\n")
 KERNEL(k_fma_salu, "", "v_fma_f32 %0, %1, %2, %0\n s_add_u32 %9, %9, 5\n")
 
+// Packed fp32 (round 4; VERDICT r3 item 2: "is two pixels per lane a lever?"): v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 work on 64-bit
+// register pairs, two independent fp32 operations per lane and instruction.  If a wave instruction of these costs the same 2 cycles as the
+// scalar form, a lane could carry two pixels (or two list entries) at half the issue cost of the full-rate part of the blend loops.
+typedef float f2 __attribute__((ext_vector_type(2)));
+#define KERNEL_PK(NAME, ASM)                                                                       \
+    __global__ void __launch_bounds__(256) NAME(float *out, long long *ticks, int iters)           \
+    {                                                                                              \
+        f2 a = {threadIdx.x * 0.5f, 1.5f}, b = {1.0001f, 0.9999f}, c = {0.25f, 0.5f}, d = a + 1.0f, e = b, f = c; \
+        const long long t0 = clock64();                                                            \
+        for (int i = 0; i < iters; i++) asm volatile(REP32(ASM) : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f)); \
+        const long long t1 = clock64();                                                            \
+        if ((threadIdx.x & 63) == 0) ticks[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;         \
+        out[blockIdx.x * 256 + threadIdx.x] = a.x + a.y + b.x + c.y + d.x + d.y + e.x + f.y;       \
+    }
+KERNEL_PK(k_pk_fma, "v_pk_fma_f32 %0, %1, %2, %0\n v_pk_fma_f32 %3, %4, %5, %3\n")
+KERNEL_PK(k_pk_mul, "v_pk_mul_f32 %0, %1, %2\n v_pk_mul_f32 %3, %4, %5\n")
+KERNEL_PK(k_pk_add, "v_pk_add_f32 %0, %1, %0\n v_pk_add_f32 %3, %4, %3\n")
+
 template <typename K>
 void run(const char *name, K kern, float *d, long long *dt, int waves_per_simd, double instr_per_iter = 64.0)
 {
@@ -103,6 +121,8 @@ int main()
     RUN("permlane32", k_swap32); RUN("v_rcp_f32", k_rcp); RUN("v_exp_f32", k_exp);
     RUN("3fma+exp", k_fma3_exp, 128.0); RUN("fma+dpp", k_fma_dpp); RUN("3fma+dpp", k_fma3_dpp, 128.0); RUN("fma+cndmask", k_fma_cnd);
     RUN("v_readlane", k_readlane); RUN("salu", k_salu); RUN("fma+salu", k_fma_salu);
+    // packed fp32: two operations per lane and instruction
+    RUN("v_pk_fma_f32", k_pk_fma); RUN("v_pk_mul_f32", k_pk_mul); RUN("v_pk_add_f32", k_pk_add);
     // fewer resident waves: does one wave reach the same rate?
     run("v_fma_f32", k_fma, d, dt, 1); run("v_fma_f32", k_fma, d, dt, 2); run("v_fma_f32", k_fma, d, dt, 4);
     run("dpp row_ror", k_dpp_ror, d, dt, 1); run("dpp row_ror", k_dpp_ror, d, dt, 2); run("dpp row_ror", k_dpp_ror, d, dt, 4);

@@ -966,6 +966,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
 
 // ts2d_test_sort_pairs / ts2d_test_inclusive_scan_rocprim: csrc/lab_hooks.hip (the rocPRIM comparators live there, outside the product's objects)
 void ts2d_lab_force_ticket_passes(int on) { ts_force_ticket_passes(on != 0); }
+void ts2d_lab_force_depth_pass4(int on) { ts_force_depth_pass4(on != 0); }
 #endif // TS2D_LAB
 
 void ts2d_profile_enable(int on)

@@ -120,6 +120,7 @@ struct DepthCensus
     unsigned long long *n_out;     // device: where the scan will leave N as well
     unsigned long long *host_out;  // pinned host word or null
     uint32_t *top_const;           // device flag
+    uint32_t force_varying;        // lab library only (ts2d_lab_force_depth_pass4): key bits reported as varying whatever the scene holds
 };
 __device__ __forceinline__ bool pass_skipped(const uint32_t *skip_flag) { return skip_flag && peer_load(skip_flag) != 0u; }
 
@@ -237,7 +238,7 @@ __global__ void __launch_bounds__(256) rs_hist_kernel(const uint32_t *__restrict
         if (t == 0)
         {
             const unsigned long long N = csum[0] + csum[1] + csum[2] + csum[3];
-            const uint32_t varying = (cor[0] | cor[1] | cor[2] | cor[3]) ^ (cand[0] & cand[1] & cand[2] & cand[3]);
+            const uint32_t varying = ((cor[0] | cor[1] | cor[2] | cor[3]) ^ (cand[0] & cand[1] & cand[2] & cand[3])) | census.force_varying;
             *census.n_out = N;
             peer_store(census.top_const, (varying >> 24) == 0u ? 1u : 0u); // no visible triangle at all: or = 0, and = ~0 -> varying = ~0 -> not set
             // pinned, device-visible host word: the host reads it after the event recorded behind this kernel (no copy kernel in between)
@@ -348,7 +349,7 @@ __device__ __forceinline__ void publish_census(const DepthCensus &census, int ch
     if (t == 0)
     {
         const unsigned long long N = psum[0] + psum[1] + psum[2] + psum[3];
-        const uint32_t varying = (por[0] | por[1] | por[2] | por[3]) ^ (pand[0] & pand[1] & pand[2] & pand[3]);
+        const uint32_t varying = ((por[0] | por[1] | por[2] | por[3]) ^ (pand[0] & pand[1] & pand[2] & pand[3])) | census.force_varying;
         *census.n_out = N;
         *census.top_const = (varying >> 24) == 0u ? 1u : 0u; // no visible triangle at all: or = 0, and = ~0 -> varying = ~0 -> not set
         // pinned, device-visible host word: the host reads it after the event recorded behind this kernel (no copy kernel in between)
@@ -634,6 +635,7 @@ void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32
 // library sets it): every sort and the scan take the hierarchical passes that otherwise only scenes of more than ~6 M triangles reach, so that
 // the suite executes them -- including the ticket-path census that produces num_rendered there.
 bool g_force_tickets = false;
+bool g_force_pass4 = false; // same kind of switch (ts2d_lab_force_depth_pass4): the depth sort never skips its fourth pass
 bool radix_direct_ok(const RadixScratchView &r) { return !g_force_tickets && r.slabs <= TS_DIRECT_MAX_SLABS; }
 void radix_pass_direct(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
                        int nbits, const RadixScratchView &r, int which, hipStream_t s, const uint32_t *skip_flag = nullptr)
@@ -901,6 +903,7 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
     c.n_out = (unsigned long long *)g.blocksum + (P + SB - 1) / SB;
     c.host_out = host_out;
     c.top_const = g.top_const;
+    c.force_varying = g_force_pass4 ? 0xFF000000u : 0u;
     if (!radix_direct_ok(g.rs))
     {
         radix_hist((const uint32_t *)g.depth, P, nullptr, 0, 8, g.rs, s, &c);
@@ -1022,3 +1025,4 @@ int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, in
 }
 
 void ts_force_ticket_passes(bool on) { g_force_tickets = on; }
+void ts_force_depth_pass4(bool on) { g_force_pass4 = on; }

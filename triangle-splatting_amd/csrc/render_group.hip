@@ -34,7 +34,8 @@
 
 #ifndef TSG_PROBE
 #define TSG_PROBE 0 // profiling builds: 1 = no contribution atomics, 2 = no contribution statistics at all, 3 = no serialised accumulate,
-                    // 4 = backward without its step loop (what the per-batch work alone costs) -- results wrong
+                    // 4 = backward without its step loop (what the per-batch work alone costs), 6 = backward without the row flush,
+                    // 7 = backward whose row flush is a plain store instead of an atomic add -- results wrong
 #endif
 namespace
 {
@@ -662,7 +663,13 @@ __global__ void __launch_bounds__(64 * WPB, 7) render_bwd_group_kernel(RenderArg
                         const uint32_t eid = __float_as_uint(rows[e * BROW + 17]);
                         float val = rows[e * BROW + ROW + sub];
                         if (rcol < 6) val *= rows[e * BROW + 6];
+#if TSG_PROBE == 6
+                        if (a.W < 0) grad_rec[eid] = val; // never taken: keeps `val` alive
+#elif TSG_PROBE == 7
+                        if (RICH || rcol < 10) grad_rec[TS_GRAD_FLOATS * (size_t)eid + rcol] = val;
+#else
                         if (RICH || rcol < 10) unsafeAtomicAdd(grad_rec + TS_GRAD_FLOATS * (size_t)eid + rcol, val);
+#endif
                     }
                 }
             }

@@ -224,6 +224,7 @@ void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const Bin
 size_t ts_radix_scratch_bytes(size_t n);                                                          // the same sort for other callers (knn.hip)
 int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s, bool force_tickets = false);
 void ts_force_ticket_passes(bool on); // lab library only (csrc/ts2d_lab.h): no exported entry point of the product library reaches it
+void ts_force_depth_pass4(bool on);   // likewise
 
 struct RenderArgs
 {

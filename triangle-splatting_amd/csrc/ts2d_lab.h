@@ -35,6 +35,10 @@ int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n
 /* on != 0: every sort and scan of later forwards IN THIS LIBRARY takes the hierarchical (ticket) passes that scenes of more than ~6 M
  * triangles / 12.6 M instances take, whatever their size -- so that the suite executes them (ticket-path depth census included). */
 void ts2d_lab_force_ticket_passes(int on);
+/* on != 0: the depth sort of later forwards in this library always runs its fourth pass.  The product skips it when all visible depths
+ * share the top key byte (sign + 7 exponent bits: depths within a factor of four -- every synthetic scene of bench.py; not a real scene
+ * that spans more): bench.py --force-depth-pass4 reports the headline without that data-dependent shortcut. */
+void ts2d_lab_force_depth_pass4(int on);
 
 #ifdef __cplusplus
 }
