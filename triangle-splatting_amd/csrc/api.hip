@@ -513,8 +513,8 @@ int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, 
     int64_t cap = state->binning ? ts_binning_capacity(state->binning_bytes, W, H) : 0;
     if (cap < 0) cap = 0;
     EarlyCount early;
-    if (!acquire_early_count(early)) return fail(TS2D_ERR_HIP, "no pinned word for the instance count");
-    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, &early)) return rc;
+    const bool have_early = acquire_early_count(early);
+    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, have_early ? &early : nullptr)) return rc;
     if (cap > 0)
     {
         // everything behind the count is queued for the CAPACITY before the host has seen the count: the GPU never waits for the host
@@ -522,7 +522,17 @@ int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, 
         if (int rc = forward_render_impl(cam, geom, flags, cap, &on_device, state, out, s)) return rc;
     }
     unsigned long long n = 0;
-    if (int rc = wait_early_count(early, &n)) return rc;
+    if (have_early)
+    {
+        if (int rc = wait_early_count(early, &n)) return rc;
+    }
+    else // no pinned word (allocation refused): the count is copied behind everything that was queued -- slower, same results
+    {
+        GeometryStateView g;
+        ts_carve_geometry((char *)state->geometry, P, g);
+        TS_HIP(hipMemcpyAsync(&n, ts_instance_count_dev(g, P), sizeof(n), hipMemcpyDeviceToHost, s));
+        TS_HIP(hipStreamSynchronize(s));
+    }
     if (n > 0x7fffffffull) // the reference's int num_rendered wraps here; instance slots are 32-bit
         return fail(TS2D_ERR_CAPACITY, "%llu tile instances exceed the 2^31 - 1 the instance list can address", n);
     *num_rendered = (int64_t)n;

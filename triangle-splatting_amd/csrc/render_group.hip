@@ -32,6 +32,15 @@
 #include "ts2d_wave.h"
 #include "ts2d_group.h"
 
+#ifndef TSG_FWD_WAVES // resident waves per SIMD the register budget is declared for (occupancy experiments: tools/build_variant.sh ... -DTSG_BWD_WAVES=8)
+#define TSG_FWD_WAVES 7
+#endif
+#ifndef TSG_BWD_WAVES
+#define TSG_BWD_WAVES 7
+#endif
+#ifndef TSG_TCAP
+#define TSG_TCAP 960
+#endif
 #ifndef TSG_PROBE
 #define TSG_PROBE 0 // profiling builds: 1 = no contribution atomics, 2 = no contribution statistics at all, 3 = no serialised accumulate,
                     // 4 = backward without its step loop (what the per-batch work alone costs), 6 = backward without the row flush,
@@ -172,7 +181,7 @@ __device__ unsigned long long g_stats_group[12];
 #endif
 
 template <bool RICH, bool GAMMA1>
-__global__ void __launch_bounds__(256, 7) render_fwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+__global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                                 const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                 float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                                                                 float *__restrict__ out_feature, float *__restrict__ out_depth,
@@ -183,7 +192,7 @@ __global__ void __launch_bounds__(256, 7) render_fwd_group_kernel(RenderArgs a, 
     __shared__ __attribute__((aligned(16))) uint32_t list_all[4][4 * NR / 2]; // per group: NR entries of (row | batch position << 8)
     // contrib_sum / contrib_max of the tile's first TCAP list entries, merged over the four quadrant waves before they leave
     // as global atomics (one L2 line operation per (tile, triangle) instead of one per (quadrant, triangle))
-    constexpr int TCAP = 960; // 960 x 12 bytes + the tables = 23.1 KB per workgroup: seven workgroups per CU (1024 entries would leave six)
+    constexpr int TCAP = TSG_TCAP; // 960: 960 x 12 bytes + the tables = 23.1 KB per workgroup: seven workgroups per CU (1024 entries would leave six)
     __shared__ unsigned long long tsum[RICH ? TCAP : 1]; // 16.48 fixed point
     __shared__ int tmax[RICH ? TCAP : 1];
 #ifdef TSG_PAD_LDS // occupancy experiment: extra LDS bytes per workgroup
@@ -418,7 +427,7 @@ __global__ void __launch_bounds__(256, 7) render_fwd_group_kernel(RenderArgs a, 
 // four slots of one CU, which shortens the tail of the launch (8160 tiles are only 5.3 rounds of 256-thread workgroups).  The four
 // quadrants of a tile stay neighbours in dispatch order and on one XCD (shared L2 for the tile's list and records).
 template <bool RICH, bool GAMMA1, int WPB>
-__global__ void __launch_bounds__(64 * WPB, 7) render_bwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
+__global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                                    const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                    const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                                    const float *__restrict__ dL_dout_feature,
