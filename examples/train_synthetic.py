@@ -116,7 +116,7 @@ def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, se
     losses, t0 = [], time.perf_counter()
     for it in range(1, iters + 1):
         m.optimizer.zero_grad(set_to_none=True)
-        pkgs, total = [], 0.0
+        pkgs, total = [], torch.zeros((), device=dev)  # the loss stays on the device: no host synchronisation inside an iteration
         for k in range(views_per_step):  # the views of one step: gradients are summed, like ranks' gradients in image-parallel training
             v = (it * views_per_step + k) % views
             pkg = render_view(cams[v], m._vertex, m._f_dc, m._f_rest, m._opacity, is_training=True, gamma=m.gamma, active_sh_degree=m.active_sh_degree, **kw)
@@ -125,7 +125,7 @@ def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, se
                 loss = loss + w_geometry * geometry_loss(pkg["depth"], pkg["normal"], cams[v].tan_fovx, cams[v].tan_fovy)
             loss.backward()
             pkgs.append(pkg)
-            total += loss.item()
+            total += loss.detach()
         m.optimizer.step()
         if updates:
             m.model_update(it, pkgs)
@@ -134,9 +134,10 @@ def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, se
                 m.update(pkg)
         losses.append(total / views_per_step)
         if log and (it % 50 == 0 or it == 1 or it == iters):
-            log(f"iter {it:4d}  loss {losses[-1]:.5f}  triangles {m._vertex.shape[0]}  gamma {m.gamma:.2f}  sh {m.active_sh_degree}")
+            log(f"iter {it:4d}  loss {float(losses[-1]):.5f}  triangles {m._vertex.shape[0]}  gamma {m.gamma:.2f}  sh {m.active_sh_degree}")
     torch.cuda.synchronize()
-    return losses, m, (time.perf_counter() - t0) / iters
+    sec = (time.perf_counter() - t0) / iters
+    return [float(x) for x in torch.stack(losses).cpu()], m, sec
 
 
 if __name__ == "__main__":

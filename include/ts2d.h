@@ -90,6 +90,11 @@ typedef struct ts2d_geometry
     const float *shs;        /* P*M*3 floats (SH mode) or NULL */
     const float *feature;    /* P*C floats (feature mode) or NULL */
     const float *opacity;    /* P floats */
+    const float *background_depth_dev; /* optional DEVICE pointer to one float: when non-NULL the kernels read the background depth from
+                                          it and `background_depth` is ignored.  The reference's model computes it on the device every
+                                          step (max |campos - vertex|, src/diff_recon/models/VanillaTS_model.py:623) and its binding turns
+                                          the 0-dim tensor into a host float -- a full device synchronisation per forward (SURVEY.md 8a,
+                                          row a1); handing over the pointer keeps the step asynchronous.  Same fp32 value either way. */
 } ts2d_geometry;
 
 /* ForwardOutput, R2D/src/param_struct.h:155-166.  depth/normal/contrib_* may be NULL without RICH_INFO.

@@ -142,3 +142,35 @@ def test_capture_through_render_view_keeps_the_chain_rule():
     # the bucket holds the gradient with respect to the rasterizer's inputs (activated opacity, rescaled vertices, concatenated SH)
     nv = bucket.named_views()
     assert float(nv["vertex"].abs().sum()) > 0 and float(nv["opacity"].abs().sum()) > 0 and float(nv["color"].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_background_depth_as_a_device_tensor_needs_no_host_value(variant):
+    """settings.background_depth may be the 0-dim device tensor the reference's model computes every step (VanillaTS_model.py:623).  The
+    reference's binding converts it to a host float (a device synchronisation per forward); here it reaches the kernels as a pointer
+    (ts2d_geometry.background_depth_dev).  Same outputs and gradients, bit for bit, as the float."""
+    import torch
+    if variant == 3:
+        from diff_triangle_rasterization_3D import TriangleRasterizer
+    else:
+        from diff_triangle_rasterization_2D import TriangleRasterizer
+    s = synthetic.scene(6000, 160, 96, 1, seed=31)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def run(bg_depth):
+        rs = helpers.hip_settings(s, rich_info=True)._replace(background_depth=bg_depth)
+        vertex, opacity, shs = t(s["vertex"]).requires_grad_(True), t(s["opacity"]).requires_grad_(True), t(s["shs"]).requires_grad_(True)
+        c2d = torch.zeros((6000, 2), device="cuda", requires_grad=True)
+        out = TriangleRasterizer(rs)(vertex, c2d, opacity, shs=shs)
+        ((out[0] * t(s["dL_dout_feature"])).sum() + (out[2] * t(s["dL_dout_depth"])).sum() + (out[3] * t(s["dL_dout_normal"])).sum()).backward()
+        return [out[0].detach(), out[2].detach(), vertex.grad, opacity.grad, shs.grad]
+
+    value = 4321.125
+    as_float = run(value)
+    as_tensor = run(torch.tensor(value, device="cuda"))            # 0-dim, like (campos - vertex).norm(dim=-1).max()
+    as_double = run(torch.tensor(value, device="cuda", dtype=torch.float64))
+    assert not torch.equal(run(1000.0)[1], as_float[1])           # the value matters: T * background_depth is part of every depth pixel
+    for a, b, c in zip(as_float, as_tensor, as_double):
+        assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())  # gradients: atomics' summation order
+        assert torch.equal(a, c) or float((a - c).abs().max()) <= 1e-6 * float(a.abs().max())
+    assert torch.equal(as_float[0], as_tensor[0]) and torch.equal(as_float[1], as_tensor[1])

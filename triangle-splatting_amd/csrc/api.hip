@@ -154,6 +154,7 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.W = cam->width; r.H = cam->height; r.C = geom->C;
     r.grid_x = (cam->width + TS_TILE - 1) / TS_TILE; r.grid_y = (cam->height + TS_TILE - 1) / TS_TILE;
     r.gamma = geom->gamma; r.background_depth = geom->background_depth;
+    r.background_depth_dev = geom->background_depth_dev;
     r.background = geom->background;
     r.rich_info = flags & TS2D_FLAG_RICH_INFO;
     r.ablate = r.bwd_mfma = r.legacy_blend = 0;

@@ -309,7 +309,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
         if (a.C > 2) out_feature[2 * HW + pix] = ab + T * bg2;
         if (RICH)
         {
-            out_depth[pix] = ad + T * a.background_depth; // forward.cu:349
+            out_depth[pix] = ad + T * (a.background_depth_dev ? *a.background_depth_dev : a.background_depth); // forward.cu:349
             out_normal[pix] = anx;
             out_normal[HW + pix] = any_;
             out_normal[2 * HW + pix] = anz;
@@ -430,7 +430,7 @@ __global__ void __launch_bounds__(256, MFMA ? 4 : 7) render_bwd_kernel(RenderArg
         {
             dnx = dL_dout_normal[pix]; dny = dL_dout_normal[HW + pix]; dnz = dL_dout_normal[2 * HW + pix];
             dd = dL_dout_depth[pix];
-            B = fmaf(dd, a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
+            B = fmaf(dd, a.background_depth_dev ? *a.background_depth_dev : a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
         }
     }
     const int slot = slot_of_lane(lane);

@@ -246,7 +246,7 @@ __global__ void __launch_bounds__(256) render3d_fwd_kernel(RenderArgs a, float t
         if (a.C > 2) out_feature[2 * HW + pix] = ab + T * bg2;
         if (RICH)
         {
-            out_depth[pix] = ad + T * a.background_depth;
+            out_depth[pix] = ad + T * (a.background_depth_dev ? *a.background_depth_dev : a.background_depth);
             out_normal[pix] = anx;
             out_normal[HW + pix] = any_;
             out_normal[2 * HW + pix] = anz;
@@ -298,7 +298,7 @@ __global__ void __launch_bounds__(256) render3d_bwd_kernel(RenderArgs a, float t
         {
             dnx = dL_dout_normal[pix]; dny = dL_dout_normal[HW + pix]; dnz = dL_dout_normal[2 * HW + pix];
             dd = dL_dout_depth[pix];
-            B = fmaf(dd, a.background_depth, B);
+            B = fmaf(dd, a.background_depth_dev ? *a.background_depth_dev : a.background_depth, B);
         }
     }
     const int slot = slot_of_lane(lane), slot4 = slot4_of_lane(lane);

@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
         if (a.C > 2) out_feature[2 * HW + pix] = ab + T * bg2;
         if (RICH)
         {
-            out_depth[pix] = ad + T * a.background_depth;
+            out_depth[pix] = ad + T * (a.background_depth_dev ? *a.background_depth_dev : a.background_depth);
             out_normal[pix] = anx;
             out_normal[HW + pix] = any_;
             out_normal[2 * HW + pix] = anz;
@@ -435,7 +435,7 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
         {
             dnx = dL_dout_normal[pix]; dny = dL_dout_normal[HW + pix]; dnz = dL_dout_normal[2 * HW + pix];
             dd = dL_dout_depth[pix];
-            B = fmaf(dd, a.background_depth, B);
+            B = fmaf(dd, a.background_depth_dev ? *a.background_depth_dev : a.background_depth, B);
         }
     }
     float lm = (float)last;

@@ -382,7 +382,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
         if (a.C > 2) out_feature[2 * HW + pix] = ab + T * bg2;
         if (RICH)
         {
-            out_depth[pix] = ad + T * a.background_depth; // forward.cu:349
+            out_depth[pix] = ad + T * (a.background_depth_dev ? *a.background_depth_dev : a.background_depth); // forward.cu:349
             out_normal[pix] = anx;
             out_normal[HW + pix] = any_;
             out_normal[2 * HW + pix] = anz;
@@ -487,7 +487,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
         {
             dnx = dL_dout_normal[pix]; dny = dL_dout_normal[HW + pix]; dnz = dL_dout_normal[2 * HW + pix];
             dd = dL_dout_depth[pix];
-            B = fmaf(dd, a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
+            B = fmaf(dd, a.background_depth_dev ? *a.background_depth_dev : a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
         }
     }
     // The six colour / normal columns of the per-step reduction are (dL_dpixel constant) x contrib: their registers are filled

@@ -551,7 +551,7 @@ __global__ void __launch_bounds__(256, 6) render_fwd_q8_kernel(RenderArgs a, con
         if (a.C > 2) out_feature[2 * HW + pix] = ab + T * bg2;
         if (RICH)
         {
-            out_depth[pix] = ad + T * a.background_depth; // forward.cu:349
+            out_depth[pix] = ad + T * (a.background_depth_dev ? *a.background_depth_dev : a.background_depth); // forward.cu:349
             out_normal[pix] = anx;
             out_normal[HW + pix] = any_;
             out_normal[2 * HW + pix] = anz;
@@ -603,7 +603,7 @@ __global__ void __launch_bounds__(256, 5) render_bwd_q8_kernel(RenderArgs a, con
         {
             dnx = dL_dout_normal[pix]; dny = dL_dout_normal[HW + pix]; dnz = dL_dout_normal[2 * HW + pix];
             dd = dL_dout_depth[pix];
-            B = fmaf(dd, a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
+            B = fmaf(dd, a.background_depth_dev ? *a.background_depth_dev : a.background_depth, B); // accum_normal starts at 0, accum_depth at background_depth
         }
     }
     // Pre-swapped constant columns of group_reduce16c: with T(x, y) = x + 2 y over (r, g, b, nx) and this lane's bits b2 = lane & 4,

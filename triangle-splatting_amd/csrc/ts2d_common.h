@@ -231,6 +231,7 @@ struct RenderArgs
     int W, H, C, grid_x, grid_y;
     float gamma, background_depth;
     const float *background; // C floats, device
+    const float *background_depth_dev; // optional: one float on the device that overrides background_depth (ts2d_geometry)
     bool rich_info;
     int ablate; // profiling only (env TS2D_ABLATE, builds with -DTS2D_ABLATION): 0 = full kernel; see render.hip
     int legacy_blend; // measurement only (env TS2D_BLEND=wave, read once): round-1 one-triangle-per-wave blend kernels

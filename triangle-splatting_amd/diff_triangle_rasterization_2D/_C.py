@@ -52,7 +52,7 @@ class _Camera(C.Structure):
 class _Geometry(C.Structure):
     _fields_ = [("P", C.c_int32), ("sh_degree", C.c_int32), ("M", C.c_int32), ("C", C.c_int32),
                 ("gamma", C.c_float), ("scale_modifier", C.c_float), ("background_depth", C.c_float),
-                ("background", _fp), ("vertex", _fp), ("shs", _fp), ("feature", _fp), ("opacity", _fp)]
+                ("background", _fp), ("vertex", _fp), ("shs", _fp), ("feature", _fp), ("opacity", _fp), ("background_depth_dev", _fp)]
 
 
 class _ForwardOut(C.Structure):
@@ -159,9 +159,16 @@ def _f32_or_raise(*tensors):
 def _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M):
     cam = _Camera(int(W), int(H), float(tan_fovx), float(tan_fovy), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos))
+    # background_depth: a float like the reference's binding takes -- or a one-element float32 tensor on the device (what the reference's
+    # model computes every step, VanillaTS_model.py:623), handed to the kernels as a pointer: no device synchronisation for the conversion
+    bg_dev = None
+    if isinstance(background_depth, torch.Tensor):
+        if not (background_depth.is_cuda and background_depth.dtype == torch.float32 and background_depth.numel() == 1):
+            raise RuntimeError("background_depth must be a float or a one-element float32 tensor on the HIP device")
+        bg_dev, background_depth = background_depth.data_ptr(), 0.0
     geom = _Geometry(int(vertex.size(0)), int(sh_degree), int(M), int(Cn), float(gamma), float(scale_modifier),
                      float(background_depth), _ptr(background), _ptr(vertex), _ptr(shs) if use_shs else None,
-                     None if use_shs else _ptr(feature), _ptr(opacity))
+                     None if use_shs else _ptr(feature), _ptr(opacity), bg_dev)
     return cam, geom
 
 

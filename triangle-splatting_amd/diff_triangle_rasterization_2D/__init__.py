@@ -64,7 +64,7 @@ def _snapshot_on_error(tag: str, args: tuple, enabled: bool):
         raise
 
 
-def _camera_and_geometry_args(rs: TriangleRasterizationSettings, background_depth: float) -> tuple:
+def _camera_and_geometry_args(rs: TriangleRasterizationSettings, background_depth) -> tuple:
     """The ten settings-derived arguments that both native entry points share, in their positional order
     (tan_fovx .. background; R2D/src/extension_interface.h:7-62)."""
     return (
@@ -125,9 +125,17 @@ class _RasterizeTriangles(torch.autograd.Function):
     @staticmethod
     def forward(ctx, vertex, center2D, shs, feature, opacity, raster_settings):
         rs = raster_settings
-        # background_depth may arrive as a 0-dim device tensor (src/diff_recon/models/VanillaTS_model.py:623);
-        # pybind converts it to float in the reference, which is the same blocking read.
-        bg_depth = float(rs.background_depth)
+        # background_depth may arrive as a 0-dim device tensor (src/diff_recon/models/VanillaTS_model.py:623: max |campos - vertex|,
+        # computed on the device every step).  pybind converts it to float in the reference -- a full device synchronisation per forward
+        #  -- here a float32 tensor on the rasterizer's device goes to the kernels as a pointer and nothing waits.
+        bg_depth = rs.background_depth
+        if isinstance(bg_depth, torch.Tensor):
+            if bg_depth.is_cuda and bg_depth.device == vertex.device and bg_depth.numel() == 1:
+                bg_depth = bg_depth.detach().to(torch.float32).reshape(1).contiguous()  # no host round trip; same fp32 value
+            else:
+                bg_depth = float(bg_depth)
+        else:
+            bg_depth = float(bg_depth)
         native_args = (rs.image_width, rs.image_height) + _camera_and_geometry_args(rs, bg_depth) + (
             vertex, shs, feature, opacity, rs.back_culling, rs.rich_info, rs.debug)
         with _snapshot_on_error("rasterize_triangles", native_args, rs.debug):
