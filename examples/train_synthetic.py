@@ -56,14 +56,22 @@ class SyntheticModel(DensificationStats):
     named Adam groups (:119-135), the six statistics arrays (:196-201, inherited), gamma / active_sh_degree and the schedulers of
     _setup_model_update_utils (:150-194)."""
 
-    def __init__(self, vertex, f_dc, f_rest, raw_opacity, iters, max_sh_degree):
+    def __init__(self, vertex, f_dc, f_rest, raw_opacity, iters, max_sh_degree, single_sh=False):
         super().__init__(vertex.shape[0], vertex.device)
         self._vertex, self._opacity = torch.nn.Parameter(vertex), torch.nn.Parameter(raw_opacity)
-        self._f_dc, self._f_rest = torch.nn.Parameter(f_dc), torch.nn.Parameter(f_rest)
+        groups = [{"params": [self._vertex], "lr": 0.03, "name": "vertex"}, {"params": [self._opacity], "lr": 0.05, "name": "opacity"}]
+        if single_sh:
+            # ONE (P, M, 3) colour tensor with the two learning rates of the reference's f_dc / f_rest groups inside it (FusedAdam: lr for the
+            # first 3 floats of every triangle's 3 M, lr_tail for the rest): no torch.cat per forward, no split of its gradient per backward
+            self._shs = torch.nn.Parameter(torch.cat([f_dc, f_rest], 1).contiguous())
+            M = self._shs.shape[1]
+            groups.append({"params": [self._shs], "lr": 0.01, "lr_tail": 0.0005, "tail_period": 3 * M, "tail_split": 3, "name": "shs"})
+        else:
+            self._f_dc, self._f_rest = torch.nn.Parameter(f_dc), torch.nn.Parameter(f_rest)
+            groups += [{"params": [self._f_dc], "lr": 0.01, "name": "f_dc"}, {"params": [self._f_rest], "lr": 0.0005, "name": "f_rest"}]
+        self.single_sh = single_sh
         # the reference's torch.optim.Adam(l, lr=0.0, eps=1e-15) (VanillaTS_model.py:108-124) as one fused launch per step (include/ts_optim.h)
-        self.optimizer = D.FusedAdam([{"params": [self._vertex], "lr": 0.03, "name": "vertex"}, {"params": [self._opacity], "lr": 0.05, "name": "opacity"},
-                                           {"params": [self._f_dc], "lr": 0.01, "name": "f_dc"}, {"params": [self._f_rest], "lr": 0.0005, "name": "f_rest"}],
-                                          lr=0.0, eps=1e-15)
+        self.optimizer = D.FusedAdam(groups, lr=0.0, eps=1e-15)
         self.max_sh_degree, self.active_sh_degree, self.gamma = max_sh_degree, 0, 1.0
         self.scene_bbox, self.ste_threshold = None, None
         q = max(iters // 4, 1)
@@ -92,7 +100,7 @@ class SyntheticModel(DensificationStats):
 
 
 def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, seed=0, views=2, views_per_step=2, log=print, updates=True,
-          w_geometry=0.0):
+          w_geometry=0.0, single_sh=False):
     """w_geometry > 0 adds the depth / normal consistency term of the *_VanillaTS_mesh.yaml configurations (geometry_loss: w_geometry 0.05,
     scale_factor 0.5, from iteration start_iter on; VanillaTS_trainer.py:30-31,64-65,84,111) -- the producer of dL_dout_depth / dL_dout_normal."""
     dev = torch.device("cuda")
@@ -112,14 +120,16 @@ def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, se
     vertex = (t(s["vertex"]) + 1.5 * torch.randn(s["vertex"].shape, device=dev, generator=g))[keep].contiguous()
     n0 = vertex.shape[0]
     m = SyntheticModel(vertex, torch.full((n0, 1, 3), 0.5, device=dev), torch.zeros((n0, (D_sh + 1) ** 2 - 1, 3), device=dev),
-                       torch.zeros((n0, 1), device=dev), iters, D_sh)
+                       torch.zeros((n0, 1), device=dev), iters, D_sh, single_sh=single_sh)
     losses, t0 = [], time.perf_counter()
     for it in range(1, iters + 1):
         m.optimizer.zero_grad(set_to_none=True)
         pkgs, total = [], torch.zeros((), device=dev)  # the loss stays on the device: no host synchronisation inside an iteration
         for k in range(views_per_step):  # the views of one step: gradients are summed, like ranks' gradients in image-parallel training
             v = (it * views_per_step + k) % views
-            pkg = render_view(cams[v], m._vertex, m._f_dc, m._f_rest, m._opacity, is_training=True, gamma=m.gamma, active_sh_degree=m.active_sh_degree, **kw)
+            colour = dict(shs=m._shs) if m.single_sh else {}
+            pkg = render_view(cams[v], m._vertex, None if m.single_sh else m._f_dc, None if m.single_sh else m._f_rest, m._opacity, is_training=True,
+                              gamma=m.gamma, active_sh_degree=m.active_sh_degree, **colour, **kw)
             loss = photometric_loss(pkg["render"], gts[v], 0.8, 0.2)  # w_L1 = 1 - w_ssim, VanillaTS_trainer.py:72,111
             if geometry_loss is not None and it > g_start_iter:
                 loss = loss + w_geometry * geometry_loss(pkg["depth"], pkg["normal"], cams[v].tan_fovx, cams[v].tan_fovy)
@@ -146,9 +156,10 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=400)
     ap.add_argument("--triangles", type=int, default=20000)
     ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--single-sh-tensor", action="store_true", help="one (P, M, 3) colour parameter with two learning rates instead of f_dc + f_rest")
     ap.add_argument("--w-geometry", type=float, default=0.0, help="weight of the depth / normal consistency loss (0.05 in the *_VanillaTS_mesh configs)")
     a = ap.parse_args()
-    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views, w_geometry=a.w_geometry)
+    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views, w_geometry=a.w_geometry, single_sh=a.single_sh_tensor)
     for row in m.log:
         print("  update", row)
     print(f"{a.rasterizer}: loss {losses[0]:.5f} -> {losses[-1]:.5f} in {a.iters} iterations, {sec * 1e3:.2f} ms/iteration (incl. Python)")

@@ -40,3 +40,23 @@ def test_geometry_loss_feeds_depth_and_normal_gradients_in_the_loop():
     losses, m, _ = train_synthetic.train("3D", iters=80, triangles=3000, width=128, height=96, views=2, views_per_step=1, log=None, w_geometry=0.05)
     assert all(l == l for l in losses)
     assert min(losses[-10:]) < losses[0]
+
+
+def test_single_colour_tensor_trains_like_the_reference_layout():
+    """The MI355X-first layout of the colour parameters -- ONE (P, M, 3) tensor with the f_dc / f_rest learning rates inside it (FusedAdam lr /
+    lr_tail), no torch.cat per forward -- against the reference's two tensors: the same losses step by step (the arithmetic is the same; what
+    differs is the summation order of the float atomics), and the structural updates carry the single tensor and its moments along."""
+    import torch
+    import train_synthetic
+
+    kw = dict(iters=40, triangles=3000, width=128, height=96, views=2, views_per_step=1, log=None)
+    split, _, _ = train_synthetic.train("2D", updates=False, **kw)
+    one, _, _ = train_synthetic.train("2D", updates=False, single_sh=True, **kw)
+    for a, b in zip(split, one):
+        assert abs(a - b) <= 2e-3 * abs(a), (a, b)
+    assert min(one[-5:]) < 0.8 * one[0]
+    losses, m, _ = train_synthetic.train("2D", iters=160, triangles=4000, width=160, height=112, views=3, views_per_step=2, log=None, single_sh=True)
+    assert all(l == l for l in losses) and min(losses[-10:]) < 0.8 * losses[0]
+    P = m._vertex.shape[0]
+    assert m._shs.shape[0] == P and m.optimizer.state[m._shs]["exp_avg"].shape == m._shs.shape and torch.isfinite(m._shs).all()
+    assert {"densification", "opacity_pruning"} <= {name for _, name, _, _ in m.log}

@@ -20,6 +20,7 @@ ap.add_argument("--iters", type=int, default=60)
 ap.add_argument("--rasterizer", default="2D")
 ap.add_argument("--bg-depth-float", action="store_true")
 ap.add_argument("--torch-adam", action="store_true")
+ap.add_argument("--single-sh-tensor", action="store_true", help="one (P, M, 3) colour parameter (lr / lr_tail) instead of f_dc + f_rest: no cat per forward")
 a = ap.parse_args()
 
 import diff_recon_hip as D
@@ -36,6 +37,7 @@ if a.torch_adam:
     D.FusedAdam = torch.optim.Adam
 
 for warm in (True, False):
-    losses, m, sec = T.train(a.rasterizer, 8 if warm else a.iters, a.triangles, a.width, a.height, views=2, views_per_step=1, log=None, updates=False)
+    losses, m, sec = T.train(a.rasterizer, 8 if warm else a.iters, a.triangles, a.width, a.height, views=2, views_per_step=1, log=None, updates=False,
+                             single_sh=a.single_sh_tensor)
 print(f"triangles {a.triangles} {a.width}x{a.height} {a.rasterizer} bg_depth={'float (sync)' if a.bg_depth_float else 'device tensor'} "
-      f"adam={'torch' if a.torch_adam else 'fused'}: {sec * 1e3:.3f} ms/iteration, loss {losses[0]:.4f} -> {losses[-1]:.4f}")
+      f"adam={'torch' if a.torch_adam else 'fused'} colour={'one tensor' if a.single_sh_tensor else 'f_dc + f_rest'}: {sec * 1e3:.3f} ms/iteration, loss {losses[0]:.4f} -> {losses[-1]:.4f}")

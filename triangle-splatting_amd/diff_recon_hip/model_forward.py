@@ -46,8 +46,14 @@ def render_view(camera, vertex: torch.Tensor, f_dc: torch.Tensor, f_rest: torch.
                 bg_color: torch.Tensor, gamma: float = 1.0, active_sh_degree: int = 0, max_sh_degree: int = 3,
                 is_training: bool = True, back_culling: bool = False, gamma_rescale: bool = False,
                 ste_threshold: Optional[float] = None, render_up_scale: Optional[int] = None,
-                rasterizer_type: str = "3D") -> Dict[str, torch.Tensor]:
-    shs = torch.cat((f_dc, f_rest), dim=1)
+                rasterizer_type: str = "3D", shs: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """`shs` (P, M, 3): the colour coefficients as ONE tensor (then f_dc and f_rest are None) -- the layout that saves the reference's
+    torch.cat((f_dc, f_rest)) of every forward (VanillaTS_model.py:79-80: 2 x 12 M bytes per triangle moved per step, and again in its
+    backward); the reference's two tensors remain the default."""
+    if shs is None:
+        shs = torch.cat((f_dc, f_rest), dim=1)
+    elif f_dc is not None or f_rest is not None:
+        raise ValueError("pass either (f_dc, f_rest) or shs")
     opacity = torch.sigmoid(raw_opacity)
     v_render = rescale_triangles(vertex, gamma_rescale_ratio(gamma)) if gamma_rescale else vertex
     o_render = ste_opacity(opacity, ste_threshold) if ste_threshold is not None else opacity

@@ -107,7 +107,10 @@ class DensificationStats:
 # name by a one-line call.  Index logic that the reference itself expresses with torch (argsort /
 # unique in `_contribution_pruning`) stays torch; every per-row pass goes through include/ts_model.h.
 
-_PARAM_GROUPS = ("vertex", "opacity", "f_dc", "f_rest")  # the groups that carry one row per triangle (:217-218 skips the affine ones)
+# the groups that carry one row per triangle (:217-218 skips the affine ones).  "shs" = the MI355X-first layout of the colour parameters: ONE
+# (P, M, 3) tensor `_shs` in place of `_f_dc` + `_f_rest` (no torch.cat per forward, VanillaTS_model.py:79-80; the two learning rates live in
+# the FusedAdam group as lr / lr_tail, diff_recon_hip/optim.py) -- a model carries either the reference's two groups or this one
+_PARAM_GROUPS = ("vertex", "opacity", "f_dc", "f_rest", "shs")
 
 
 def _stream():
