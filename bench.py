@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scene-mode", default="frustum", choices=["frustum", "centered", "maincu"],
+                    help="frustum = SURVEY 8d's uniform scene (the headline); centered = the same triangles concentrated about the optical axis "
+                         "(object-centric view, non-uniform load over the tiles); NOT the headline when changed")
     ap.add_argument("--settle-steps", type=int, default=40,
                     help="untimed steps in front of the W warm-up steps (0 = none): ~70 ms of load bring the device's clocks up; what matters is that "
                          "NOTHING sits between the last warm-up step and the timed region (see the sequence comment in main)")
@@ -145,7 +148,7 @@ def main():
             raise SystemExit("--force-depth-pass4 needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
         _C._lib.ts2d_lab_force_depth_pass4(1)
     P, W, H, D = args.triangles, args.width, args.height, args.sh_degree
-    s = synthetic.scene(P, W, H, D, seed=42)
+    s = synthetic.scene(P, W, H, D, seed=42, mode=args.scene_mode)
     # one view per rank: same triangles, camera shifted sideways by a few world units per rank
     cam = synthetic.camera(W, H)
     if rank > 0:
@@ -354,7 +357,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
-                   "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N,
+                   "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N, "scene_mode": args.scene_mode,
                    "forward": ("sync-free (ts2d_forward, device-side instance count)" if args.sync_free else
                                "speculative (ts2d_forward_speculative: queued for 1.25 x the recent instance count, exact num_rendered read back "
                                "behind the queue; the package default)"),

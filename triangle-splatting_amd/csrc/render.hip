@@ -149,7 +149,8 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
     __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CSTF];
     __shared__ float stage_all[RICH ? 4 : 1][8][64];
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
@@ -394,7 +395,8 @@ __global__ void __launch_bounds__(256, MFMA ? 4 : 7) render_bwd_kernel(RenderArg
     __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CST];
     __shared__ __attribute__((aligned(16))) float tile_all[MFMA ? 4 : 1][MFMA ? MROWS * MRS : 4];
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
@@ -692,7 +694,7 @@ void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const
                           const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
                           float *contrib_sum, float *contrib_max, hipStream_t s)
 {
-    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y ? ts_tile_units(a.grid_x, a.grid_y) : 0));
     if (grid.x == 0) return;
     TS_DISPATCH(render_fwd_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, out_feature, out_depth,
                 out_normal, contrib_sum, contrib_max);
@@ -702,7 +704,7 @@ void ts_launch_render_bwd(const RenderArgs &a, const GeometryStateView &g, const
                           const ImageStateView &im, const float *dL_dout_feature, const float *dL_dout_depth,
                           const float *dL_dout_normal, float *grad_rec, hipStream_t s)
 {
-    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y ? ts_tile_units(a.grid_x, a.grid_y) : 0));
     if (grid.x == 0) return;
     if (!a.bwd_mfma) // default: cross-lane (permlane / DPP) reduction networks; TS2D_BWD=mfma selects the matrix-core variant
         TS_DISPATCH_BWD(false, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature, dL_dout_depth,

@@ -112,7 +112,8 @@ __global__ void __launch_bounds__(256) render3d_fwd_kernel(RenderArgs a, float t
     __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CS3F];
     __shared__ float stage_all[RICH ? 4 : 1][8][64];
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
@@ -266,7 +267,8 @@ __global__ void __launch_bounds__(256) render3d_bwd_kernel(RenderArgs a, float t
 {
     __shared__ __attribute__((aligned(16))) float cst_all[4][64 * CS3B];
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int X0 = tx * TS_TILE + (wave & 1) * 8, Y0 = ty * TS_TILE + (wave >> 1) * 8;
@@ -470,7 +472,7 @@ void ts_launch_render3d_fwd(const RenderArgs &a, float tan_fovx, float tan_fovy,
                             const BinningStateView &b, const ImageStateView &im, float *out_feature, float *out_depth,
                             float *out_normal, float *contrib_sum, float *contrib_max, hipStream_t s)
 {
-    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y ? ts_tile_units(a.grid_x, a.grid_y) : 0));
     if (grid.x == 0) return;
     TS_DISPATCH3(render3d_fwd_kernel, a, tan_fovx, tan_fovy, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, out_feature,
                  out_depth, out_normal, contrib_sum, contrib_max);
@@ -480,7 +482,7 @@ void ts_launch_render3d_bwd(const RenderArgs &a, float tan_fovx, float tan_fovy,
                             const BinningStateView &b, const ImageStateView &im, const float *dL_dout_feature,
                             const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec, hipStream_t s)
 {
-    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y ? ts_tile_units(a.grid_x, a.grid_y) : 0));
     if (grid.x == 0) return;
     TS_DISPATCH3(render3d_bwd_kernel, a, tan_fovx, tan_fovy, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib,
                  dL_dout_feature, dL_dout_depth, dL_dout_normal, grad_rec);

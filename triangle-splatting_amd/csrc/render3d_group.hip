@@ -200,7 +200,8 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
     __shared__ unsigned long long tsum[RICH ? TCAP : 1]; // 16.48 fixed point (ts2d_group.h)
     __shared__ int tmax[RICH ? TCAP : 1];
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane >> 4, sub = lane & 15;
@@ -390,17 +391,19 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
     int tile, quad, wave;
     if (WPB == 4)
     {
-        tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+        tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
         quad = wave = threadIdx.x >> 6;
     }
     else
     {
-        const int ntiles = a.grid_x * a.grid_y, q8 = ntiles >> 3, r8 = ntiles & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        if ((j >> 2) >= q8 + (x < r8 ? 1 : 0)) return; // the grid is padded to the longest band
-        tile = x * q8 + min(x, r8) + (j >> 2);
+        // single-wave workgroups: four consecutive units of an XCD are the four quadrants of one tile (they stay neighbours in dispatch order
+        // and on one XCD: shared L2 for the tile's list and records)
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = tile_of_block(((j >> 2) << 3) | x, a.grid_x, a.grid_y);
         quad = j & 3;
         wave = 0;
     }
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 4, sub = lane & 15;
@@ -611,8 +614,8 @@ void ts_launch_render3d_fwd_group(const RenderArgs &a, float tan_fovx, float tan
                                   const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal, float *contrib_sum,
                                   float *contrib_max, hipStream_t s)
 {
-    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
-    if (grid.x == 0) return;
+    if (a.grid_x * a.grid_y == 0) return;
+    const dim3 grid((unsigned)ts_tile_units(a.grid_x, a.grid_y));
     TS_DISPATCH_G3(render3d_fwd_group_kernel, a, tan_fovx, tan_fovy, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, out_feature, out_depth,
                    out_normal, contrib_sum, contrib_max);
 }
@@ -624,8 +627,7 @@ void ts_launch_render3d_bwd_group(const RenderArgs &a, float tan_fovx, float tan
     const dim3 grid((unsigned)(a.grid_x * a.grid_y));
     if (grid.x == 0) return;
     constexpr int WPB = 1;
-    const int ntiles = a.grid_x * a.grid_y;
-    const dim3 grid1((unsigned)(WPB == 4 ? ntiles : 8 * 4 * ((ntiles + 7) / 8)));
+    const dim3 grid1((unsigned)((WPB == 4 ? 1 : 4) * ts_tile_units(a.grid_x, a.grid_y))); // padded: units past the image return at once
     const bool g1 = (a.gamma == 1.0f);
 #define TS_BWD3(R, G) hipLaunchKernelGGL((render3d_bwd_group_kernel<R, G, WPB>), grid1, dim3(64 * WPB), 0, s, a, tan_fovx, tan_fovy, im.ranges, b.vals, \
                                          g.rec, im.final_T, im.n_contrib, dL_dout_feature, dL_dout_depth, dL_dout_normal, grad_rec)

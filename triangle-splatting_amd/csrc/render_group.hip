@@ -200,7 +200,8 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
     if (a.W < 0) pad_lds[threadIdx.x] = 1, atomicAdd(&tmax[0], pad_lds[255 - threadIdx.x]);
 #endif
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int grp = lane >> 4, sub = lane & 15;
@@ -444,18 +445,19 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
     int tile, quad, wave; // quad = which 8x8 quadrant of the tile, wave = index into this workgroup's LDS arrays
     if (WPB == 4)
     {
-        tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+        tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
         quad = wave = threadIdx.x >> 6;
     }
     else
     {
-        // block b runs on XCD b % 8 (observed; used for locality only): that XCD's j-th block is quadrant j & 3 of the (j >> 2)-th tile of its band
-        const int ntiles = a.grid_x * a.grid_y, q8 = ntiles >> 3, r8 = ntiles & 7, x = blockIdx.x & 7, j = blockIdx.x >> 3;
-        if ((j >> 2) >= q8 + (x < r8 ? 1 : 0)) return; // the grid is padded to the longest band
-        tile = x * q8 + min(x, r8) + (j >> 2);
+        // single-wave workgroups: four consecutive units of an XCD are the four quadrants of one tile (they stay neighbours in dispatch order
+        // and on one XCD: shared L2 for the tile's list and records)
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        tile = tile_of_block(((j >> 2) << 3) | x, a.grid_x, a.grid_y);
         quad = j & 3;
         wave = 0;
     }
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int lane = threadIdx.x & 63;
     const int grp = lane >> 4, sub = lane & 15;
@@ -704,8 +706,8 @@ void ts_launch_render_fwd_group(const RenderArgs &a, const GeometryStateView &g,
                                 float *out_feature, float *out_depth, float *out_normal, float *contrib_sum, float *contrib_max,
                                 hipStream_t s)
 {
-    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
-    if (grid.x == 0) return;
+    if (a.grid_x * a.grid_y == 0) return;
+    const dim3 grid((unsigned)ts_tile_units(a.grid_x, a.grid_y));
     TS_DISPATCH_G(render_fwd_group_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, out_feature, out_depth, out_normal,
                   contrib_sum, contrib_max);
 }
@@ -730,8 +732,7 @@ void ts_launch_render_bwd_group(const RenderArgs &a, const GeometryStateView &g,
     const dim3 grid((unsigned)(a.grid_x * a.grid_y));
     if (grid.x == 0) return;
     constexpr int WPB = 1;
-    const int ntiles = a.grid_x * a.grid_y;
-    const dim3 grid1((unsigned)(WPB == 4 ? ntiles : 8 * 4 * ((ntiles + 7) / 8)));
+    const dim3 grid1((unsigned)((WPB == 4 ? 1 : 4) * ts_tile_units(a.grid_x, a.grid_y))); // padded: units past the image return at once
     const bool g1 = (a.gamma == 1.0f);
 #define TS_BWD(R, G) hipLaunchKernelGGL((render_bwd_group_kernel<R, G, WPB>), grid1, dim3(64 * WPB), 0, s, a, im.ranges, b.vals, g.rec, im.final_T, \
                                         im.n_contrib, dL_dout_feature, dL_dout_depth, dL_dout_normal, grad_rec)

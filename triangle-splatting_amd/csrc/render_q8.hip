@@ -347,7 +347,8 @@ __global__ void __launch_bounds__(256, 6) render_fwd_q8_kernel(RenderArgs a, con
     __shared__ unsigned long long tsum[RICH ? TCAP : 1]; // 16.48 fixed point
     __shared__ int tmax[RICH ? TCAP : 1];
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane >> 4, sub = lane & 15;
@@ -571,7 +572,8 @@ __global__ void __launch_bounds__(256, 5) render_bwd_q8_kernel(RenderArgs a, con
 {
     __shared__ __attribute__((aligned(16))) char smem[4 * BWAVE];
 
-    const int tile = tile_of_block(blockIdx.x, a.grid_x * a.grid_y);
+    const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
+    if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = lane >> 4, sub = lane & 15;
@@ -858,7 +860,7 @@ __global__ void __launch_bounds__(256, 5) render_bwd_q8_kernel(RenderArgs a, con
 void ts_launch_render_fwd_q8(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                              float *out_feature, float *out_depth, float *out_normal, float *contrib_sum, float *contrib_max, hipStream_t s)
 {
-    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y ? ts_tile_units(a.grid_x, a.grid_y) : 0));
     if (grid.x == 0) return;
     TS_DISPATCH_Q8(render_fwd_q8_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, out_feature, out_depth, out_normal, contrib_sum,
                    contrib_max);
@@ -867,7 +869,7 @@ void ts_launch_render_fwd_q8(const RenderArgs &a, const GeometryStateView &g, co
 void ts_launch_render_bwd_q8(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                              const float *dL_dout_feature, const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec, hipStream_t s)
 {
-    const dim3 grid((unsigned)(a.grid_x * a.grid_y));
+    const dim3 grid((unsigned)(a.grid_x * a.grid_y ? ts_tile_units(a.grid_x, a.grid_y) : 0));
     if (grid.x == 0) return;
     TS_DISPATCH_Q8(render_bwd_q8_kernel, a, im.ranges, b.vals, g.rec, im.final_T, im.n_contrib, dL_dout_feature, dL_dout_depth, dL_dout_normal,
                    grad_rec);

@@ -168,13 +168,34 @@ __device__ __forceinline__ float pow_nonneg(float x, float y)
 }
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
-// blockIdx -> tile so that each XCD (block b runs on XCD b % 8) owns one contiguous band of row-major tiles:
-// neighbouring tiles gather mostly the same triangle records, which then stay in that XCD's 4 MiB L2.
-__device__ __forceinline__ int tile_of_block(int b, int ntiles)
+// blockIdx -> tile.  Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8) and an XCD never takes over another
+// one's blocks, so the mapping decides two things: which tiles share an L2 (neighbouring tiles gather mostly the same triangle records),
+// and how evenly the WORK is spread over the XCDs.
+//   TS2D_XCD_BANDS (rounds 1-3): XCD x owns one contiguous band of row-major tiles (a ninth of the image height at 1080p).  Best locality,
+//     but a view whose content sits in the middle of the image (an object-centric capture) leaves the XCDs of the top and bottom bands idle.
+//   default (round 4): XCD x owns the tile ROWS x, x + 8, x + 16, ... of the first 8 floor(rows / 8) rows -- every XCD samples the whole
+//     image height, horizontal neighbours still share an L2 (a row of 120 tiles at 1080p), vertical neighbours are fetched by two XCDs --
+//     and an eighth of the tiles of the remaining rows (68 rows at 1080p: XCDs with nine rows against XCDs with eight would cost the
+//     uniform scene 6 %).  Measured (profiles/r04_notes.md): the same triangles concentrated about the optical axis 1.00 instead of 1.52 ms
+//     per step; the uniform headline scene within 1 % of the bands.
+// Every XCD gets ceil(ntiles / 8) units; a unit past its share returns -1 (the grid is padded to 8 x that).
+static inline int ts_tile_units(int grid_x, int grid_y) { return 8 * ((grid_x * grid_y + 7) / 8); }
+#ifdef TS2D_XCD_BANDS
+__device__ __forceinline__ int tile_of_block(int b, int grid_x, int grid_y)
 {
-    const int q = ntiles >> 3, r = ntiles & 7, x = b & 7, i = b >> 3;
-    return x * q + min(x, r) + i;
+    const int ntiles = grid_x * grid_y, q = ntiles >> 3, r = ntiles & 7, x = b & 7, i = b >> 3;
+    return i < q + (x < r ? 1 : 0) ? x * q + min(x, r) + i : -1;
 }
+#else
+__device__ __forceinline__ int tile_of_block(int b, int grid_x, int grid_y)
+{
+    const int x = b & 7, i = b >> 3;
+    const int rows8 = grid_y >> 3, full = rows8 * grid_x; // units of an XCD that are whole rows
+    if (i < full) return (x + 8 * (i / grid_x)) * grid_x + i % grid_x;
+    const int rest = (grid_y & 7) * grid_x, q = rest >> 3, r = rest & 7, k = i - full; // the last grid_y % 8 rows, shared out tile by tile
+    return k < q + (x < r ? 1 : 0) ? 8 * full + x * q + min(x, r) + k : -1;
+}
+#endif
 
 // ---- reduce4: 4 values per lane x 64 lanes -> every lane of row r returns the complete sum of value map[r] ----
 __device__ __forceinline__ float reduce4(float x0, float x1, float x2, float x3)

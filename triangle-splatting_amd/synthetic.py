@@ -48,6 +48,8 @@ def scene(P: int, W: int, H: int, D: int = 3, seed: int = 42, edge_px: float = 6
     mode="frustum": centroids fill the view frustum at z in [0,200], sigma chosen for a mean projected
                     edge of `edge_px` pixels.
     mode="maincu":  every vertex uniform in the whole box of R2D/main.cu:29 (huge triangles; stress case).
+    mode="centered": like "frustum" but the centroids are concentrated about the optical axis (an object in the middle of the image,
+                    empty borders): the load is far from uniform over the tiles.
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     cam = camera(W, H)
@@ -60,8 +62,16 @@ def scene(P: int, W: int, H: int, D: int = 3, seed: int = 42, edge_px: float = 6
     else:
         z = rng.random((P, 1), dtype=np.float32) * 200.0
         zv = CAM_DIST - z  # view-space depth of the centroid
-        cx = (rng.random((P, 1), dtype=np.float32) * 2 - 1) * (zv * tx)
-        cy = (rng.random((P, 1), dtype=np.float32) * 2 - 1) * (zv * ty)
+        if mode == "centered":
+            # an object-centric view (NeRF-synthetic-like): centroids normally distributed about the optical axis, sigma = 0.2 of the half
+            # extent, clipped to the frustum -- the middle of the image carries most of the work, the borders almost none
+            ux = np.clip(rng.standard_normal((P, 1), dtype=np.float32) * np.float32(0.2), -1, 1)
+            uy = np.clip(rng.standard_normal((P, 1), dtype=np.float32) * np.float32(0.2), -1, 1)
+        else:
+            ux = rng.random((P, 1), dtype=np.float32) * 2 - 1
+            uy = rng.random((P, 1), dtype=np.float32) * 2 - 1
+        cx = ux * (zv * tx)
+        cy = uy * (zv * ty)
         centroid = np.concatenate([cx, cy, z], axis=1)[:, None, :]
         px_per_unit = 0.5 * W / ((CAM_DIST - 100.0) * tx)
         sigma = edge_px / (math.sqrt(math.pi) * px_per_unit)  # E|edge_2D| = sqrt(pi) * sigma for N(0, 2 sigma^2 I_2)
