@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gamma", type=float, default=1.0,
+                    help="the reference's compactness exponent (scheduled 1 -> 50 during training, VanillaTS_model.py:549-554); 1 = the headline "
+                         "(SURVEY 8d), anything else is NOT the headline: the blend kernels then evaluate ecc^(2 gamma) with a log / exp pair")
     ap.add_argument("--scene-mode", default="frustum", choices=["frustum", "centered", "maincu"],
                     help="frustum = SURVEY 8d's uniform scene (the headline); centered = the same triangles concentrated about the optical axis "
                          "(object-centric view, non-uniform load over the tiles); NOT the headline when changed")
@@ -161,7 +164,7 @@ def main():
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     rs = TriangleRasterizationSettings(
         image_width=W, image_height=H, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], viewmatrix=t(cam["viewmatrix"]),
-        projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]), sh_degree=D, gamma=1.0, scale_modifier=1.0,
+        projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]), sh_degree=D, gamma=args.gamma, scale_modifier=1.0,
         background_depth=5000.0, background=t(s["background"]), back_culling=False, rich_info=True, debug=False)
     raster = TriangleRasterizer(rs)
     vertex = t(s["vertex"]).requires_grad_(True)
@@ -356,7 +359,7 @@ def main():
         "value": round(mpix_s, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma=1): fwd+bwd of one view per GPU",
+        "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma={args.gamma:g}): fwd+bwd of one view per GPU",
                    "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N, "scene_mode": args.scene_mode,
                    "forward": ("sync-free (ts2d_forward, device-side instance count)" if args.sync_free else
                                "speculative (ts2d_forward_speculative: queued for 1.25 x the recent instance count, exact num_rendered read back "
