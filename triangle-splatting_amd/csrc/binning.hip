@@ -650,8 +650,8 @@ void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32
 // buffer for the pass after this one.  Every block reads the totals of all slabs, so sorts of more than TS_DIRECT_MAX_SLABS slabs (12.6 M
 // pairs at 4096 per chunk) keep the hierarchical pass, whose cost does not grow with the slab count.
 // g_force_tickets: a lab-library switch (csrc/ts2d_lab.h, ts2d_lab_force_ticket_passes; the symbol is not exported and nothing in the product
-// library sets it): every sort and the scan take the hierarchical passes that otherwise only scenes of more than ~6 M triangles reach, so that
-// the suite executes them -- including the ticket-path census that produces num_rendered there.
+// library sets it): every sort takes the hierarchical passes that otherwise only sorts of more than 48 slabs reach (> 6.3 M triangles, > 12.6 M
+// instances), so that the suite executes them -- including the ticket-path census that produces num_rendered there.
 bool g_force_tickets = false;
 bool g_force_pass4 = false; // same kind of switch (ts2d_lab_force_depth_pass4): the depth sort never skips its fourth pass
 bool radix_direct_ok(const RadixScratchView &r) { return !g_force_tickets && r.slabs <= TS_DIRECT_MAX_SLABS; }
@@ -669,10 +669,13 @@ void radix_pass_direct(const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
 // ---- step 2: tiles_sorted = tiles_touched[perm], 64-bit block sums, their prefix, N ---------------------------------------
 constexpr int SB = 1024; // triangles per scan block (256 threads x 4)
 
-// DIRECT (round 3): the block sums stay raw and nobody waits for a last block; every emission block adds up the sums in front of it itself
-// (scan_emit_kernel<true>; blocksum[nblocks] = N is already there from the depth sort's census).
-template <bool DIRECT>
-__global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometryStateView g, uint32_t *ticket)
+// The block sums stay RAW and nobody waits for a last block (round 3): every emission block adds up the sums in front of it itself
+// (blocksum[nblocks] = N is already there from the depth sort's census): up to 2048 of them (2 M triangles), eight loads per thread.  Beyond
+// that (round 4) a second level `supersum` holds the sum of every 64 consecutive block sums (fire-and-forget 64-bit atomics, zeroed by the
+// step's first launch), so an emission block adds at most nblocks / 64 + 63 values at any size.  Until then such scenes fell back to an
+// elected block that turned the sums into their prefix -- one same-address ticket atomic per block, 4883 in a row at 5 M triangles: scan
+// 0.113 -> 0.087 ms there.  (Below 2048 blocks the atomics cost more than they save: 13 -> 18 us at 1 M triangles, hence the two forms.)
+__global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometryStateView g, bool two_level)
 {
     __shared__ unsigned long long wsum[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -694,50 +697,12 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if (lane == 0) wsum[wave] = sum;
     __syncthreads();
-    const int nblocks = gridDim.x;
-    if (DIRECT)
+    if (t == 0)
     {
-        if (t == 0) g.blocksum[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        return;
+        const unsigned long long total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        g.blocksum[blockIdx.x] = total;
+        if (two_level && total) __hip_atomic_fetch_add((unsigned long long *)g.supersum + (blockIdx.x >> 6), total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (t == 0) peer_store((unsigned long long *)g.blocksum + blockIdx.x, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
-    if (!last_arrival(ticket, (uint32_t)nblocks)) return;
-    // the last block to finish turns the block sums into their exclusive prefix; blocksum[nblocks] = N
-    __shared__ unsigned long long carry;
-    if (t == 0) carry = 0;
-    __syncthreads();
-    for (int b00 = 0; b00 < nblocks; b00 += 256 * 8)
-    {
-        // eight rounds' block sums are requested together (this block is alone on the critical path: one memory round trip, not eight)
-        unsigned long long xs[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) xs[k] = (b00 + 256 * k + t < nblocks) ? peer_load((const unsigned long long *)g.blocksum + b00 + 256 * k + t) : 0ull;
-#pragma unroll
-        for (int k = 0; k < 8; k++)
-        {
-            const int b0 = b00 + 256 * k;
-            if (b0 >= nblocks) break;
-            const int b = b0 + t;
-            const unsigned long long x = xs[k];
-            // inclusive scan over the 256 threads: inside the wave by shuffles, across the four waves through LDS
-            unsigned long long inc = x;
-            for (int o = 1; o < 64; o <<= 1)
-            {
-                const unsigned long long y = __shfl_up(inc, o);
-                if (lane >= o) inc += y;
-            }
-            if (lane == 63) wsum[wave] = inc;
-            __syncthreads();
-            unsigned long long wbase = 0;
-            for (int w = 0; w < wave; w++) wbase += wsum[w];
-            const unsigned long long c = carry;
-            if (b < nblocks) g.blocksum[b] = c + wbase + inc - x;
-            __syncthreads();
-            if (t == 255) carry = c + wbase + inc;
-            __syncthreads();
-        }
-    }
-    if (t == 0) g.blocksum[nblocks] = carry;
 }
 
 // ---- step 3: instance slots + emission ------------------------------------------------------------------------------------------
@@ -747,9 +712,8 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
 // (rasterizer.cu:63-73); the later sort is by tile id, so only the order BETWEEN triangles matters.
 constexpr uint32_t SMALL = 32;
 
-template <bool DIRECT>
 __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
-                                                         float *contrib_sum, float *contrib_max, long long capacity, int32_t *status)
+                                                         float *contrib_sum, float *contrib_max, long long capacity, int32_t *status, bool two_level)
 {
     __shared__ uint32_t wtot[4];
     __shared__ unsigned long long wpart[4];
@@ -771,11 +735,15 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     uint32_t tiles = valid ? g.tiles_sorted[i] : 0u;
     const uint32_t id_ahead = valid ? sorted_ids(g)[i] : 0u; // wanted after the scan: requested now, one round trip less behind it
     // Everything in front of this block, requested together and reduced once: the earlier quarters of this scan block (scan blocks are 1024
-    // triangles = four of these 256-lane blocks) and -- DIRECT -- the raw sums of the scan blocks before it.
+    // triangles = four of these 256-lane blocks), the raw sums of the scan blocks of its group of 64, the group sums in front of that.
     const int sblock = blockIdx.x >> 2, quarter = blockIdx.x & 3;
     unsigned long long part = 0;
-    const unsigned long long scanned = DIRECT ? 0ull : g.blocksum[sblock]; // ticket path: the exclusive prefix is already there
-    if (DIRECT)
+    if (two_level)
+    {
+        for (int k = t; k < (sblock >> 6); k += 256) part += g.supersum[k];
+        if (t < (sblock & 63)) part += g.blocksum[(sblock & ~63) + t];
+    }
+    else
         for (int k = t; k < sblock; k += 256) part += g.blocksum[k];
     for (int q = 0; q < quarter; q++)
     {
@@ -798,7 +766,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     __syncthreads();
     uint32_t before = 0;
     for (int w = 0; w < wave; w++) before += wtot[w];
-    const unsigned long long qbase = scanned + wpart[0] + wpart[1] + wpart[2] + wpart[3];
+    const unsigned long long qbase = wpart[0] + wpart[1] + wpart[2] + wpart[3];
     const uint32_t incl = (uint32_t)(qbase + before + inc); // N < 2^31 is checked on the host before anything is emitted
     if (valid) g.offsets[i] = incl;
     uint2 rect = {0u, 0u};
@@ -962,27 +930,21 @@ void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t 
     radix_pass_direct(g.sk[0], g.sv[0], g.sk[1], g.sv[1], P, nullptr, 24, 8, g.rs, 1, s, g.top_const);
 }
 
-// Every emission block adds up the raw block sums in front of it (up to 8 per thread); beyond that the elected-block prefix pays off again.
-static bool scan_direct_ok(int32_t P) { return !g_force_tickets && (P + SB - 1) / SB <= 2048; }
-// Step 2: tiles_sorted = tiles_touched[perm], block sums (-> exclusive prefix on the ticket path), blocksum[nblocks] = N.
+// Step 2: tiles_sorted = tiles_touched[perm], raw block sums (+ their groups' sums above 2048 blocks, or always under the lab library's
+// ts2d_lab_force_ticket_passes, so that the suite runs the two-level form on small scenes); blocksum[nblocks] = N comes from the census.
+static bool scan_two_level(int32_t P) { return g_force_tickets || (P + SB - 1) / SB > 2048; }
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
     if (P <= 0) return;
-    const int nblocks = (P + SB - 1) / SB;
-    if (scan_direct_ok(P)) hipLaunchKernelGGL(gather_blocksum_kernel<true>, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, g.rs.tickets + 1);
-    else hipLaunchKernelGGL(gather_blocksum_kernel<false>, dim3((unsigned)nblocks), dim3(256), 0, s, P, g, g.rs.tickets + 1);
+    hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)((P + SB - 1) / SB)), dim3(256), 0, s, P, g, scan_two_level(P));
 }
 
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                          float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s)
 {
     if (P <= 0) return;
-    if (scan_direct_ok(P))
-        hipLaunchKernelGGL(scan_emit_kernel<true>, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges,
-                           contrib_sum, contrib_max, (long long)capacity, status);
-    else
-        hipLaunchKernelGGL(scan_emit_kernel<false>, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges,
-                           contrib_sum, contrib_max, (long long)capacity, status);
+    hipLaunchKernelGGL(scan_emit_kernel, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges, contrib_sum,
+                       contrib_max, (long long)capacity, status, scan_two_level(P));
 }
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P) { return (const unsigned long long *)(g.blocksum + (P + SB - 1) / SB); }
 

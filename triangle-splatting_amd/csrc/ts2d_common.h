@@ -66,7 +66,8 @@ struct GeometryStateView
                              // their top byte, the 4th pass was skipped and the order is in sk[0] / sv[0] (binning.hip, sorted_ids())
     uint32_t *tiles_sorted;  // P   tiles_touched[perm[i]]
     uint32_t *offsets;       // P   inclusive prefix sum of tiles_sorted: instance slots of the i-th nearest triangle
-    uint64_t *blocksum;      // ceil(P / 1024) + 2   per-block sums of tiles_sorted, then their exclusive prefix; [nblocks] = N
+    uint64_t *blocksum;      // ceil(P / 1024) + 2   raw per-block sums of tiles_sorted; [nblocks] = N (scratch of the depth sort's census before that)
+    uint64_t *supersum;      // ceil(nblocks / 64) + 1   sums of 64 consecutive block sums (atomics; zeroed by the step's first launch)
     RadixScratchView rs;
 };
 
@@ -128,6 +129,7 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.tiles_sorted, n);
     ts_carve(p, v.offsets, n);
     ts_carve(p, v.blocksum, (n + 1023) / 1024 + 2);
+    ts_carve(p, v.supersum, ((n + 1023) / 1024 + 63) / 64 + 1);
     ts_carve_radix(p, n, v.rs, TS_RS_CHUNK_SMALL);
     v.top_const = v.rs.tickets + v.rs.slabs + 4;
     return (size_t)(p - base) + TS_ALIGN;
@@ -215,7 +217,7 @@ void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const Geo
 // binning.hip -- every step hand-written for gfx950 (the round-1 rocPRIM calls survive only as test comparators)
 void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s); // first histogram + N + key-bit census
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s);          // the rest: (depth bits, id) -> sorted ids
-void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);                  // tiles_sorted, block sums, N
+void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);                  // tiles_sorted, block sums + their groups' sums
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                          float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P);                        // where the scan leaves N

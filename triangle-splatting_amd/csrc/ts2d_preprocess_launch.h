@@ -19,19 +19,21 @@ namespace ts
 {
 // The binning kernels' "last block finishes" tickets (binning.hip) are zeroed by the first launch of the step.  Every grid has at
 // least 64 threads and slabs + TS_RS_TICKET_EXTRA <= max(P, 64), so the threads beyond P of a tiny scene take part.  The slab totals of the
-// depth sort's first (ticket-free) histogram are cleared here as well.
-__device__ __forceinline__ void clear_tickets(const GeometryStateView &g, int idx)
+// depth sort's first (ticket-free) histogram and the group sums of the scan are cleared here as well.
+__device__ __forceinline__ void clear_tickets(const GeometryStateView &g, int idx, int P)
 {
     if (idx < g.rs.slabs + TS_RS_TICKET_EXTRA) g.rs.tickets[idx] = 0u;
     const int nthreads = (int)(gridDim.x * blockDim.x);
     for (int k = idx; k < g.rs.slabs * TS_RS_BINS; k += nthreads) g.rs.slabacc[0][k] = 0u;
+    const int groups = (((P + 1023) >> 10) + 63) >> 6; // the scan's second level (binning.hip): one sum per 64 scan blocks of 1024 triangles
+    for (int k = idx; k < groups + 1; k += nthreads) g.supersum[k] = 0ull;
 }
 
 template <class Body>
 __global__ void __launch_bounds__(256) preprocess_fwd_direct_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
 {
     const int idx = blockIdx.x * 256 + threadIdx.x;
-    clear_tickets(g, idx);
+    clear_tickets(g, idx, a.P);
     if (idx >= a.P) return;
     Body::fwd(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr, g.rec + 4 * (size_t)idx);
 }
@@ -56,7 +58,7 @@ __global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArg
     stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
     if (SHROW > 0 && !SH_REGS) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
     __syncthreads();
-    clear_tickets(g, idx);
+    clear_tickets(g, idx, a.P);
     // the 64 render records of the workgroup are one contiguous 4 KB block: each lane parks its record in LDS (row stride 80 bytes:
     // conflict-free 128-bit accesses) and the block leaves with coalesced dwordx4 stores instead of four stores at a 64-byte lane stride
     __shared__ float4 s_rec[64 * 5];
