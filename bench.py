@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--edge-px", type=float, default=6.0, help="mean projected triangle edge in pixels (SURVEY 8d: 6 = the headline; anything else is NOT the headline)")
     ap.add_argument("--gamma", type=float, default=1.0,
                     help="the reference's compactness exponent (scheduled 1 -> 50 during training, VanillaTS_model.py:549-554); 1 = the headline "
                          "(SURVEY 8d), anything else is NOT the headline: the blend kernels then evaluate ecc^(2 gamma) with a log / exp pair")
@@ -151,7 +152,7 @@ def main():
             raise SystemExit("--force-depth-pass4 needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
         _C._lib.ts2d_lab_force_depth_pass4(1)
     P, W, H, D = args.triangles, args.width, args.height, args.sh_degree
-    s = synthetic.scene(P, W, H, D, seed=42, mode=args.scene_mode)
+    s = synthetic.scene(P, W, H, D, seed=42, mode=args.scene_mode, edge_px=args.edge_px)
     # one view per rank: same triangles, camera shifted sideways by a few world units per rank
     cam = synthetic.camera(W, H)
     if rank > 0:
@@ -360,7 +361,7 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma={args.gamma:g}): fwd+bwd of one view per GPU",
-                   "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N, "scene_mode": args.scene_mode,
+                   "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N, "scene_mode": args.scene_mode, "edge_px": args.edge_px,
                    "forward": ("sync-free (ts2d_forward, device-side instance count)" if args.sync_free else
                                "speculative (ts2d_forward_speculative: queued for 1.25 x the recent instance count, exact num_rendered read back "
                                "behind the queue; the package default)"),
