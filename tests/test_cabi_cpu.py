@@ -197,3 +197,36 @@ def test_compiled_reference_side_binding_loads(hip_lib_built):
         z = torch.zeros
         ext.rasterize_triangles(8, 8, 0.3, 0.3, z(4, 4), z(4, 4), z(3), 0, 1.0, 1.0, 1.0, z(3), z(2, 3, 3), z(2, 1, 3), torch.empty(0), z(2, 1),
                                 False, True, False)
+
+
+def test_ctypes_structures_match_the_c_headers(tmp_path, hip_lib_built):
+    """The ctypes mirrors of the C ABI's structs (diff_triangle_rasterization_2D/_C.py, diff_recon_hip/optim.py) against the headers themselves:
+    a probe compiled with gcc from include/*.h prints sizeof / offsetof of every field; a field added to a header but not to its mirror (or
+    the other way round) fails here, without a GPU."""
+    import subprocess
+    from diff_triangle_rasterization_2D import _C
+    from diff_recon_hip import optim
+    mirrors = {"ts2d_camera": _C._Camera, "ts2d_geometry": _C._Geometry, "ts2d_forward_out": _C._ForwardOut, "ts2d_loss_grads": _C._LossGrads,
+               "ts2d_backward_out": _C._BackwardOut, "ts2d_state": _C._State, "tso_adam_slice": optim._Slice}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ts2d.h"', '#include "ts_optim.h"', 'int main(void) {']
+    for cname, mirror in mirrors.items():
+        lines.append(f'printf("{cname} size %zu\\n", sizeof({cname}));')
+        for fname, _ in mirror._fields_:
+            lines.append(f'printf("{cname} {fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines.append("return 0; }")
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out.splitlines()}
+    for cname, mirror in mirrors.items():
+        assert got[(cname, "size")] == ctypes.sizeof(mirror), cname
+        for fname, _ in mirror._fields_:
+            assert got[(cname, fname)] == getattr(mirror, fname).offset, (cname, fname)
+    # and the header has no field the mirror lacks: the sizes above already say so for trailing fields; count the declarators for the rest
+    for cname, mirror, header in [("ts2d_geometry", _C._Geometry, "ts2d.h"), ("tso_adam_slice", optim._Slice, "ts_optim.h")]:
+        text = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+        body = re.search(r"typedef struct " + cname + r"\s*\{(.*?)\}\s*" + cname + r"\s*;", text, flags=re.S).group(1)
+        declared = [n for stmt in body.split(";") for n in re.findall(r"\**\s*([A-Za-z_]\w*)\s*(?:,|$)", stmt.strip().split(None, 1)[-1] if stmt.strip() else "")]
+        assert len(declared) == len(mirror._fields_), (cname, declared, [f for f, _ in mirror._fields_])
