@@ -174,3 +174,26 @@ def test_background_depth_as_a_device_tensor_needs_no_host_value(variant):
         assert torch.equal(a, b) or float((a - b).abs().max()) <= 1e-6 * float(a.abs().max())  # gradients: atomics' summation order
         assert torch.equal(a, c) or float((a - c).abs().max()) <= 1e-6 * float(a.abs().max())
     assert torch.equal(as_float[0], as_tensor[0]) and torch.equal(as_float[1], as_tensor[1])
+
+
+def test_nothing_visible_after_a_history_exists():
+    """A guessed capacity > 0 and a true count of 0 (every triangle behind the camera): the speculative launches run over an empty list --
+    background image, zero radii / statistics, zero gradients -- and num_rendered is 0."""
+    import torch
+    w, h = 203, 131  # own image size: own capacity history
+    s = synthetic.scene(5000, w, h, 1, seed=5)
+    first = helpers.hip_forward_backward(s, True)
+    assert first["num_rendered"] > 0
+    from diff_triangle_rasterization_2D import _C
+    assert int(_C._lib.ts2d_instance_capacity_hint(5000, w, h, 0)) > 0
+    hidden = dict(s)
+    hidden["vertex"] = s["vertex"].copy()
+    hidden["vertex"][:, :, 2] += 5000.0  # behind the camera at z = 1200 looking down -z
+    got = helpers.hip_forward_backward(hidden, True)
+    assert got["num_rendered"] == 0 and not got["radii"].any()
+    assert np.array_equal(got["out_feature"], np.broadcast_to(s["background"][:, None, None], got["out_feature"].shape))
+    assert not got["contrib_sum"].any() and not got["normal"].any()
+    for k in ("dL_dvertex", "dL_dshs", "dL_dopacity", "dL_dcenter2D"):
+        assert not got[k].any(), k
+    again = helpers.hip_forward_backward(s, True)  # and the visible scene still renders as before
+    assert again["num_rendered"] == first["num_rendered"] and np.array_equal(again["out_feature"], first["out_feature"])
