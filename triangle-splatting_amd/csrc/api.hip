@@ -195,7 +195,13 @@ bool acquire_early_count(EarlyCount &e)
     const unsigned i = next.fetch_add(1) % SLOTS;
     {
         std::lock_guard<std::mutex> lk(mu);
-        if (!events[dev][i] && hipEventCreateWithFlags(&events[dev][i], hipEventDisableTiming) != hipSuccess) return false;
+        // hipEventBlockingSync: a host thread that has watched the pinned word in vain for its bounded time SLEEPS on the event instead of
+        // spinning inside the runtime (eight ranks = eight cores otherwise); the wake-up latency is off the GPU's critical path,
+        // the rest of the forward is queued by then
+#ifndef TS2D_COUNT_EVENT_FLAGS
+#define TS2D_COUNT_EVENT_FLAGS (hipEventDisableTiming | hipEventBlockingSync)
+#endif
+        if (!events[dev][i] && hipEventCreateWithFlags(&events[dev][i], TS2D_COUNT_EVENT_FLAGS) != hipSuccess) return false;
     }
     e.host = ring + (size_t)dev * SLOTS + i;
     e.ev = events[dev][i];
