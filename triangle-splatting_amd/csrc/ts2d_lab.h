@@ -32,8 +32,9 @@ int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint3
                          int32_t end_bit, int32_t which, void *stream);
 int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream);
 
-/* on != 0: every sort and scan of later forwards IN THIS LIBRARY takes the hierarchical (ticket) passes that scenes of more than ~6 M
- * triangles / 12.6 M instances take, whatever their size -- so that the suite executes them (ticket-path depth census included). */
+/* on != 0: every sort of later forwards IN THIS LIBRARY takes the hierarchical (ticket) passes that sorts of more than 48 slabs take (> 6.3 M
+ * triangles, > 12.6 M instances) and the scan its two-level form (> 2 M triangles), whatever the scene's size -- so that the suite executes
+ * them (ticket-path depth census included). */
 void ts2d_lab_force_ticket_passes(int on);
 /* on != 0: the depth sort of later forwards in this library always runs its fourth pass.  The product skips it when all visible depths
  * share the top key byte (sign + 7 exponent bits: depths within a factor of four -- every synthetic scene of bench.py; not a real scene
