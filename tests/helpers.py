@@ -244,6 +244,7 @@ def _ref_request(line, timeout=600):
             _ref_server.stdin.flush()
         except BrokenPipeError:
             _ref_server = None
+            _sweep_device_caches()
             continue
         ready, _, _ = select.select([_ref_server.stdout], [], [], timeout)
         ans = _ref_server.stdout.readline().strip() if ready else ""
@@ -252,8 +253,27 @@ def _ref_request(line, timeout=600):
         _ref_server.kill()
         _ref_server.wait()
         _ref_server = None
+        _sweep_device_caches()
         return None
     return None
+
+
+def _sweep_device_caches():
+    """Called after the reference-kernel server died.  It dies of GPU memory-access faults inside the reference's kernels, and on this platform
+    a process that faults leaves the SURVIVING processes on the device with stale cache lines: the next large launch of this process can then
+    read memory as it was before its own memset / atomics (whole 128-byte lines of the backward's gradient records; tests/triage/fuzz_flow.py
+    reproduces it with a neighbour that runs none of the reference's code, tests/triage/gpu_faulter.py: 6 of 8 runs wrong, none without a
+    faulting neighbour, none with this sweep -- profiles/r04_neighbour_fault.txt).  Writing and re-reading 2 GiB pushes every line of the
+    eight L2s and of the memory-side cache out while nothing of this process is live."""
+    import torch
+    if not torch.cuda.is_available():
+        return
+    x = torch.empty(2 << 30, dtype=torch.uint8, device="cuda")
+    x.fill_(1)
+    x.add_(1)
+    torch.cuda.synchronize()
+    del x
+    torch.cuda.empty_cache()
 
 
 def ref3d_builds(s, rich=True, back=False, use_feature=False, fuzz_seed=None):
@@ -282,16 +302,16 @@ def ref3d_builds(s, rich=True, back=False, use_feature=False, fuzz_seed=None):
 
 
 def _dist3d(k, x, y):
+    """(distance, number of depth pixels set aside).  Depth only: a pixel whose ray lies nearly IN a triangle's plane (|p_ray.n| small but
+    above the reference's absolute 1e-8 guard, R3D forward.cu:241-243) gets depth = v1.n / p_ray.n of 1e4 ... 1e11 in EVERY build, each with
+    its own rounding noise, and one such pixel outweighs the rest of the map in an L2 norm: pixels that differ by more than 1e-3 of their (or
+    the typical) depth are counted and the norm is taken over the others.  How many may be set aside is judged by the caller -- like the
+    distances themselves, against what the reference's own builds do to each other."""
     if k == "depth":
-        # a pixel whose ray lies nearly IN a triangle's plane (|p_ray.n| small but above the reference's absolute 1e-8 guard, R3D
-        # forward.cu:241-243) gets depth = v1.n / p_ray.n of 1e4 ... 1e11 in EVERY build, each with its own rounding noise, and one such
-        # pixel outweighs the rest of the map in an L2 norm: at most 1e-4 of the pixels (at least one) may differ by more than 1e-3 of
-        # their (or the typical) depth; the norm is taken over the others
         scale = np.maximum(np.abs(y), np.median(np.abs(y)))
         bad = ~(np.abs(x - y) <= 1e-3 * scale)
-        assert bad.sum() <= max(1, int(1e-4 * bad.size)), (k, int(bad.sum()))
-        x, y = x[~bad], y[~bad]
-    return rel_l2(x, y)
+        return rel_l2(x[~bad], y[~bad]), int(bad.sum())
+    return rel_l2(x, y), 0
 
 
 def assert_inside_reference_spread_3d(hf, builds, what=""):
@@ -301,9 +321,19 @@ def assert_inside_reference_spread_3d(hf, builds, what=""):
     for k, tol in R3D_BARS.items():
         if k not in hf or any(k not in builds[b] for b in names):
             continue
-        own = [_dist3d(k, builds[a][k], builds[b][k]) for i, a in enumerate(names) for b in names[i + 1:]]
-        mine = [_dist3d(k, hf[k], builds[b][k]) for b in names]
+        own_pairs = [_dist3d(k, builds[a][k], builds[b][k]) for i, a in enumerate(names) for b in names[i + 1:]]
+        mine_pairs = [_dist3d(k, hf[k], builds[b][k]) for b in names]
+        own, mine = [d for d, _ in own_pairs], [d for d, _ in mine_pairs]
         report[k] = (mine, own)
         assert min(mine) <= max(tol, float(np.median(own))), (what, k, "closest build", mine, own)
         assert max(mine) <= max(tol, 1.25 * max(own)), (what, k, "farthest build", mine, own)
+        if k == "depth":
+            # the pixels set aside: at most 1e-4 of the map (at least one) -- or as many as the reference's builds set aside among themselves
+            # (extended fuzz sweep: seed 93, 5 of 33 150 pixels between two builds of the reference, 1 - 4 for the product; seed 161, 0 - 1 of
+            # 7 905 between builds, 1 - 2 for the product -- counts this small scatter by a factor two between any two evaluations)
+            size = int(np.asarray(hf[k]).size)
+            budget = max(1, int(1e-4 * size))
+            own_bad, mine_bad = [n for _, n in own_pairs], [n for _, n in mine_pairs]
+            assert min(mine_bad) <= max(budget, int(np.median(own_bad))), (what, k, "pixels set aside, closest build", mine_bad, own_bad)
+            assert max(mine_bad) <= max(budget, 2 * max(own_bad)), (what, k, "pixels set aside, farthest build", mine_bad, own_bad)
     return report

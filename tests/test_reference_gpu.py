@@ -72,7 +72,8 @@ def test_oracle_and_hip_against_the_reference_build(P, W, H, D, rich, gamma, bac
             if k in nofma and oracle.get(k) is not None and k in ("out_feature", "depth", "normal", "contrib_sum", "contrib_max", "dL_dshs", "dL_dopacity", "dL_dvertex", "dL_dcenter2D"):
                 if not rich and k in ("depth", "normal", "contrib_sum", "contrib_max"):
                     continue
-                assert helpers._dist3d(k, oracle[k], nofma[k]) < 2e-5, ("oracle vs the reference's -ffp-contract=off build", k)
+                dist, set_aside = helpers._dist3d(k, oracle[k], nofma[k])
+                assert dist < 2e-5 and set_aside <= max(1, int(1e-4 * np.asarray(oracle[k]).size)), ("oracle vs the reference's -ffp-contract=off build", k, dist, set_aside)
         helpers.assert_inside_reference_spread_3d(oracle, builds, "oracle")
         hf = helpers.hip_forward_backward(s, rich, back_culling, variant=variant)
         assert hf["num_rendered"] == nofma["num_rendered"] and np.array_equal(hf["radii"], nofma["radii"])
