@@ -96,7 +96,7 @@ def hip_forward_backward(s, rich_info=True, back_culling=False, use_feature=Fals
 # ---- private-state reader: tools/bin/libts2d_lab.so (csrc/ts2d_lab.h) ---------------------------------------------------------
 # The product library exports no diagnostics.  The lab library contains the product's objects (same layout code), so its reader
 # decodes the state buffers of a forward that the PRODUCT library ran in this process.
-LAB_LIB = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libts2d_lab.so")
+LAB_LIB = os.environ.get("TS2D_LAB_LIBRARY_PATH") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "bin", "libts2d_lab.so")  # the override: a variant build's lab library (tools/build_flag_variant.sh)
 _lab = None
 
 
@@ -160,7 +160,10 @@ def debug_read_state(name, P, num_rendered, W, H, geometryBuffer, binningBuffer,
 def hip_state(res, s, name):
     g, b, im = res["buffers"]
     P = s["vertex"].shape[0]
-    return debug_read_state(name, P, res["num_rendered"], s["image_width"], s["image_height"], g, b, im).numpy()
+    a = debug_read_state(name, P, res["num_rendered"], s["image_width"], s["image_height"], g, b, im).numpy()
+    if name in ("vals", "vals_unsorted"):
+        a = a & 0x0FFFFFFF  # triangle ids; a -DTS2D_QMASK build keeps a quadrant mask in the top four bits (csrc/ts2d_support.h)
+    return a
 
 
 def grazing_mask(of, cos_limit):

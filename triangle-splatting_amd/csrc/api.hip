@@ -116,6 +116,9 @@ int validate(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags)
     if (cam->width <= 0 || cam->height <= 0) return fail(TS2D_ERR_INVALID, "image size must be positive");
     if (cam->width > 65535 * TS_TILE || cam->height > 65535 * TS_TILE) return fail(TS2D_ERR_INVALID, "image too large");
     if (geom->P < 0) return fail(TS2D_ERR_INVALID, "P must be >= 0");
+#ifdef TS2D_QMASK
+    if (geom->P > 0x0FFFFFFF) return fail(TS2D_ERR_CAPACITY, "more than 2^28 - 1 triangles: the instance values keep four bits for the quadrant mask");
+#endif
     if (geom->C > TS2D_MAX_CHANNELS) // extension_interface.cu:65-68
         return fail(TS2D_ERR_INVALID, "feature's num_channels can't be larger than MAX_CHANNELS");
     if (geom->C < 1) return fail(TS2D_ERR_INVALID, "need at least one colour channel");
@@ -389,9 +392,14 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     if (P > 0)
     {
         {
+#ifdef TS2D_QMASK // quadrant masks for the 2D blend kernels (ts2d_support.h); the 3D kernels take plain ids
+            const float quad_g2 = (flags & TS2D_FLAG_3D) ? -1.0f : fmaxf(0.0f, 2.0f * geom->gamma); // 2 gamma < 1e-6: the whole ecc <= 10 region
+#else
+            const float quad_g2 = -1.0f;
+#endif
             ProfScope ps("emit_keys", s);
             ts_launch_emit_keys(P, r.grid_x, ntiles, g, b, im, rich ? out->contrib_sum : nullptr, rich ? out->contrib_max : nullptr,
-                                n_dev ? N : -1, im.status, s);
+                                n_dev ? N : -1, im.status, quad_g2, s);
         }
         TS_CHECK(flags, s, "emit_keys");
     }
@@ -948,7 +956,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
             TS_HIP(hipStreamSynchronize(s));
         }
         uint64_t *o = (uint64_t *)dst;
-        for (int64_t i = 0; i < N; i++) o[i] = ((uint64_t)tile[i] << 32) | depth[vals[i]];
+        for (int64_t i = 0; i < N; i++) o[i] = ((uint64_t)tile[i] << 32) | depth[vals[i] & 0x0FFFFFFFu]; // id bits (the top four: quadrant mask, ts2d_support.h)
         return TS2D_OK;
     }
     case 11: src = b.vals; bytes = (size_t)N * 4; break;

@@ -34,6 +34,7 @@
 // tests/test_binning_gpu.py.
 #include "ts2d_common.h"
 #include "ts2d_wave.h"
+#include "ts2d_support.h"
 
 namespace
 {
@@ -713,7 +714,8 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
 constexpr uint32_t SMALL = 32;
 
 __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
-                                                         float *contrib_sum, float *contrib_max, long long capacity, int32_t *status, bool two_level)
+                                                         float *contrib_sum, float *contrib_max, long long capacity, int32_t *status, bool two_level,
+                                                         float quad_g2)
 {
     __shared__ uint32_t wtot[4];
     __shared__ unsigned long long wpart[4];
@@ -779,6 +781,17 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     }
     const uint32_t minx = rect.x & 0xffffu, miny = rect.x >> 16, maxx = rect.y & 0xffffu, maxy = rect.y >> 16;
     uint32_t *tile_out = b.k[0], *val_out = b.v[0];
+    // quad_g2 >= 0 (-DTS2D_QMASK builds, 2D variant; the value is 2 gamma): the four spare bits of an instance's value say which 8x8 quadrants
+    // of its tile the triangle's support can reach (ts2d_support.h); the blend kernels' quadrant waves then skip the other entries unseen
+    const bool qm = quad_g2 >= 0.0f;
+    auto setup_of = [&](uint32_t tri) {
+        const float4 *rp = g.rec + 4 * (size_t)tri;
+        const float4 r0 = rp[0], r1 = rp[1];
+        const float E = quad_g2 == 2.0f ? support_scale<true>(r1.z, quad_g2) : support_scale<false>(r1.z, quad_g2);
+        return quad_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, E);
+    };
+    QuadSetup qs{};
+    if (qm && tiles > 0 && tiles <= SMALL) qs = setup_of(id);
     // The block's instances are one contiguous run of the list.  A lane writing its triangle's few slots straight to memory issues 4-byte
     // stores a few slots apart from its neighbours' (a 32-64 byte fabric write each on this chip); runs of up to STAGE instances are put
     // together in LDS instead and leave as coalesced rows.
@@ -796,7 +809,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
                 for (uint32_t x = minx; x < maxx; x++)
                 {
                     stage_t[o] = y * grid_x + x;
-                    stage_v[o] = id;
+                    stage_v[o] = qm ? id | (quadrant_mask(qs, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS) : id;
                     o++;
                 }
         }
@@ -805,7 +818,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
                 for (uint32_t x = minx; x < maxx; x++)
                 {
                     tile_out[o] = y * grid_x + x;
-                    val_out[o] = id;
+                    val_out[o] = qm ? id | (quadrant_mask(qs, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS) : id;
                     o++;
                 }
     }
@@ -817,18 +830,21 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         const uint32_t t_minx = __shfl(minx, j), t_miny = __shfl(miny, j), t_maxx = __shfl(maxx, j);
         const uint32_t t_tiles = __shfl(tiles, j), t_off = __shfl(off, j), t_id = __shfl(id, j);
         const uint32_t w = t_maxx - t_minx;
+        QuadSetup tq{};
+        if (qm) tq = setup_of(t_id); // every lane of the wave for itself: the same record, no 20-value broadcast
         for (uint32_t k = lane; k < t_tiles; k += 64)
         {
             const uint32_t y = t_miny + k / w, x = t_minx + k % w;
+            const uint32_t val = qm ? t_id | (quadrant_mask(tq, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS) : t_id;
             if (staged)
             {
                 stage_t[t_off - run0 + k] = y * grid_x + x;
-                stage_v[t_off - run0 + k] = t_id;
+                stage_v[t_off - run0 + k] = val;
             }
             else
             {
                 tile_out[t_off + k] = y * grid_x + x;
-                val_out[t_off + k] = t_id;
+                val_out[t_off + k] = val;
             }
         }
     }
@@ -940,11 +956,11 @@ void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 }
 
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
-                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s)
+                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, float quad_g2, hipStream_t s)
 {
     if (P <= 0) return;
     hipLaunchKernelGGL(scan_emit_kernel, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges, contrib_sum,
-                       contrib_max, (long long)capacity, status, scan_two_level(P));
+                       contrib_max, (long long)capacity, status, scan_two_level(P), quad_g2);
 }
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P) { return (const unsigned long long *)(g.blocksum + (P + SB - 1) / SB); }
 

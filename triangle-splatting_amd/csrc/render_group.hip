@@ -31,6 +31,7 @@
 #include "ts2d_common.h"
 #include "ts2d_wave.h"
 #include "ts2d_group.h"
+#include "ts2d_support.h"
 
 #ifndef TSG_FWD_WAVES // resident waves per SIMD the register budget is declared for (occupancy experiments: tools/build_variant.sh ... -DTSG_BWD_WAVES=8)
 #define TSG_FWD_WAVES 7
@@ -87,7 +88,7 @@ template <bool RICH>
 __device__ __forceinline__ uint32_t republish_row(float *row, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, uint32_t pos,
                                                   int jpos, float OX, float OY)
 {
-    const uint32_t id = point_list[pos];
+    const uint32_t id = point_list[pos] & TS_ID_MASK; // -DTS2D_QMASK: the top bits are the instance's quadrant mask
     const float4 *rp = rec + 4 * (size_t)id;
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = RICH ? rp[3] : make_float4(0, 0, 0, 0);
     BlockCull s;
@@ -109,15 +110,7 @@ __device__ __forceinline__ BlockCull block_cull(float v1x, float v1y, float v2x,
     const float C2 = (s.u3x * s.u1y - s.u3y * s.u1x) * s.ia, A2 = (v3y - v1y) * s.ia, B2 = (v1x - v3x) * s.ia;
     const float A3 = -A1 - A2, B3 = -B1 - B2, C3 = 1.0f - C1 - C2;
     // alpha >= 1/255 needs ecc^(2 gamma) <= 2 ln(255 op); ecc <= E is the triangle scaled by E about its centroid
-    const float t = 255.0f * op;
-    float E = -1.0f;
-    if (t >= 1.0f)
-    {
-        const float L = 2.0f * 0.6931471805599453f * __builtin_amdgcn_logf(t);
-        if (GAMMA1) E = __builtin_amdgcn_sqrtf(L);
-        else E = (g2 < 1e-6f) ? 10.0f : pow_nonneg(L, 1.0f / g2);
-        E = fminf(E * 1.0005f + 0.002f, 10.01f);
-    }
+    const float E = support_scale<GAMMA1>(op, g2); // ts2d_support.h
     const float cx = (s.u1x + s.u2x + s.u3x) * (1.0f / 3.0f), cy = (s.u1y + s.u2y + s.u3y) * (1.0f / 3.0f);
     const float e1x = E * (s.u1x - cx), e2x = E * (s.u2x - cx), e3x = E * (s.u3x - cx);
     const float e1y = E * (s.u1y - cy), e2y = E * (s.u2y - cy), e3y = E * (s.u3y - cy);
@@ -150,7 +143,11 @@ __device__ __forceinline__ void write_dummy_row(float *row, int lane)
         if (lane == 0 || lane == 1 || lane == 3 || lane == 4) v = 1000.0f;
         if (lane == 2 || lane == 5) v = 1001.0f;
         if (lane == 6) v = 1.0f;
+#ifdef TS2D_QMASK
+        if (lane == 18) v = __int_as_float(0x7fffffff); // list position of the dummy: beyond every pixel's range
+#else
         if (lane == 18) v = __int_as_float(255); // batch position of the dummy: beyond every pixel's range
+#endif
         row[lane] = v;
     }
 }
@@ -233,12 +230,35 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
 #ifdef TS2D_STATS
     unsigned long long stat_acc[12] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
 #endif
+#ifdef TS2D_QMASK
+    // dense batches: only the entries whose quadrant bit is set are gathered and culled (ts2d_group.h, stream_refill); `pos` = list position
+    uint32_t id = 0;
+    int pos = 0, cursor = 0;
+    constexpr int base = 0; // row column 18 holds the list position itself
+    for (;;)
+    {
+        const unsigned long long alive = ballot(!done);
+        if (alive == 0) break;
+        int nq = 0;
+        stream_refill<false>(id, pos, nq, point_list + range.x, cursor, len, TS_ID_BITS + wave, lane);
+        if (nq == 0) break;
+        const bool valid = lane < nq;
+        const int ent = pos;
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+        if (valid)
+        {
+            const float4 *rp = rec + 4 * (size_t)id;
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+            if (RICH) r3 = rp[3];
+        }
+#else
     for (int base = 0; base < len; base += 64)
     {
         const unsigned long long alive = ballot(!done);
         if (alive == 0) break;
         const int k = base + lane;
         const bool valid = k < len;
+        const int ent = lane, pos = k; // row column 18 holds the position inside the batch
         uint32_t id = 0;
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
         if (valid)
@@ -248,6 +268,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
             if (RICH) r3 = rp[3];
         }
+#endif
         const BlockCull s = block_cull<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
         // one entry mask per block; a block whose 16 pixels are all saturated takes no more entries
         unsigned long long M[4];
@@ -266,7 +287,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
         const int rank = lane_rank(any), nact = __popcll(any);
         const int r = rank & (NR - 1);
         bool mine = anybit && rank < NR;
-        if (mine) publish_row(cst + r * ROW, s, id, lane, r1, r2, r3);
+        if (mine) publish_row(cst + r * ROW, s, id, ent, r1, r2, r3);
         for (int h = 0;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
@@ -364,7 +385,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
             }
             if (++h * NR >= nact) break;
             mine = anybit && rank >= NR;
-            if (mine) republish_row<RICH>(cst + r * ROW, point_list, rec, range.x + base + lane, lane, OX, OY);
+            if (mine) republish_row<RICH>(cst + r * ROW, point_list, rec, range.x + pos, ent, OX, OY);
         }
     }
 
@@ -398,7 +419,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
         for (int j = 0; j < NF; j++)
         {
             const int k = (int)threadIdx.x + 256 * j;
-            ids[j] = k < nflush ? point_list[range.x + k] : 0u;
+            ids[j] = k < nflush ? point_list[range.x + k] & TS_ID_MASK : 0u;
         }
         __syncthreads(); // the only rendezvous of the four quadrant waves: the tile's merged contribution statistics leave
 #pragma unroll
@@ -516,10 +537,37 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
     const int maxlast = max(max(glast[0], glast[1]), max(glast[2], glast[3]));
     if (maxlast <= 0) return;
 
+#ifdef TS2D_QMASK
+    // dense batches, walked back to front: lane 0 holds the entry farthest back (ts2d_group.h, stream_refill<true>); `pos` = list position
+    constexpr bool FRONT_LANE_FIRST = true; // processing order inside a batch = ascending lane
+    constexpr int base = 0;                 // row column 18 holds the list position itself
+    uint32_t id = 0;
+    int pos = 0, cursor = maxlast;
+    for (;;)
+    {
+        int nq = 0;
+        stream_refill<true>(id, pos, nq, point_list + range.x, cursor, maxlast, TS_ID_BITS + quad, lane);
+        if (nq == 0) break;
+        const bool valid = lane < nq;
+        const int ent = pos;
+        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
+        if (valid)
+        {
+            const float4 *rp = rec + 4 * (size_t)id;
+            r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
+            if (RICH) r3 = rp[3];
+        }
+        const BlockCull s = block_cull<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
+        unsigned long long M[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) M[g] = ballot(valid && s.ov[g] && pos < glast[g]); // entries at or behind glast[g] are skipped by all of block g's pixels
+#else
+    constexpr bool FRONT_LANE_FIRST = false; // a batch holds ascending list positions: back to front = descending lane
     for (int base = ((maxlast - 1) >> 6) << 6; base >= 0; base -= 64)
     {
         const int k = base + lane;
         const bool valid = k < maxlast;
+        const int ent = lane, pos = k; // row column 18 holds the position inside the batch
         uint32_t id = 0;
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
         if (valid)
@@ -538,6 +586,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
             const unsigned long long keep = n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
             M[g] = ballot(valid && s.ov[g]) & keep;
         }
+#endif
         const unsigned long long any = M[0] | M[1] | M[2] | M[3];
         if (any == 0) continue;
         // compacted table rows, at most NR per pass (see the forward); back to front: the upper half of a full batch first
@@ -545,8 +594,8 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
         const int rank = lane_rank(any), nact = __popcll(any);
         const int lrel = last - base; // entries [0, lrel) of this batch are in front of the pixel's last contributor
         const int r = rank & (NR - 1);
-        bool mine = anybit && (rank / NR) == (nact - 1) / NR;
-        if (mine) publish_row(rows + r * BROW, s, id, lane, r1, r2, r3);
+        bool mine = anybit && (FRONT_LANE_FIRST ? rank < NR : (rank / NR) == (nact - 1) / NR);
+        if (mine) publish_row(rows + r * BROW, s, id, ent, r1, r2, r3);
         for (int h = (nact - 1) / NR;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
@@ -562,7 +611,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
             {
                 const unsigned long long Mh = M[g] & mm;
                 const int n = __popcll(Mh);
-                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (n - 1 - lane_rank(Mh))] = (unsigned short)(row0 + r * (BROW * 4));
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (FRONT_LANE_FIRST ? lane_rank(Mh) : n - 1 - lane_rank(Mh))] = (unsigned short)(row0 + r * (BROW * 4));
                 steps = max(steps, n);
             }
             const u16a *mylist = (const u16a *)list + grp * NR;
@@ -685,8 +734,8 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
                 }
             }
             if (--h < 0) break;
-            mine = anybit && rank < NR;
-            if (mine) republish_row<RICH>(rows + r * BROW, point_list, rec, range.x + base + lane, lane, OX, OY);
+            mine = anybit && (FRONT_LANE_FIRST ? rank >= NR : rank < NR);
+            if (mine) republish_row<RICH>(rows + r * BROW, point_list, rec, range.x + pos, ent, OX, OY);
         }
     }
 }

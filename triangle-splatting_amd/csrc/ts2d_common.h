@@ -24,6 +24,13 @@
 // area2 is not stored: it is recomputed as cross(v2-v1, v3-v1), the expression the reference stores.
 #define TS_REC_FLOATS 16
 
+// Quadrant masks (ts2d_support.h): the emission kernel marks in the four spare bits of an instance's value which 8x8 quadrants of its tile the
+// triangle's support can reach, and the 2D blend kernels' quadrant waves gather and cull only those entries, in dense batches.  Round 4,
+// measured product vs -DTS2D_NO_QMASK alternating on one box (profiles/r04_qmask.txt): render_fwd 0.429 -> 0.398 ms, render_bwd 0.839 -> 0.791,
+// emission 0.029 -> 0.053, step 1.658 -> 1.604.  -DTS2D_NO_QMASK restores the plain lists (triangle ids < 2^32 instead of < 2^28).
+#if !defined(TS2D_NO_QMASK) && !defined(TS2D_QMASK)
+#define TS2D_QMASK 1
+#endif
 // Gradient record (16 floats = 64 B), accumulated by render_bwd, consumed by preprocess_bwd.
 //   [0..5] dL/dv{1,2,3}_2D   [6] dL/dopacity   [7..9] dL/drgb   [10..12] dL/dnormal_view   [13..15] dL/dv_depth
 #define TS_GRAD_FLOATS 16
@@ -219,7 +226,7 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s);          // the rest: (depth bits, id) -> sorted ids
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);                  // tiles_sorted, block sums + their groups' sums
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
-                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path
+                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, float quad_g2, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path; quad_g2 >= 0: quadrant masks in the values' top bits (ts2d_support.h)
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P);                        // where the scan leaves N
 void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s); // stable, tile bits only
 void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s);

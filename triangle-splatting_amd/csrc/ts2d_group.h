@@ -18,6 +18,46 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) // set bits of m 
 // 0 <= ecc <= 10 (forward.cu:307) as ONE unsigned compare: negative floats and NaN have larger bit patterns than 10.0f
 __device__ __forceinline__ bool ecc_in_range(float ecc) { return __float_as_uint(ecc) <= 0x41200000u; }
 
+// ---- dense batches (-DTS2D_QMASK) -------------------------------------------------------------------------------------------------------
+// The emission kernel marks in the top four bits of an instance's value which quadrants of the tile the triangle can reach (ts2d_support.h).
+// A quadrant wave reads the tile's list 64 candidates at a time and keeps the entries whose bit is set, COMPACTED: lanes [0, n) of (id, pos)
+// hold the next n entries in processing order (pos = the entry's position in the tile's list).  One refill = one ballot, one cross-lane
+// permutation (ds_permute: taken lanes go to slots n, n + 1, ..., the others fill the rest of the permutation) and no LDS memory; a window
+// that does not fit is consumed only up to the last entry that does (the cursor moves by that many candidates).
+// DESC = false: candidates cursor, cursor + 1, ... (< end), cursor moves up.  DESC = true: cursor - 1, cursor - 2, ... (>= 0), cursor moves down
+// (the backward walks the list back to front; lane 0 is then the entry farthest back).
+template <bool DESC>
+__device__ __forceinline__ void stream_refill(uint32_t &id, int &pos, int &n, const uint32_t *__restrict__ list, int &cursor, int end, int qbit, int lane)
+{
+    while (n < 64 && (DESC ? cursor > 0 : cursor < end))
+    {
+        const int k = DESC ? cursor - 1 - lane : cursor + lane;
+        const bool valid = DESC ? k >= 0 : k < end;
+        const uint32_t v = valid ? list[k] : 0u;
+        const bool want = valid && ((v >> qbit) & 1u);
+        unsigned long long mt = ballot(want);
+        int adv = 64;
+        const int room = 64 - n;
+        bool taken = want;
+        if (__popcll(mt) > room) // keep the first `room` of them; the next refill starts behind the last one kept
+        {
+            taken = want && lane_rank(mt) < room;
+            mt = ballot(taken);
+            adv = 64 - __builtin_clzll(mt);
+        }
+        cursor += DESC ? -adv : adv;
+        if (mt == 0) continue;
+        const int cnt = __popcll(mt), rk = lane_rank(mt);
+        const int dest = (taken ? n + rk : n + cnt + (lane - rk)) & 63; // a permutation of the 64 lanes
+        const uint32_t pid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(v & 0x0FFFFFFFu));
+        const int ppos = __builtin_amdgcn_ds_permute(dest << 2, k);
+        const bool fresh = lane >= n && lane < n + cnt;
+        id = fresh ? pid : id;
+        pos = fresh ? ppos : pos;
+        n += cnt;
+    }
+}
+
 // ---- 16-lane (DPP row) transpose-reduce: N values per lane -> each lane keeps the row-wide reduction of ONE value ----
 // Level 1 pairs lanes l, l ^ 8 (row_ror:8), level 2 lanes inside a group of 8 (row_half_mirror), level 3 l, l ^ 2, then l, l ^ 1.
 struct RowSel
@@ -169,7 +209,7 @@ __device__ __forceinline__ void tile_stats_add(unsigned long long *tsum, int *tm
         __hip_atomic_fetch_add(tsum + k, to_fixed48(sm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_max(tmax + k, __float_as_int(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    else global_stats_add(tile_list[k], sm, mx, contrib_sum, contrib_max); // list positions beyond the LDS arrays (a very long tile list)
+    else global_stats_add(tile_list[k] & 0x0FFFFFFFu, sm, mx, contrib_sum, contrib_max); // list positions beyond the LDS arrays (a very long tile list); -DTS2D_QMASK: id bits only
 }
 __device__ __forceinline__ void tile_stats_flush(unsigned long long fx48, int mxbits, uint32_t tid, float *contrib_sum, float *contrib_max)
 {
