@@ -78,7 +78,7 @@ typedef struct ts2d_camera
 /* GeometryInfo, R2D/src/param_struct.h:138-153.  All pointers are device pointers. */
 typedef struct ts2d_geometry
 {
-    int32_t P;         /* number of triangles */
+    int32_t P;         /* number of triangles; at most 2^28 - 1 (the instance lists keep four bits of each value for a quadrant mask: TS2D_ERR_CAPACITY) */
     int32_t sh_degree; /* active SH degree D, 0..3 */
     int32_t M;         /* SH coefficients stored per triangle ((max_degree+1)^2); 0 in feature mode */
     int32_t C;         /* colour channels: 3 in SH mode, feature.size(1) <= 3 otherwise */
