@@ -106,6 +106,20 @@ def test_null_arguments_are_rejected_not_crashed(lib):
     assert rc == 1 and b"null" in lib.ts2d_last_error()
 
 
+def test_triangle_count_beyond_the_id_bits_is_refused(lib):
+    """The instance lists keep four bits of each value for the quadrant mask (csrc/ts2d_support.h): 2^28 triangles are a capacity error of the
+    argument check, before any memory is touched."""
+    from diff_triangle_rasterization_2D import _C
+    lib.ts2d_forward_bin.restype = ctypes.c_int
+    lib.ts2d_last_error.restype = ctypes.c_char_p
+    cam, geom = _C._Camera(), _C._Geometry()
+    cam.width, cam.height = 64, 64
+    geom.P, geom.C, geom.M, geom.gamma = 1 << 28, 3, 0, 1.0
+    n = ctypes.c_int64(0)
+    rc = lib.ts2d_forward_bin(ctypes.byref(cam), ctypes.byref(geom), 0, None, None, ctypes.byref(n), None)
+    assert rc == 3 and b"2^28" in lib.ts2d_last_error()  # TS2D_ERR_CAPACITY
+
+
 # ---- Python surface: same names / order / errors as R2D/diff_triangle_rasterization_2D/__init__.py ----------
 REFERENCE_SETTINGS_FIELDS = ("image_width", "image_height", "tanfovx", "tanfovy", "viewmatrix", "projmatrix", "campos",
                              "sh_degree", "gamma", "scale_modifier", "background_depth", "background", "back_culling",
