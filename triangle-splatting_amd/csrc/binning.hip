@@ -791,7 +791,6 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         return quad_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, E);
     };
     QuadSetup qs{};
-    if (qm && tiles > 0 && tiles <= SMALL) qs = setup_of(id);
     // The block's instances are one contiguous run of the list.  A lane writing its triangle's few slots straight to memory issues 4-byte
     // stores a few slots apart from its neighbours' (a 32-64 byte fabric write each on this chip); runs of up to STAGE instances are put
     // together in LDS instead and leave as coalesced rows.
@@ -799,6 +798,13 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     __shared__ uint32_t stage_t[STAGE], stage_v[STAGE];
     const uint32_t run0 = (uint32_t)qbase, run = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     const bool staged = run <= STAGE;
+    // Staged runs form their masks in the flush loop below, one lane per INSTANCE, evenly spread over the block (a lane that walks its triangle's
+    // tiles makes the whole wave wait for the triangle with the most tiles); the tile travels through LDS as (x | y << 16).  Measured at 1 M
+    // triangles: 0.052 ms against 0.053 with the test inside the tile loops and 0.029 without masks -- the cost is the test itself (~130 VALU
+    // instructions and a 32-byte record gather per instance), not the imbalance.  Runs too long for the stage (big triangles) test per tile
+    // where they write.
+    const bool qstage = qm && staged;
+    if (qm && !staged && tiles > 0 && tiles <= SMALL) qs = setup_of(id);
     if (tiles > 0 && tiles <= SMALL)
     {
         uint32_t o = off;
@@ -808,8 +814,8 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
             for (uint32_t y = miny; y < maxy; y++)
                 for (uint32_t x = minx; x < maxx; x++)
                 {
-                    stage_t[o] = y * grid_x + x;
-                    stage_v[o] = qm ? id | (quadrant_mask(qs, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS) : id;
+                    stage_t[o] = qstage ? (x | (y << 16)) : y * grid_x + x;
+                    stage_v[o] = id;
                     o++;
                 }
         }
@@ -831,15 +837,15 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         const uint32_t t_tiles = __shfl(tiles, j), t_off = __shfl(off, j), t_id = __shfl(id, j);
         const uint32_t w = t_maxx - t_minx;
         QuadSetup tq{};
-        if (qm) tq = setup_of(t_id); // every lane of the wave for itself: the same record, no 20-value broadcast
+        if (qm && !staged) tq = setup_of(t_id); // every lane of the wave for itself: the same record, no 20-value broadcast
         for (uint32_t k = lane; k < t_tiles; k += 64)
         {
             const uint32_t y = t_miny + k / w, x = t_minx + k % w;
-            const uint32_t val = qm ? t_id | (quadrant_mask(tq, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS) : t_id;
+            const uint32_t val = (qm && !staged) ? t_id | (quadrant_mask(tq, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS) : t_id;
             if (staged)
             {
-                stage_t[t_off - run0 + k] = y * grid_x + x;
-                stage_v[t_off - run0 + k] = val;
+                stage_t[t_off - run0 + k] = qstage ? (x | (y << 16)) : y * grid_x + x;
+                stage_v[t_off - run0 + k] = t_id;
             }
             else
             {
@@ -853,8 +859,16 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         __syncthreads();
         for (uint32_t k = t; k < run; k += 256)
         {
-            tile_out[run0 + k] = stage_t[k];
-            val_out[run0 + k] = stage_v[k];
+            uint32_t tl = stage_t[k], v = stage_v[k];
+            if (qstage)
+            {
+                const uint32_t x = tl & 0xffffu, y = tl >> 16;
+                const QuadSetup q = setup_of(v);
+                v |= quadrant_mask(q, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS;
+                tl = y * grid_x + x;
+            }
+            tile_out[run0 + k] = tl;
+            val_out[run0 + k] = v;
         }
     }
 }
