@@ -53,7 +53,7 @@ for rep in range(int(sys.argv[3]) if len(sys.argv) > 3 else 1):
             print("   radii", lo_i, radii[lo_i:hi_i].tolist())
             saved = node.saved_tensors; gb, bb, ib = saved[5:8]
             P, N, W, H = len(e), node.num_rendered, s["image_width"], s["image_height"]
-            vals = helpers.debug_read_state("vals", P, N, W, H, gb, bb, ib).numpy().astype(np.int64).ravel()
+            vals = helpers.debug_read_state("vals", P, N, W, H, gb, bb, ib).numpy().astype(np.int64).ravel() & 0x0FFFFFFF  # id bits (csrc/ts2d_support.h)
             nc = helpers.debug_read_state("n_contrib", P, N, W, H, gb, bb, ib).numpy().astype(np.int64)
             rg = helpers.debug_read_state("ranges", P, N, W, H, gb, bb, ib).numpy().astype(np.int64)
             print("   N", N, "ranges", rg.ravel().tolist()[:8], "n_contrib max", nc.max(), "min", nc.min())
