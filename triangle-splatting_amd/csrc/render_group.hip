@@ -50,7 +50,7 @@
 namespace
 {
 // ROW (ts2d_group.h) = 20 floats per entry row of the constants table:
-//   [0..3] u1x u1y u2x u2y   [4..7] u3x u3y 1/area2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [17] id   [18] position in the batch
+//   [0..3] u1x u1y u2x u2y   [4..7] u3x u3y 1/area2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [17] id   [18] the entry's position in the tile's list (plain lists, -DTS2D_NO_QMASK: in the batch)
 // (u_k = screen vertex k relative to the quadrant origin); row -1 is a dummy that fails every pixel's ecc test.  The backward appends the
 // entry's 16 gradient sums to the row (BROW floats).  A list entry is the LDS BYTE OFFSET of its row (u16): the step loops spend no
 // instruction on unpacking or scaling an index (round 3: four half-rate instructions per step gone; gfx950 issues shifts, bit-field
@@ -589,7 +589,8 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
 #endif
         const unsigned long long any = M[0] | M[1] | M[2] | M[3];
         if (any == 0) continue;
-        // compacted table rows, at most NR per pass (see the forward); back to front: the upper half of a full batch first
+        // compacted table rows, at most NR per pass (see the forward); back to front: with dense batches the low lanes first (lane 0 is the entry
+        // farthest back), with plain lists the upper half of a full batch first
         const bool anybit = (any >> lane) & 1;
         const int rank = lane_rank(any), nact = __popcll(any);
         const int lrel = last - base; // entries [0, lrel) of this batch are in front of the pixel's last contributor
