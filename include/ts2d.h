@@ -178,13 +178,22 @@ int ts2d_forward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fla
  * wait for the instance count, which the GPU publishes ~0.1 ms into the forward through a pinned word: the GPU never idles for the host's
  * round trip, the host is back while the blend kernel still runs, and *num_rendered is exact.  If *num_rendered exceeds the capacity the
  * speculative launches emitted nothing (the image is the background): the caller allocates ts2d_binning_state_bytes(*num_rendered, W, H)
- * and calls ts2d_forward_render(*num_rendered) -- the per-triangle half is done and valid.  state->binning may be NULL / 0 bytes: then only
- * that half runs (== ts2d_forward_bin).  ts2d_backward takes the exact *num_rendered. */
+ * and calls ts2d_forward_render(*num_rendered) -- the per-triangle half is done and valid.  state->binning may be NULL: then only
+ * that half runs (== ts2d_forward_bin) and the caller ALWAYS follows with ts2d_forward_render.  A non-NULL buffer too small for a single
+ * instance is refused (TS2D_ERR_CAPACITY): it would queue no render and a scene of zero instances would pass the overflow test.
+ * ts2d_backward takes the exact *num_rendered. */
 int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state,
                              const ts2d_forward_out *out, int64_t *num_rendered, void *stream);
 /* A capacity for the next forward of P triangles at this image size on the current device: 1.25 x the recent maximum of instances per
  * triangle that forwards of the same variant (flags & TS2D_FLAG_3D) and size returned here, or 0 when there is no history yet. */
 int64_t ts2d_instance_capacity_hint(int32_t P, int32_t width, int32_t height, uint32_t flags);
+/* The histories behind the hint are kept per (device, variant, image size, KEY).  The key is the calling thread's (default 0): a caller with
+ * several streams of views of one size -- train and evaluation cameras, two models in one process -- names them so that one does not size
+ * the other's buffers.  ts2d_speculative_overflow_count: how many ts2d_forward_speculative calls of this process returned a num_rendered
+ * above their capacity (each costs the caller a second render): a counter that keeps growing says the hint's 1.25 x margin is too small
+ * for the caller's sequence of views (use a key per camera group, or the exact two-call form). */
+void ts2d_set_capacity_hint_key(uint64_t key);
+uint64_t ts2d_speculative_overflow_count(void);
 /* overflowed = 1 when the last ts2d_forward on this state exceeded its capacity; num_rendered = the true instance count. */
 int ts2d_forward_status(const ts2d_state *state, int32_t P, int32_t width, int32_t height, int32_t *overflowed, int64_t *num_rendered,
                         void *stream);

@@ -10,7 +10,8 @@
  *
  * Arithmetic per element, fp32, in torch's operation order (torch/optim/adam.py, _single_tensor_adam):
  *     g            = grad * grad_scale                      (grad_scale = 1, or 1 / world for mean-reduced gradients)
- *     exp_avg      = exp_avg + (g - exp_avg) * (1 - beta1)                                  (lerp_)
+ *     exp_avg      = exp_avg + (g - exp_avg) * (1 - beta1)                                  (lerp_; for beta1 <= 0.5 ATen's other branch:
+ *                    g - (g - exp_avg) * (1 - (1 - beta1)))
  *     exp_avg_sq   = exp_avg_sq * beta2 + (1 - beta2) * g * g                               (mul_, addcmul_)
  *     denom        = sqrt(exp_avg_sq) / bias2_sqrt + eps        bias2_sqrt = sqrt(1 - beta2^t)
  *     param        = param - step_size * (exp_avg / denom)      step_size  = lr / (1 - beta1^t)

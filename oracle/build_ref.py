@@ -6,7 +6,8 @@ What this is: the reference's three torch extensions
     submodules/diff-triangle-rasterization-2D   -> oracle/_ref/_ref2d_C.so   (rasterize_triangles, rasterize_triangles_backward)
     submodules/diff-triangle-rasterization-3D   -> oracle/_ref/_ref3d_C.so
     submodules/simple-knn                       -> oracle/_ref/_refknn_C.so  (distCUDA2, nearestNeighbor)
-plus _ref3d_scalar_C.so / _ref3d_nofma_C.so: the 3D extension again with -fno-slp-vectorize / -ffp-contract=off (see CODEGEN_FLAGS)
+plus _ref3d_scalar_C.so / _ref3d_nofma_C.so: the 3D extension again with -fno-slp-vectorize / -ffp-contract=off, and _ref2d_nofma_C.so: the 2D
+extension again with -ffp-contract=off (see CODEGEN_FLAGS)
 compiled from the sources WHERE THEY LIE under /root/reference, with the toolchain this image ships for exactly that
 purpose: ROCm's `hipify-perl` (CUDA -> HIP source translation; the same step torch.utils.cpp_extension performs when a CUDA
 extension is installed on a ROCm build of PyTorch), `hipcc`, hipCUB / rocThrust, and the installed PyTorch headers and
@@ -48,6 +49,12 @@ EXTENSIONS = {
     "_ref3d_C": ("diff-triangle-rasterization-3D", ["src/forward.cu", "src/backward.cu", "src/rasterizer.cu", "src/extension_interface.cu", "ext.cpp"],
                  ["src/auxiliary.h", "src/backward.h", "src/config.h", "src/extension_interface.h", "src/forward.h", "src/param_struct.h",
                   "src/rasterizer.h"]),
+    # the 2D extension again with -ffp-contract=off (round 5): the product's and the oracle's per-triangle kernels are compiled without
+    # contraction, so against THIS build num_rendered, radii, the sorted instance list and the tile ranges are compared for equality
+    # (tests/test_reference_gpu.py::test_integer_chain_equals_the_references_uncontracted_build)
+    "_ref2d_nofma_C": ("diff-triangle-rasterization-2D", ["src/forward.cu", "src/backward.cu", "src/rasterizer.cu", "src/extension_interface.cu", "ext.cpp"],
+                       ["src/auxiliary.h", "src/backward.h", "src/config.h", "src/extension_interface.h", "src/forward.h", "src/param_struct.h",
+                        "src/rasterizer.h"]),
     # the 3D extension twice more, same sources, other code-generation switches: its per-pixel ray / plane arithmetic is so
     # ill-conditioned that WHICH products the compiler fuses into FMAs decides gradients of grazing triangles outright
     # (tests/triage/noise_floor.py, DESIGN.md "noise floor"); these builds measure the reference's distance to itself
@@ -62,7 +69,7 @@ EXTENSIONS = {
 
 # hipcc's defaults are -ffp-contract=fast plus the SLP vectorizer (which turns pairs of products into v_pk_mul_f32, i.e. keeps
 # them OUT of FMAs): "_scalar" switches the vectorizer off (every a*b+c fuses), "_nofma" switches contraction off
-CODEGEN_FLAGS = {"_ref3d_scalar_C": ["-fno-slp-vectorize"], "_ref3d_nofma_C": ["-ffp-contract=off"]}
+CODEGEN_FLAGS = {"_ref3d_scalar_C": ["-fno-slp-vectorize"], "_ref3d_nofma_C": ["-ffp-contract=off"], "_ref2d_nofma_C": ["-ffp-contract=off"]}
 
 DROP = ("cooperative_groups/reduce.h", "<cub/device/device_radix_sort.cuh>", '#include ""', "#include <>")
 

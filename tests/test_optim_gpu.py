@@ -175,3 +175,72 @@ def test_sharded_adam_on_the_hip_kernel_equals_fused_adam():
     assert p.exitcode == 0
     res = q.get(timeout=10)
     assert all(res.values()), res
+
+
+def test_sharded_adam_end_to_end_through_the_rasterizer_backward():
+    """ShardedAdam driven by a REAL rasterizer backward under `opt.bucket.capture()` -- not by gradients copied into the bucket --
+    against FusedAdam fed by ordinary autograd on the same scene: after three steps (rasterize -> loss -> backward -> step) both hold the
+    same vertex / opacity / SH parameters.  The colour tensor is registered as "shs" (the name of INTEGRATION.md's example and of the
+    reference's rasterizer argument); it lands in the bucket's `color` slot.  (world = 1: the sharding protocol itself is
+    tests/test_parallel_cpu.py's, the RCCL branch test_sharded_adam_on_the_hip_kernel_equals_fused_adam's.)"""
+    import torch
+    import helpers
+    import synthetic
+    from diff_recon_hip import FusedAdam, ShardedAdam
+    from diff_triangle_rasterization_2D import TriangleRasterizer
+    dev = "cuda"
+    s = synthetic.scene(4000, 160, 128, 2, seed=77)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs = helpers.hip_settings(s, True)
+    lrs = {"vertex": 1e-3, "opacity": 1e-2, "shs": 5e-3}
+    M = s["shs"].shape[1]
+    opt = ShardedAdam({"vertex": t(s["vertex"]), "opacity": t(s["opacity"]), "shs": t(s["shs"])}, lrs, eps=1e-15, tails={"shs": (2.5e-4, 3 * M, 3)})
+    assert set(opt.bucket.named_views()) == {"vertex", "opacity", "color"}
+    ref = {k: t(s[k]).requires_grad_() for k in ("vertex", "opacity", "shs")}
+    ropt = FusedAdam([{"params": [ref["vertex"]], "lr": lrs["vertex"]}, {"params": [ref["opacity"]], "lr": lrs["opacity"]},
+                      {"params": [ref["shs"]], "lr": lrs["shs"], "lr_tail": 2.5e-4, "tail_period": 3 * M, "tail_split": 3}], lr=0.0, eps=1e-15)
+    gi, gd, gn = t(s["dL_dout_feature"]), t(s["dL_dout_depth"]), t(s["dL_dout_normal"])
+
+    def loss_of(p):
+        c2d = torch.zeros((p["vertex"].shape[0], 2), device=dev, requires_grad=True)
+        out = TriangleRasterizer(rs)(p["vertex"], c2d, p["opacity"], shs=p["shs"])
+        return (out[0] * gi).sum() + (out[2] * gd).sum() + (out[3] * gn).sum()
+
+    for _ in range(3):
+        with opt.bucket.capture():
+            loss_of(opt.params).backward()
+        assert all(p.grad is None for p in opt.params.values())  # the gradients live in the bucket, not in .grad
+        opt.step()
+        params = opt.wait()
+        ropt.zero_grad(set_to_none=True)
+        loss_of(ref).backward()
+        ropt.step()
+    torch.cuda.synchronize()
+    for k in ref:
+        # same kernels on both sides; the only freedom is the order of the backward's atomic adds
+        scale = float(ref[k].detach().abs().max())
+        assert float((params[k].detach() - ref[k].detach()).abs().max()) <= 1e-4 * scale, k
+        assert not torch.equal(params[k].detach(), t(s[k]))  # ... and the parameters did move
+
+
+def test_sharded_adam_refuses_what_a_capture_cannot_fill():
+    """Unknown tensor names raise (a capture writes vertex / opacity / center2D / colour only); under capture the rasterizer's inputs must be
+    the optimizer's own leaves -- an activation between parameter and rasterizer raises instead of training on the wrong gradient."""
+    import torch
+    import helpers
+    import synthetic
+    from diff_recon_hip import ShardedAdam
+    from diff_triangle_rasterization_2D import TriangleRasterizer
+    dev = "cuda"
+    s = synthetic.scene(500, 64, 64, 0, seed=3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    with pytest.raises(ValueError, match="not gradient slots"):
+        ShardedAdam({"vertex": t(s["vertex"]), "sh_coefficients": t(s["shs"])}, {"vertex": 1e-3, "sh_coefficients": 1e-3})
+    with pytest.raises(ValueError, match="same gradient slot"):
+        ShardedAdam({"shs": t(s["shs"]), "color": t(s["shs"])}, {"shs": 1e-3, "color": 1e-3})
+    opt = ShardedAdam({"vertex": t(s["vertex"]), "opacity": t(s["opacity"]), "shs": t(s["shs"])}, {"vertex": 1e-3, "opacity": 1e-3, "shs": 1e-3})
+    c2d = torch.zeros((500, 2), device=dev, requires_grad=True)
+    out = TriangleRasterizer(helpers.hip_settings(s, True))(opt.params["vertex"], c2d, torch.sigmoid(opt.params["opacity"]), shs=opt.params["shs"])
+    with opt.bucket.capture():
+        with pytest.raises(RuntimeError, match="is not the parameter the bucket's optimizer owns"):
+            out[0].sum().backward()

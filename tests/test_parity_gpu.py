@@ -264,13 +264,20 @@ def test_forced_ticket_passes_match_oracle():
             assert v < (1.0 if k.startswith("int_") else GRAD_TOL if k.startswith("dL_") else IMG_TOL), (k, v)
 
 
-@pytest.mark.parametrize("P,W,H,D,variant", [
-    (1_000_000, 1920, 1080, 3, 2),   # bench.py headline
-    (300_000, 800, 800, 3, 2),       # BASELINE.json configs[1]
-    (2_000_000, 1920, 1080, 3, 2),   # configs[2]
-    (93_000, 1600, 1600, 0, 3),      # configs[3] (3D rasterizer, 800^2 x render_up_scale 2)
+@pytest.mark.parametrize("P,W,H,D,variant,gamma", [
+    (1_000_000, 1920, 1080, 3, 2, 1.0),   # bench.py headline
+    (300_000, 800, 800, 3, 2, 1.0),       # BASELINE.json configs[1]
+    (2_000_000, 1920, 1080, 3, 2, 1.0),   # configs[2]
+    (93_000, 1600, 1600, 0, 3, 1.0),      # configs[3] (3D rasterizer, 800^2 x render_up_scale 2)
+    # gamma > 1 at size: the *_mesh configurations ramp gamma 1 -> 50 (config/NerfSynthetic_VanillaTS_mesh.yaml:142-146,
+    # VanillaTS_model.py:181-192), i.e. configs[3] / [4] spend most of their iterations in the kernels' GAMMA1 = false instantiation
+    # (pow(ecc, 2 gamma): R3D/src/forward.cu:263-264, backward.cu:347-349, 384-385; R2D forward.cu:309-311, backward.cu:443-447)
+    (1_000_000, 1920, 1080, 3, 2, 50.0),
+    (1_000_000, 1920, 1080, 3, 2, 7.0),
+    (93_000, 1600, 1600, 0, 3, 50.0),
+    (93_000, 1600, 1600, 0, 3, 7.0),
 ])
-def test_full_size_against_oracle(P, W, H, D, variant):
+def test_full_size_against_oracle(P, W, H, D, variant, gamma):
     """Full-size parity against the oracle itself (not only through properties).  The OpenMP oracle needs a many-core host
     for this to stay within seconds (about 6 s for the headline on the GPU box); skipped on small hosts.
 
@@ -288,6 +295,7 @@ def test_full_size_against_oracle(P, W, H, D, variant):
         pytest.skip("full-size oracle runs need a many-core host")
     import test_parity3d_gpu as T3
     s = synthetic.scene(P, W, H, D, seed=42)
+    s["gamma"] = gamma
     of = helpers.oracle_forward(s, True, False, variant=variant)
     ob = helpers.oracle_backward(s, of, True)
     hf = helpers.hip_forward_backward(s, True, False, variant=variant)

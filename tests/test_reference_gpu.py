@@ -51,6 +51,41 @@ def _compare(a, b, rich, img_tol, grad_tol, what, s=None, of=None, variant=2):
         raise AssertionError("the 3D variant is compared through helpers.assert_inside_reference_spread_3d")
 
 
+@pytest.mark.parametrize("P,W,H,D,kw", [
+    (10_000, 256, 256, 0, {}),                    # BASELINE.json configs[0]
+    (20_000, 96, 96, 1, {"edge_px": 2.0}),        # heavy overdraw: long tile lists, many equal-depth candidates per tile
+    (1000, 320, 240, 3, {"mode": "maincu"}),      # the reference's own main.cu recipe
+    (300_000, 800, 800, 3, {}),                   # configs[1]'s shape
+    (1_000_000, 1920, 1080, 3, {}),               # the headline
+])
+def test_integer_chain_equals_the_references_uncontracted_build(P, W, H, D, kw):
+    """product == oracle == REFERENCE for the integer / index state of the 2D path, bit for bit.  The product's per-triangle
+    kernel is compiled without FMA contraction; so is oracle/_ref/_ref2d_nofma_C.so (the reference's sources, -ffp-contract=off).  Against that
+    build there is no tolerance: num_rendered, radii, tiles_touched, the reference's own SORTED instance list (BinningState::point_list,
+    R2D/src/param_struct.h:105-125, rasterizer.cu:211-222) and its tile ranges (ImageState::ranges, rasterizer.cu:229-236) equal the product's
+    private state (read by the lab library).  The sorted list being equal also says that the product's two-stage ordering (depth per triangle,
+    then tile bits per instance, both stable) resolves equal keys exactly as the reference's single stable 64-bit sort does.
+    `_same_integer_state`'s tolerances remain in use only against the CONTRACTING build (_ref2d_C)."""
+    s = synthetic.scene(P, W, H, D, seed=97 + P, **kw)
+    s["gamma"] = 1.0
+    ref = ref_build.forward_integer_state(s, "_ref2d_nofma_C")
+    hf = helpers.hip_forward_backward(s, True, False, backward=False)
+    assert hf["num_rendered"] == ref["num_rendered"]
+    assert np.array_equal(hf["radii"], ref["radii"])
+    assert np.array_equal(helpers.hip_state(hf, s, "tiles_touched").astype(np.uint32), ref["tiles_touched"])
+    n = ref["num_rendered"]
+    assert n > 0
+    assert np.array_equal(helpers.hip_state(hf, s, "vals").astype(np.uint32)[:n], ref["point_list"])
+    assert np.array_equal(helpers.hip_state(hf, s, "ranges").astype(np.uint32), ref["ranges"])
+    # the reference's sorted 64-bit keys (tile << 32 | bits of the fp32 depth, rasterizer.cu:62-66), rebuilt from the product's state by the lab reader
+    assert np.array_equal(helpers.hip_state(hf, s, "keys").view(np.uint64).reshape(-1)[:n], ref["keys"])
+    if P <= 20_000:  # and the oracle, which the CPU suite and every parity test lean on
+        of = helpers.oracle_forward(s, True, False)
+        assert of["num_rendered"] == n and np.array_equal(of["radii"], ref["radii"])
+        assert np.array_equal(of["state"].field("vals").reshape(-1)[:n], ref["point_list"])
+        assert np.array_equal(of["state"].field("keys").reshape(-1)[:n], ref["keys"])
+
+
 @pytest.mark.parametrize("variant", [2, 3])
 @pytest.mark.parametrize("P,W,H,D,rich,gamma,back_culling,kw", CASES)
 def test_oracle_and_hip_against_the_reference_build(P, W, H, D, rich, gamma, back_culling, kw, variant):
@@ -164,8 +199,9 @@ def test_headline_size_three_way_noise_floor():
     json.dump(report, open(os.path.join(out_dir, "three_way_headline.json"), "w"), indent=1)
 
 
-@pytest.mark.parametrize("P,W,H,D", [(93_000, 1600, 1600, 0), (5_000_000, 1920, 1080, 0)])  # BASELINE.json configs[3]- and configs[4]-like
-def test_3d_variant_sits_inside_the_references_own_spread(P, W, H, D):
+@pytest.mark.parametrize("P,W,H,D,gamma", [(93_000, 1600, 1600, 0, 1.0), (5_000_000, 1920, 1080, 0, 1.0),  # BASELINE.json configs[3]- and configs[4]-like
+                                           (93_000, 1600, 1600, 0, 50.0), (93_000, 1600, 1600, 0, 7.0)])      # ... and where their gamma schedule spends its time
+def test_3d_variant_sits_inside_the_references_own_spread(P, W, H, D, gamma):
     """The 3D rasterizer's per-pixel ray / plane arithmetic (R3D forward.cu:238-256) is ill-conditioned: depth = v1.n / p_ray.n
     cancels catastrophically for triangles seen edge-on, and one ulp of the depth moves the barycentrics by ~depth / edge ulps, so
     WHICH products the compiler fuses into FMAs decides argmin ties and whole gradients of grazing triangles.  The yardstick is
@@ -179,6 +215,7 @@ def test_3d_variant_sits_inside_the_references_own_spread(P, W, H, D):
       * against every build it is no further than the widest distance between two builds (x 1.25);
       * images and the well-conditioned gradients meet the north-star bars against every build outright."""
     s = synthetic.scene(P, W, H, D, seed=42)
+    s["gamma"] = gamma
     builds = {b: ref_build.forward_backward(s, True, False, variant=3, build=b) for b in ("_ref3d_C", "_ref3d_scalar_C", "_ref3d_nofma_C")}
     hf = helpers.hip_forward_backward(s, True, False, variant=3)
     names = list(builds)

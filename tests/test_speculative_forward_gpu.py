@@ -103,6 +103,39 @@ def test_speculative_c_abi_contract():
     assert L.ts2d_forward_status(C.byref(st), P, W, H, C.byref(over), C.byref(n_true), stream) == 0 and over.value == 0
     ref = helpers.oracle_forward(s, True)
     assert helpers.rel_l2(img.cpu().numpy(), ref["out_feature"]) < 1e-4
+    # a non-NULL binning buffer too small for any instance is refused (it would queue no render, and a scene of zero instances
+    # would then pass the caller's  num_rendered > capacity  test with 0 > 0 and leave the outputs unwritten)
+    tiny = torch.empty(64, **u8)
+    assert L.ts2d_binning_capacity(tiny.numel(), W, H) == 0
+    st = _C._State(g.data_ptr(), g.numel(), tiny.data_ptr(), tiny.numel(), im.data_ptr(), im.numel())
+    assert L.ts2d_forward_speculative(C.byref(cam), C.byref(geom), flags, radii.data_ptr(), C.byref(st), C.byref(out), C.byref(n), stream) == 3  # TS2D_ERR_CAPACITY
+    assert b"too small for any instance" in L.ts2d_last_error()
+
+
+def test_capacity_hint_keys_and_the_overflow_counter():
+    """the histories behind ts2d_instance_capacity_hint are kept per caller key, so a stream of small views (key 1) is not sized by
+    a stream of large ones (key 2) of the same image size; every speculative forward whose guess was too small is counted."""
+    import diff_triangle_rasterization_2D as pkg
+    P = 7000
+    small = synthetic.scene(P, 208, 176, 1, seed=31, edge_px=3.0)
+    large = synthetic.scene(P, 208, 176, 1, seed=32, edge_px=14.0)
+    hint = lambda: int(pkg._C._lib.ts2d_instance_capacity_hint(P, 208, 176, 0))
+    try:
+        pkg.set_capacity_hint_key(1)
+        n_small = helpers.hip_forward_backward(small, True, backward=False)["num_rendered"]
+        pkg.set_capacity_hint_key(2)
+        assert hint() == 0                                   # key 2 has no history although key 1 rendered this size
+        n_large = helpers.hip_forward_backward(large, True, backward=False)["num_rendered"]
+        assert n_large > 2 * n_small and hint() >= n_large
+        pkg.set_capacity_hint_key(1)
+        assert n_small < hint() < n_large                    # ... and key 1's history is untouched by the large views
+        before = pkg.speculative_overflows()
+        helpers.hip_forward_backward(small, True, backward=False)   # fits
+        assert pkg.speculative_overflows() == before
+        got = helpers.hip_forward_backward(large, True, backward=False)  # key 1's guess is too small for the large view: counted, result exact
+        assert pkg.speculative_overflows() == before + 1 and got["num_rendered"] == n_large
+    finally:
+        pkg.set_capacity_hint_key(0)
 
 
 def test_capture_through_render_view_keeps_the_chain_rule():

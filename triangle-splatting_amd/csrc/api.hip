@@ -116,9 +116,7 @@ int validate(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags)
     if (cam->width <= 0 || cam->height <= 0) return fail(TS2D_ERR_INVALID, "image size must be positive");
     if (cam->width > 65535 * TS_TILE || cam->height > 65535 * TS_TILE) return fail(TS2D_ERR_INVALID, "image too large");
     if (geom->P < 0) return fail(TS2D_ERR_INVALID, "P must be >= 0");
-#ifdef TS2D_QMASK
-    if (geom->P > 0x0FFFFFFF) return fail(TS2D_ERR_CAPACITY, "more than 2^28 - 1 triangles: the instance values keep four bits for the quadrant mask");
-#endif
+    if (geom->P > (int)TS_ID_MASK) return fail(TS2D_ERR_CAPACITY, "more than 2^28 - 1 triangles: the instance values keep four bits for the quadrant mask");
     if (geom->C > TS2D_MAX_CHANNELS) // extension_interface.cu:65-68
         return fail(TS2D_ERR_INVALID, "feature's num_channels can't be larger than MAX_CHANNELS");
     if (geom->C < 1) return fail(TS2D_ERR_INVALID, "need at least one colour channel");
@@ -248,7 +246,11 @@ int wait_early_count(const EarlyCount &early, unsigned long long *n_out)
 // ---- capacity hints for the speculative forward ------------------------------------------------------------------------------------
 // What the last forwards of a given (device, variant, image size) rendered, per triangle: the next call's binning buffer is sized for 1.25 x
 // the recent maximum.  A wrong guess costs one cheap overflow (nothing is emitted) and the reference's sequence for that call, never a result.
-struct CapacityHint { int dev, variant, W, H; double per_triangle; unsigned long long stamp; };
+// Slots are keyed by (device, variant, image size, CALLER KEY): train and evaluation cameras of one size, or two models in one process, keep
+// separate histories when the caller names them (ts2d_set_capacity_hint_key, thread-local, default 0).
+struct CapacityHint { int dev, variant, W, H; unsigned long long key; double per_triangle; unsigned long long stamp; };
+thread_local unsigned long long t_hint_key = 0;
+std::atomic<unsigned long long> g_speculative_overflows{0};
 std::mutex g_hint_mu;
 std::vector<CapacityHint> g_hints;
 unsigned long long g_hint_clock = 0;
@@ -261,16 +263,16 @@ void record_instance_count(int variant, int W, int H, int P, unsigned long long 
     std::lock_guard<std::mutex> lk(g_hint_mu);
     CapacityHint *slot = nullptr;
     for (auto &h : g_hints)
-        if (h.dev == dev && h.variant == variant && h.W == W && h.H == H) slot = &h;
+        if (h.dev == dev && h.variant == variant && h.W == W && h.H == H && h.key == t_hint_key) slot = &h;
     if (!slot)
     {
-        if (g_hints.size() < 32) { g_hints.push_back({dev, variant, W, H, 0.0, 0}); slot = &g_hints.back(); }
+        if (g_hints.size() < 32) { g_hints.push_back({dev, variant, W, H, t_hint_key, 0.0, 0}); slot = &g_hints.back(); }
         else // recycle the entry that was used longest ago
         {
             slot = &g_hints[0];
             for (auto &h : g_hints)
                 if (h.stamp < slot->stamp) slot = &h;
-            *slot = {dev, variant, W, H, 0.0, 0};
+            *slot = {dev, variant, W, H, t_hint_key, 0.0, 0};
         }
     }
     slot->per_triangle = per > 0.97 * slot->per_triangle ? per : 0.97 * slot->per_triangle; // a decaying maximum over the recent views
@@ -311,7 +313,7 @@ int64_t ts2d_instance_capacity_hint(int32_t P, int32_t W, int32_t H, uint32_t fl
     const int variant = (flags & TS2D_FLAG_3D) ? 3 : 2;
     std::lock_guard<std::mutex> lk(g_hint_mu);
     for (auto &h : g_hints)
-        if (h.dev == dev && h.variant == variant && h.W == W && h.H == H)
+        if (h.dev == dev && h.variant == variant && h.W == W && h.H == H && h.key == t_hint_key)
         {
             h.stamp = ++g_hint_clock;
             const double want = 1.25 * h.per_triangle * (double)P + 4096.0;
@@ -392,11 +394,8 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     if (P > 0)
     {
         {
-#ifdef TS2D_QMASK // quadrant masks for the 2D blend kernels (ts2d_support.h); the 3D kernels take plain ids
+            // quadrant masks for the 2D blend kernels (ts2d_support.h); the 3D kernels take plain ids
             const float quad_g2 = (flags & TS2D_FLAG_3D) ? -1.0f : fmaxf(0.0f, 2.0f * geom->gamma); // 2 gamma < 1e-6: the whole ecc <= 10 region
-#else
-            const float quad_g2 = -1.0f;
-#endif
             ProfScope ps("emit_keys", s);
             ts_launch_emit_keys(P, r.grid_x, ntiles, g, b, im, rich ? out->contrib_sum : nullptr, rich ? out->contrib_max : nullptr,
                                 n_dev ? N : -1, im.status, quad_g2, s);
@@ -526,7 +525,10 @@ int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, 
     if (P == 0) return forward_render_impl(cam, geom, flags, 0, nullptr, state, out, s); // extension_interface.cu:130: background only
     if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
     int64_t cap = state->binning ? ts_binning_capacity(state->binning_bytes, W, H) : 0;
-    if (cap < 0) cap = 0;
+    // a buffer too small for even an empty binning state would queue no render, and a scene of zero instances would then leave the outputs
+    // unwritten without tripping the caller's  num_rendered > capacity  test (0 > 0): refuse it; no buffer at all (NULL) is the
+    // documented "first call" form (== ts2d_forward_bin, the caller then runs ts2d_forward_render)
+    if (state->binning && cap <= 0) return fail(TS2D_ERR_CAPACITY, "binning state buffer too small for any instance (pass NULL to size it from num_rendered)");
     EarlyCount early;
     const bool have_early = acquire_early_count(early);
     if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, have_early ? &early : nullptr)) return rc;
@@ -552,8 +554,12 @@ int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, 
         return fail(TS2D_ERR_CAPACITY, "%llu tile instances exceed the 2^31 - 1 the instance list can address", n);
     *num_rendered = (int64_t)n;
     record_instance_count((flags & TS2D_FLAG_3D) ? 3 : 2, W, H, P, n);
+    if (cap > 0 && (int64_t)n > cap) g_speculative_overflows.fetch_add(1, std::memory_order_relaxed); // the caller now renders a second time
     return TS2D_OK;
 }
+
+void ts2d_set_capacity_hint_key(uint64_t key) { t_hint_key = key; }
+uint64_t ts2d_speculative_overflow_count(void) { return g_speculative_overflows.load(std::memory_order_relaxed); }
 
 int ts2d_forward_status(const ts2d_state *state, int32_t P, int32_t width, int32_t height, int32_t *overflowed, int64_t *num_rendered,
                         void *stream)
@@ -956,7 +962,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
             TS_HIP(hipStreamSynchronize(s));
         }
         uint64_t *o = (uint64_t *)dst;
-        for (int64_t i = 0; i < N; i++) o[i] = ((uint64_t)tile[i] << 32) | depth[vals[i] & 0x0FFFFFFFu]; // id bits (the top four: quadrant mask, ts2d_support.h)
+        for (int64_t i = 0; i < N; i++) o[i] = ((uint64_t)tile[i] << 32) | depth[vals[i] & TS_ID_MASK]; // id bits (the top four: quadrant mask, ts2d_support.h)
         return TS2D_OK;
     }
     case 11: src = b.vals; bytes = (size_t)N * 4; break;

@@ -781,7 +781,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     }
     const uint32_t minx = rect.x & 0xffffu, miny = rect.x >> 16, maxx = rect.y & 0xffffu, maxy = rect.y >> 16;
     uint32_t *tile_out = b.k[0], *val_out = b.v[0];
-    // quad_g2 >= 0 (-DTS2D_QMASK builds, 2D variant; the value is 2 gamma): the four spare bits of an instance's value say which 8x8 quadrants
+    // quad_g2 >= 0 (2D variant; the value is 2 gamma): the four spare bits of an instance's value say which 8x8 quadrants
     // of its tile the triangle's support can reach (ts2d_support.h); the blend kernels' quadrant waves then skip the other entries unseen
     const bool qm = quad_g2 >= 0.0f;
     auto setup_of = [&](uint32_t tri) {

@@ -22,7 +22,9 @@ struct AdamTable
 __device__ __forceinline__ void adam_element(float &p, float g, float &m, float &v, const AdamTable &t, float step_size, float bias2_sqrt, float grad_scale)
 {
     g = g * grad_scale;
-    m = m + (g - m) * t.w1;                       // exp_avg.lerp_(grad, 1 - beta1)
+    // exp_avg.lerp_(grad, 1 - beta1): ATen's lerp (aten/src/ATen/native/Lerp.h) takes  self + w (end - self)  for |w| < 0.5 and
+    // end - (end - self)(1 - w)  otherwise (beta1 <= 0.5) -- both forms, so that the 1-ulp statement of include/ts_optim.h holds for every beta1
+    m = t.w1 < 0.5f ? m + (g - m) * t.w1 : g - (g - m) * (1.0f - t.w1);
     v = v * t.beta2;                              // exp_avg_sq.mul_(beta2)
     v = v + (t.w2 * g) * g;                       // .addcmul_(grad, grad, value = 1 - beta2)
     const float denom = __fsqrt_rn(v) / bias2_sqrt + t.eps;

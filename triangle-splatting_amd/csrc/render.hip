@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(256) render_fwd_kernel(RenderArgs a, const uin
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
         if (valid)
         {
-            id = point_list[range.x + k] & 0x0FFFFFFFu; // id bits (-DTS2D_QMASK: the top four are a quadrant mask, ts2d_support.h)
+            id = point_list[range.x + k] & TS_ID_MASK; // id bits (the top four are a quadrant mask, ts2d_support.h)
             const float4 *rp = rec + 4 * (size_t)id;
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
             if (RICH) r3 = rp[3];
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(256, MFMA ? 4 : 7) render_bwd_kernel(RenderArg
         float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
         if (valid)
         {
-            id = point_list[range.x + k] & 0x0FFFFFFFu; // id bits (-DTS2D_QMASK: the top four are a quadrant mask, ts2d_support.h)
+            id = point_list[range.x + k] & TS_ID_MASK; // id bits (the top four are a quadrant mask, ts2d_support.h)
             const float4 *rp = rec + 4 * (size_t)id;
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
             if (RICH) r3 = rp[3];

@@ -50,7 +50,7 @@
 namespace
 {
 // ROW (ts2d_group.h) = 20 floats per entry row of the constants table:
-//   [0..3] u1x u1y u2x u2y   [4..7] u3x u3y 1/area2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [17] id   [18] the entry's position in the tile's list (plain lists, -DTS2D_NO_QMASK: in the batch)
+//   [0..3] u1x u1y u2x u2y   [4..7] u3x u3y 1/area2 opacity   [8..11] r g b nx   [12..15] ny nz vd1 vd2   [16] vd3   [17] id   [18] the entry's position in the tile's list
 // (u_k = screen vertex k relative to the quadrant origin); row -1 is a dummy that fails every pixel's ecc test.  The backward appends the
 // entry's 16 gradient sums to the row (BROW floats).  A list entry is the LDS BYTE OFFSET of its row (u16): the step loops spend no
 // instruction on unpacking or scaling an index (round 3: four half-rate instructions per step gone; gfx950 issues shifts, bit-field
@@ -88,7 +88,7 @@ template <bool RICH>
 __device__ __forceinline__ uint32_t republish_row(float *row, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, uint32_t pos,
                                                   int jpos, float OX, float OY)
 {
-    const uint32_t id = point_list[pos] & TS_ID_MASK; // -DTS2D_QMASK: the top bits are the instance's quadrant mask
+    const uint32_t id = point_list[pos] & TS_ID_MASK; // the top bits are the instance's quadrant mask
     const float4 *rp = rec + 4 * (size_t)id;
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = RICH ? rp[3] : make_float4(0, 0, 0, 0);
     BlockCull s;
@@ -143,11 +143,7 @@ __device__ __forceinline__ void write_dummy_row(float *row, int lane)
         if (lane == 0 || lane == 1 || lane == 3 || lane == 4) v = 1000.0f;
         if (lane == 2 || lane == 5) v = 1001.0f;
         if (lane == 6) v = 1.0f;
-#ifdef TS2D_QMASK
         if (lane == 18) v = __int_as_float(0x7fffffff); // list position of the dummy: beyond every pixel's range
-#else
-        if (lane == 18) v = __int_as_float(255); // batch position of the dummy: beyond every pixel's range
-#endif
         row[lane] = v;
     }
 }
@@ -230,11 +226,9 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
 #ifdef TS2D_STATS
     unsigned long long stat_acc[12] = {0, 0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0};
 #endif
-#ifdef TS2D_QMASK
     // dense batches: only the entries whose quadrant bit is set are gathered and culled (ts2d_group.h, stream_refill); `pos` = list position
     uint32_t id = 0;
     int pos = 0, cursor = 0;
-    constexpr int base = 0; // row column 18 holds the list position itself
     for (;;)
     {
         const unsigned long long alive = ballot(!done);
@@ -251,24 +245,6 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
             if (RICH) r3 = rp[3];
         }
-#else
-    for (int base = 0; base < len; base += 64)
-    {
-        const unsigned long long alive = ballot(!done);
-        if (alive == 0) break;
-        const int k = base + lane;
-        const bool valid = k < len;
-        const int ent = lane, pos = k; // row column 18 holds the position inside the batch
-        uint32_t id = 0;
-        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-        if (valid)
-        {
-            id = point_list[range.x + k];
-            const float4 *rp = rec + 4 * (size_t)id;
-            r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
-            if (RICH) r3 = rp[3];
-        }
-#endif
         const BlockCull s = block_cull<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
         // one entry mask per block; a block whose 16 pixels are all saturated takes no more entries
         unsigned long long M[4];
@@ -333,7 +309,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
                         const float4 q2 = *(const float4 *)(row + 8);
                         float4 q3 = make_float4(0, 0, 0, 0);
                         float vd3 = 0.0f;
-                        int jpos; // position in the batch
+                        int jpos; // position in the tile's list
                         if (RICH)
                         {
                             q3 = *(const float4 *)(row + 12);
@@ -364,7 +340,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
                         }
                         T *= (1.0f - al);
                         const bool sat = hit && T <= 0.0001f; // forward.cu:333
-                        last = sat ? (uint32_t)(base + jpos + 1) : last;
+                        last = sat ? (uint32_t)(jpos + 1) : last;
                         done = done || sat;
                     }
                 }
@@ -378,7 +354,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
                     // instruction, ds_add_f32 193) -- no ordering between groups or waves is needed.
                     const float sm = row_reduce8(c, rsel, OpAdd());
                     const float mx = row_reduce8(c, rsel, OpMax());
-                    const int k = base + (int)row_select8(cjc, rsel);
+                    const int k = (int)row_select8(cjc, rsel);
                     if ((lane & 1) == 0 && sm > 0.0f) tile_stats_add<TCAP>(tsum, tmax, k, sm, mx, point_list + range.x, contrib_sum, contrib_max);
                 }
 #endif
@@ -537,10 +513,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
     const int maxlast = max(max(glast[0], glast[1]), max(glast[2], glast[3]));
     if (maxlast <= 0) return;
 
-#ifdef TS2D_QMASK
     // dense batches, walked back to front: lane 0 holds the entry farthest back (ts2d_group.h, stream_refill<true>); `pos` = list position
-    constexpr bool FRONT_LANE_FIRST = true; // processing order inside a batch = ascending lane
-    constexpr int base = 0;                 // row column 18 holds the list position itself
     uint32_t id = 0;
     int pos = 0, cursor = maxlast;
     for (;;)
@@ -561,41 +534,13 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
         unsigned long long M[4];
 #pragma unroll
         for (int g = 0; g < 4; g++) M[g] = ballot(valid && s.ov[g] && pos < glast[g]); // entries at or behind glast[g] are skipped by all of block g's pixels
-#else
-    constexpr bool FRONT_LANE_FIRST = false; // a batch holds ascending list positions: back to front = descending lane
-    for (int base = ((maxlast - 1) >> 6) << 6; base >= 0; base -= 64)
-    {
-        const int k = base + lane;
-        const bool valid = k < maxlast;
-        const int ent = lane, pos = k; // row column 18 holds the position inside the batch
-        uint32_t id = 0;
-        float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
-        if (valid)
-        {
-            id = point_list[range.x + k];
-            const float4 *rp = rec + 4 * (size_t)id;
-            r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
-            if (RICH) r3 = rp[3];
-        }
-        const BlockCull s = block_cull<GAMMA1>(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, g2, OX, OY);
-        unsigned long long M[4];
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-        {
-            const int n = glast[g] - base; // entries [0, n) of this batch can still matter to block g
-            const unsigned long long keep = n >= 64 ? ~0ull : (n <= 0 ? 0ull : ((1ull << n) - 1ull));
-            M[g] = ballot(valid && s.ov[g]) & keep;
-        }
-#endif
         const unsigned long long any = M[0] | M[1] | M[2] | M[3];
         if (any == 0) continue;
-        // compacted table rows, at most NR per pass (see the forward); back to front: with dense batches the low lanes first (lane 0 is the entry
-        // farthest back), with plain lists the upper half of a full batch first
+        // compacted table rows, at most NR per pass (see the forward); back to front = the low lanes first (lane 0 is the entry farthest back)
         const bool anybit = (any >> lane) & 1;
         const int rank = lane_rank(any), nact = __popcll(any);
-        const int lrel = last - base; // entries [0, lrel) of this batch are in front of the pixel's last contributor
         const int r = rank & (NR - 1);
-        bool mine = anybit && (FRONT_LANE_FIRST ? rank < NR : (rank / NR) == (nact - 1) / NR);
+        bool mine = anybit && rank < NR;
         if (mine) publish_row(rows + r * BROW, s, id, ent, r1, r2, r3);
         for (int h = (nact - 1) / NR;;)
         {
@@ -612,7 +557,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
             {
                 const unsigned long long Mh = M[g] & mm;
                 const int n = __popcll(Mh);
-                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (FRONT_LANE_FIRST ? lane_rank(Mh) : n - 1 - lane_rank(Mh))] = (unsigned short)(row0 + r * (BROW * 4));
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + lane_rank(Mh)] = (unsigned short)(row0 + r * (BROW * 4));
                 steps = max(steps, n);
             }
             const u16a *mylist = (const u16a *)list + grp * NR;
@@ -641,7 +586,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
                     const float4 q2 = *(const float4 *)(row + 8);
                     float4 q3 = make_float4(0, 0, 0, 0);
                     float vd3 = 0.0f;
-                    int jpos; // position in the batch
+                    int jpos; // position in the tile's list
                     if (RICH)
                     {
                         q3 = *(const float4 *)(row + 12);
@@ -654,7 +599,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
                     const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f); // exp(-0.5 pw)
                     const float opG = q1.w * G;
                     const float alpha = fminf(0.99f, opG);
-                    const bool hit = (jpos < lrel) && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f; // backward.cu:378,393,400
+                    const bool hit = (jpos < last) && ecc_in_range(b.ecc) && alpha >= 1.0f / 255.0f; // backward.cu:378,393,400
                     // branch-free from here on: a lane that does not hit runs with alpha = 0, so T and B stay bit-unchanged and every
                     // value it feeds into the reduction is an exact 0
                     const float al = hit ? alpha : 0.0f;
@@ -735,7 +680,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
                 }
             }
             if (--h < 0) break;
-            mine = anybit && (FRONT_LANE_FIRST ? rank >= NR : rank < NR);
+            mine = anybit && rank >= NR;
             if (mine) republish_row<RICH>(rows + r * BROW, point_list, rec, range.x + pos, ent, OX, OY);
         }
     }

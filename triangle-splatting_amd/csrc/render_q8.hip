@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(256, 6) render_fwd_q8_kernel(RenderArgs a, con
             float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
             if (valid)
             {
-                id = point_list[range.x + k] & 0x0FFFFFFFu; // id bits (ts2d_support.h)
+                id = point_list[range.x + k] & TS_ID_MASK; // id bits (ts2d_support.h)
                 const float4 *rp = rec + 4 * (size_t)id;
                 r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
                 if (RICH) r3 = rp[3];
@@ -539,7 +539,7 @@ __global__ void __launch_bounds__(256, 6) render_fwd_q8_kernel(RenderArgs a, con
         for (int k = threadIdx.x; k < min(len, TCAP); k += 256)
         {
             const unsigned long long fx48 = tsum[k];
-            if (fx48 != 0ull) tile_stats_flush(fx48, tmax[k], point_list[range.x + k] & 0x0FFFFFFFu, contrib_sum, contrib_max);
+            if (fx48 != 0ull) tile_stats_flush(fx48, tmax[k], point_list[range.x + k] & TS_ID_MASK, contrib_sum, contrib_max);
         }
     }
     if (inside)
@@ -683,7 +683,7 @@ __global__ void __launch_bounds__(256, 5) render_bwd_q8_kernel(RenderArgs a, con
             float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0, r3 = r0;
             if (valid)
             {
-                id = point_list[range.x + k] & 0x0FFFFFFFu; // id bits (ts2d_support.h)
+                id = point_list[range.x + k] & TS_ID_MASK; // id bits (ts2d_support.h)
                 const float4 *rp = rec + 4 * (size_t)id;
                 r0 = rp[0]; r1 = rp[1]; r2 = rp[2];
                 if (RICH) r3 = rp[3];

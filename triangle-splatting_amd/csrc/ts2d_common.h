@@ -25,12 +25,12 @@
 #define TS_REC_FLOATS 16
 
 // Quadrant masks (ts2d_support.h): the emission kernel marks in the four spare bits of an instance's value which 8x8 quadrants of its tile the
-// triangle's support can reach, and the 2D blend kernels' quadrant waves gather and cull only those entries, in dense batches.  Round 4,
-// measured product vs -DTS2D_NO_QMASK alternating on one box (profiles/r04_qmask.txt): render_fwd 0.429 -> 0.398 ms, render_bwd 0.839 -> 0.791,
-// emission 0.029 -> 0.053, step 1.658 -> 1.604.  -DTS2D_NO_QMASK restores the plain lists (triangle ids < 2^32 instead of < 2^28).
-#if !defined(TS2D_NO_QMASK) && !defined(TS2D_QMASK)
-#define TS2D_QMASK 1
-#endif
+// triangle's support can reach, and the blend kernels' quadrant waves gather and cull only those entries, in dense batches.  Round 4,
+// measured against plain lists alternating on one box (profiles/r04_qmask.txt): render_fwd 0.429 -> 0.398 ms, render_bwd 0.839 -> 0.791,
+// emission 0.029 -> 0.053, step 1.658 -> 1.604.  The plain-list front end was deleted from the product in round 5 (it lives on in the lab
+// kernels render.hip / render_q8.hip, which ignore the mask bits): triangle ids are < 2^28 everywhere (validate() in api.hip).
+#define TS_ID_BITS 28
+#define TS_ID_MASK 0x0FFFFFFFu
 // Gradient record (16 floats = 64 B), accumulated by render_bwd, consumed by preprocess_bwd.
 //   [0..5] dL/dv{1,2,3}_2D   [6] dL/dopacity   [7..9] dL/drgb   [10..12] dL/dnormal_view   [13..15] dL/dv_depth
 #define TS_GRAD_FLOATS 16

@@ -18,7 +18,7 @@ __device__ __forceinline__ int lane_rank(unsigned long long m) // set bits of m 
 // 0 <= ecc <= 10 (forward.cu:307) as ONE unsigned compare: negative floats and NaN have larger bit patterns than 10.0f
 __device__ __forceinline__ bool ecc_in_range(float ecc) { return __float_as_uint(ecc) <= 0x41200000u; }
 
-// ---- dense batches (-DTS2D_QMASK) -------------------------------------------------------------------------------------------------------
+// ---- dense batches -------------------------------------------------------------------------------------------------------
 // The emission kernel marks in the top four bits of an instance's value which quadrants of the tile the triangle can reach (ts2d_support.h).
 // A quadrant wave reads the tile's list 64 candidates at a time and keeps the entries whose bit is set, COMPACTED: lanes [0, n) of (id, pos)
 // hold the next n entries in processing order (pos = the entry's position in the tile's list).  One refill = one ballot, one cross-lane
@@ -49,7 +49,7 @@ __device__ __forceinline__ void stream_refill(uint32_t &id, int &pos, int &n, co
         if (mt == 0) continue;
         const int cnt = __popcll(mt), rk = lane_rank(mt);
         const int dest = (taken ? n + rk : n + cnt + (lane - rk)) & 63; // a permutation of the 64 lanes
-        const uint32_t pid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(v & 0x0FFFFFFFu));
+        const uint32_t pid = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)(v & TS_ID_MASK));
         const int ppos = __builtin_amdgcn_ds_permute(dest << 2, k);
         const bool fresh = lane >= n && lane < n + cnt;
         id = fresh ? pid : id;
@@ -209,7 +209,7 @@ __device__ __forceinline__ void tile_stats_add(unsigned long long *tsum, int *tm
         __hip_atomic_fetch_add(tsum + k, to_fixed48(sm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __hip_atomic_fetch_max(tmax + k, __float_as_int(mx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
-    else global_stats_add(tile_list[k] & 0x0FFFFFFFu, sm, mx, contrib_sum, contrib_max); // list positions beyond the LDS arrays (a very long tile list); -DTS2D_QMASK: id bits only
+    else global_stats_add(tile_list[k] & TS_ID_MASK, sm, mx, contrib_sum, contrib_max); // list positions beyond the LDS arrays (a very long tile list); id bits only
 }
 __device__ __forceinline__ void tile_stats_flush(unsigned long long fx48, int mxbits, uint32_t tid, float *contrib_sum, float *contrib_max)
 {

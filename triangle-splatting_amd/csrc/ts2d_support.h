@@ -1,12 +1,11 @@
 // ts2d_support.h -- where a 2D triangle's window can reach: the scale of its support (shared by the blend kernels' block cull, render_group.hip,
-// and the emission kernel, binning.hip) and the QUADRANT MASK of an instance (-DTS2D_QMASK): which of the four 8x8 quadrants of a 16x16 tile
+// and the emission kernel, binning.hip) and the QUADRANT MASK of an instance: which of the four 8x8 quadrants of a 16x16 tile
 // the support can reach.  The emission kernel stores the mask in the four spare bits of the instance's value (triangle id < 2^28); a quadrant
 // wave of the blend kernels then gathers and culls only the entries whose bit is set (36 % of a tile's list on the headline scene).
 #pragma once
 #include "ts2d_wave.h"
 
-#define TS_ID_BITS 28
-#define TS_ID_MASK 0x0FFFFFFFu
+#include "ts2d_common.h" // TS_ID_BITS, TS_ID_MASK
 
 namespace
 {

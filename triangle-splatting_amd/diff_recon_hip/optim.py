@@ -145,14 +145,30 @@ class ShardedAdam:
         opt.step()      # reduce-scatter(grads) -> fused Adam on this rank's slice -> all-gather(params), on the bucket's side stream
         opt.wait()      # the compute stream waits; every rank now holds identical, updated parameters
 
+    Names are the rasterizer's gradient slots (GradBucket.SLOTS): "vertex", "opacity", "center2D", and ONE colour tensor under "shs",
+    "feature" or "color" (all three mean the bucket's `color` slot, which the backward fills with dL_dshs / dL_dfeature).  Any other name
+    raises: a capture would never write it, and step() reads nothing but the bucket.  For the same reason the tensors handed
+    to the rasterizer under `bucket.capture()` must BE `opt.params[...]`: the bucket holds the gradient with respect to the rasterizer's
+    input, and step() applies it to the flat parameters -- an activation in between (sigmoid(raw_opacity), cat(f_dc, f_rest)) would make
+    that the wrong gradient, so the backward refuses it (diff_triangle_rasterization_2D.__init__, `expected_inputs`).
+
     Layout of `flat_param` == layout of `bucket.flat` (tensor after tensor, padded to a multiple of 4 * world floats).  Rank r owns
     [r * n, (r + 1) * n), n = padded / world; its moments are n floats each.  `mean=True` averages the gradients over the ranks.
     `lr_tail` / `tail_period` / `tail_split` per name as in FusedAdam.  `step_fn` replaces the HIP kernel (CPU tests only)."""
+
+    SLOT_OF = {"vertex": "vertex", "opacity": "opacity", "center2D": "center2D", "shs": "color", "feature": "color", "color": "color"}
 
     def __init__(self, tensors: Dict[str, torch.Tensor], lrs: Dict[str, float], group=None, betas=(0.9, 0.999), eps: float = 1e-15,
                  mean: bool = False, tails: Optional[Dict[str, Tuple[float, int, int]]] = None, step_fn=None, force_collectives: bool = False):
         from diff_triangle_rasterization_2D.parallel import GradBucket
         names = list(tensors)
+        slots = [self.SLOT_OF.get(n) for n in names]
+        unknown = [n for n, sl in zip(names, slots) if sl is None]
+        if unknown:
+            raise ValueError(f"ShardedAdam: {unknown} are not gradient slots of the rasterizer's backward; use {sorted(self.SLOT_OF)} "
+                             "(a tensor under another name would never be written by bucket.capture() and would be stepped on stale data)")
+        if len(set(slots)) != len(slots):
+            raise ValueError(f"ShardedAdam: {names} name the same gradient slot twice (shs / feature / color are ONE slot)")
         first = tensors[names[0]]
         self.device, self.group, self.betas, self.eps, self.mean = first.device, group, betas, eps, mean
         self.lrs = dict(lrs)
@@ -162,7 +178,7 @@ class ShardedAdam:
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.rank = dist.get_rank(group) if self.world > 1 else 0
         self.force_collectives = force_collectives
-        self.bucket = GradBucket([t.shape for t in tensors.values()], self.device, group=group, names=names, force_collectives=force_collectives)
+        self.bucket = GradBucket([t.shape for t in tensors.values()], self.device, group=group, names=slots, force_collectives=force_collectives)
         self.flat_param = torch.zeros(self.bucket.padded, device=self.device, dtype=torch.float32)
         self.segments: List[Tuple[str, int, int]] = []  # (name, offset, count) inside the flat buffers
         self.params: Dict[str, torch.Tensor] = {}
@@ -173,6 +189,8 @@ class ShardedAdam:
             self.params[name] = self.flat_param[off:off + n].view(t.shape).requires_grad_(True)  # a leaf that shares the flat storage
             self.segments.append((name, off, n))
             off += n
+        # what a capture of this bucket accepts as rasterizer inputs: these very leaves (see the class doc)
+        self.bucket.expected_inputs = {sl: self.params[n] for n, sl in zip(names, slots)}
         self.slice_len = self.bucket.padded // self.world
         self.lo, self.hi = self.rank * self.slice_len, (self.rank + 1) * self.slice_len
         self.exp_avg = torch.zeros(self.slice_len, device=self.device, dtype=torch.float32)

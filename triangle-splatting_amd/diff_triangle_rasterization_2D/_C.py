@@ -103,6 +103,10 @@ _lib.ts2d_binning_capacity.restype = C.c_int64
 _lib.ts2d_binning_capacity.argtypes = [C.c_size_t, C.c_int32, C.c_int32]
 _lib.ts2d_instance_capacity_hint.restype = C.c_int64
 _lib.ts2d_instance_capacity_hint.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_uint32]
+_lib.ts2d_set_capacity_hint_key.restype = None
+_lib.ts2d_set_capacity_hint_key.argtypes = [C.c_uint64]
+_lib.ts2d_speculative_overflow_count.restype = C.c_uint64
+_lib.ts2d_speculative_overflow_count.argtypes = []
 _lib.ts2d_forward_speculative.restype = C.c_int
 _lib.ts2d_forward_speculative.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, _fp, C.POINTER(_State), C.POINTER(_ForwardOut),
                                           C.POINTER(C.c_int64), _fp]
@@ -110,6 +114,18 @@ _lib.ts2d_profile_enable.argtypes = [C.c_int]
 _lib.ts2d_profile_only.argtypes = [C.c_char_p]
 _lib.ts2d_profile_read.restype = C.c_int
 _lib.ts2d_profile_read.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+
+
+def set_capacity_hint_key(key: int) -> None:
+    """Names the stream of views the calling thread's next forwards belong to (ts2d_set_capacity_hint_key): the speculative forward sizes its
+    binning buffer from the history of (device, variant, image size, key).  Train and evaluation cameras of one size, or two models in one
+    process, should use different keys; the default is 0."""
+    _lib.ts2d_set_capacity_hint_key(int(key) & 0xFFFFFFFFFFFFFFFF)
+
+
+def speculative_overflows() -> int:
+    """How many speculative forwards of this process guessed too small a binning buffer and rendered a second time (ts2d.h)."""
+    return int(_lib.ts2d_speculative_overflow_count())
 
 
 def version() -> str:

@@ -184,6 +184,19 @@ class _RasterizeTriangles(torch.autograd.Function):
         with _snapshot_on_error("rasterize_triangles_backward", native_args, rs.debug):
             sink = _sh_grad_sink if (ctx.needs_input_grad[2] and shs.numel() > 0) else None
             bucket = _grad_bucket
+            if bucket is not None and bucket.expected_inputs is not None:
+                # the bucket's owner steps ITS parameters with what lands in the bucket (ShardedAdam): the gradient with respect to the
+                # rasterizer's input is the parameter's gradient only if the input IS that parameter
+                given = {"vertex": vertex, "opacity": opacity, "color": shs if shs.numel() > 0 else feature}
+                for slot, want in bucket.expected_inputs.items():
+                    got = given.get(slot)
+                    if got is None:
+                        continue
+                    is_leaf = ctx.input_is_leaf[{"vertex": 0, "opacity": 3, "color": 1 if shs.numel() > 0 else 2}[slot]]
+                    if not is_leaf or got.data_ptr() != want.data_ptr() or got.shape != want.shape:
+                        raise RuntimeError(f"GradBucket.capture(): the rasterizer's `{slot}` input is not the parameter the bucket's optimizer owns "
+                                           "(pass opt.params[...] itself; an operation between the parameter and the rasterizer would make the "
+                                           "bucket hold the wrong gradient)")
             place = bucket.named_views() if (bucket is not None and not bucket._filled) else None
             g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(
                 *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place)
@@ -245,4 +258,8 @@ class TriangleRasterizer(nn.Module):
             opacity, self.raster_settings)
 
 
-__all__ = ["TriangleRasterizationSettings", "TriangleRasterizer", "set_instance_capacity", "forward_overflowed"]
+set_capacity_hint_key = _C.set_capacity_hint_key      # separate binning-size histories per camera group / model (include/ts2d.h)
+speculative_overflows = _C.speculative_overflows      # forwards that guessed too small and rendered twice, since the process started
+
+__all__ = ["TriangleRasterizationSettings", "TriangleRasterizer", "set_instance_capacity", "forward_overflowed", "set_capacity_hint_key",
+           "speculative_overflows"]

@@ -65,6 +65,9 @@ class GradBucket:
         self._stream = torch.cuda.Stream(device=device) if torch.device(device).type == "cuda" else None
         self._work = None
         self._filled = False
+        # set by an owner that applies the captured gradients to ITS OWN parameters (diff_recon_hip.ShardedAdam): {slot: leaf tensor}.  A
+        # backward under capture() then insists that the rasterizer's inputs for these slots are exactly these leaves.
+        self.expected_inputs: Optional[Dict[str, torch.Tensor]] = None
 
     def views(self) -> List[torch.Tensor]:
         out, off = [], 0
