@@ -123,7 +123,14 @@ def main():
     ap.add_argument("--sync-free", action="store_true",
                     help="use the sync-free forward (ts2d_forward, capacity = 1.25 x the instance count of the cold step) instead of the "
                          "reference's sequence with its blocking read of num_rendered; overflow is checked after the timed region")
+    ap.add_argument("--hip-graph", action="store_true",
+                    help="NOT the driver's command: the step (sync-free forward, loss gradients, backward) is captured ONCE into a HIP graph "
+                         "(torch.cuda.CUDAGraph on the rasterizer's launches; the sync-free forward has no host read to break the capture) and the "
+                         "timed steps are graph replays -- what a training loop with a fixed triangle count between densifications can do.  Host "
+                         "cost per step = one graph launch; implies --sync-free, N = 1")
     args = ap.parse_args()
+    if args.hip_graph:
+        args.sync_free = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -276,6 +283,26 @@ def main():
         dominant = max(rows0, key=lambda r: r[1] / max(r[2], 1))[0] if rows0 else ""
         _C.profile_reset()
         _C.profile_only(dominant if args.timed_kernel_events == "dominant" else "")
+    eager_step = step
+    if args.hip_graph:
+        if world > 1:
+            raise SystemExit("--hip-graph is a single-GPU measurement")
+        if events:
+            _C.profile_enable(False)  # the profile hook records HIP events: not inside a capture
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # torch's capture recipe: a few eager iterations on the side stream first
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        torch.cuda.synchronize()
+        step = graph.replay
+        if events:
+            _C.profile_enable(True)
     gc.collect()
     gc.disable()
     settle_steps = max(args.settle_steps, 0)
@@ -322,7 +349,7 @@ def main():
         _C.profile_only("")
         _C.profile_enable(True)
         for _ in range(10):
-            step()
+            eager_step()  # (--hip-graph: a replay carries no per-kernel events; the table is the eager step's)
         barrier()
         warm_rows = _C.profile_read()
     gc.enable()
@@ -362,7 +389,8 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma={args.gamma:g}): fwd+bwd of one view per GPU",
                    "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N, "scene_mode": args.scene_mode, "edge_px": args.edge_px,
-                   "forward": ("sync-free (ts2d_forward, device-side instance count)" if args.sync_free else
+                   "forward": ("sync-free, the whole step replayed from ONE captured HIP graph (torch.cuda.CUDAGraph): not the driver's command" if args.hip_graph else
+                               "sync-free (ts2d_forward, device-side instance count)" if args.sync_free else
                                "speculative (ts2d_forward_speculative: queued for 1.25 x the recent instance count, exact num_rendered read back "
                                "behind the queue; the package default)"),
                    "parallelism": f"image-parallel x{world}" + ((", RCCL reduce-scatter + all-gather of one 12-float/triangle bucket the backward writes into (GradBucket.capture) + all-gather of factored SH grads (3 floats/triangle/view)" if factored
@@ -393,6 +421,8 @@ def main():
     if rank == 0:
         if events:
             rows = timed_rows  # the dominant kernel (or, with --timed-kernel-events all, every kernel), timed inside the timed region
+            if not rows:       # --hip-graph: replays carry no events; the dominant kernel's duration is the eager table's
+                rows = [r for r in warm_rows if r[0] == dominant]
             if args.timed_kernel_events == "all":
                 result["kernels_avg_ms_timed_region"] = {name: round(ms / max(n, 1), 4) for name, ms, n in rows}
                 result["config"]["gpu_busy_ms_per_step_timed_region"] = round(sum(ms / max(n, 1) for _, ms, n in rows), 4)

@@ -77,3 +77,61 @@ def test_concurrent_forwards_read_their_own_instance_count():
     for t in threads:
         t.join()
     assert not errors, errors[:3]
+
+
+@pytest.mark.parametrize("variant", [2, 3])
+def test_a_training_step_replays_from_one_hip_graph(variant):
+    """The sync-free forward has no host read, so a whole step -- forward, the loss's upstream gradients, backward -- can be captured ONCE into
+    a HIP graph (torch.cuda.CUDAGraph over the library's launches and torch's allocations) and replayed: one graph launch per step instead of
+    ~20 kernel launches, ~15 allocations and the autograd engine (bench.py --hip-graph; what bounds a 10 k-triangle step is the host).  A
+    replay on NEW parameter values (written in place, as an optimizer does) must equal the eager step on those values."""
+    import torch
+    import diff_triangle_rasterization_2D as pkg
+    from diff_triangle_rasterization_2D import TriangleRasterizer as R2
+    from diff_triangle_rasterization_3D import TriangleRasterizer as R3
+    P = 12000
+    a = synthetic.scene(P, 256, 192, 2, seed=61)
+    b = synthetic.scene(P, 256, 192, 2, seed=62)  # same camera and sizes, other triangles
+    want = helpers.hip_forward_backward(b, True, variant=variant)
+    cap = 2 * max(want["num_rendered"], helpers.hip_forward_backward(a, True, variant=variant, backward=False)["num_rendered"]) + 4096
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    vertex, shs, opacity = t(a["vertex"]).requires_grad_(True), t(a["shs"]).requires_grad_(True), t(a["opacity"]).requires_grad_(True)
+    gi, gd, gn = t(a["dL_dout_feature"]), t(a["dL_dout_depth"]), t(a["dL_dout_normal"])
+    raster = (R3 if variant == 3 else R2)(helpers.hip_settings(a, True))
+    keep = {}
+
+    def step():
+        c2d = torch.zeros((P, 2), device="cuda", requires_grad=True)
+        out = raster(vertex, c2d, opacity, shs=shs)
+        torch.autograd.backward([out[0], out[2], out[3]], [gi, gd, gn])
+        keep.update(out=out, c2d=c2d)
+
+    try:
+        pkg.set_instance_capacity(cap)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                vertex.grad = shs.grad = opacity.grad = None
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        vertex.grad = shs.grad = opacity.grad = None
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            step()
+        with torch.no_grad():  # an optimizer's in-place update
+            vertex.copy_(t(b["vertex"])); shs.copy_(t(b["shs"])); opacity.copy_(t(b["opacity"]))
+            gi.copy_(t(b["dL_dout_feature"])); gd.copy_(t(b["dL_dout_depth"])); gn.copy_(t(b["dL_dout_normal"]))
+        graph.replay()
+        torch.cuda.synchronize()
+        out = keep["out"]
+        assert np.array_equal(out[1].cpu().numpy(), want["radii"])
+        for k, got in (("out_feature", out[0]), ("depth", out[2]), ("normal", out[3])):
+            assert np.array_equal(got.detach().cpu().numpy(), want[k]), k
+        for k, got in (("contrib_sum", out[4]), ("contrib_max", out[5]), ("dL_dvertex", vertex.grad), ("dL_dshs", shs.grad),
+                       ("dL_dopacity", opacity.grad), ("dL_dcenter2D", keep["c2d"].grad)):
+            assert helpers.rel_l2(got.detach().cpu().numpy().reshape(want[k].shape), want[k]) < 1e-6, k
+        assert pkg.forward_overflowed() == (False, want["num_rendered"])
+    finally:
+        pkg.set_instance_capacity(None)

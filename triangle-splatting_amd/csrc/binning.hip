@@ -715,7 +715,7 @@ constexpr uint32_t SMALL = 32;
 
 __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
                                                          float *contrib_sum, float *contrib_max, long long capacity, int32_t *status, bool two_level,
-                                                         float quad_g2)
+                                                         QuadMaskArgs qmask)
 {
     __shared__ uint32_t wtot[4];
     __shared__ unsigned long long wpart[4];
@@ -781,12 +781,19 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     }
     const uint32_t minx = rect.x & 0xffffu, miny = rect.x >> 16, maxx = rect.y & 0xffffu, maxy = rect.y >> 16;
     uint32_t *tile_out = b.k[0], *val_out = b.v[0];
-    // quad_g2 >= 0 (2D variant; the value is 2 gamma): the four spare bits of an instance's value say which 8x8 quadrants
-    // of its tile the triangle's support can reach (ts2d_support.h); the blend kernels' quadrant waves then skip the other entries unseen
-    const bool qm = quad_g2 >= 0.0f;
-    auto setup_of = [&](uint32_t tri) {
+    // the four spare bits of an instance's value say which 8x8 quadrants of its tile the triangle's support can reach (ts2d_support.h; both
+    // variants since round 5, ts2d_common.h: QuadMaskArgs); the blend kernels' quadrant waves then skip the other entries unseen
+    constexpr bool qm = true;
+    const float quad_g2 = qmask.g2;
+    auto setup_of = [&](uint32_t tri, uint32_t tminx, uint32_t tminy, uint32_t tmaxx, uint32_t tmaxy) { // the triangle and its tile rectangle
         const float4 *rp = g.rec + 4 * (size_t)tri;
         const float4 r0 = rp[0], r1 = rp[1];
+        if (qmask.variant == 3)
+        {
+            const float E = quad_g2 == 2.0f ? support_scale<true>(1.0f, quad_g2) : support_scale<false>(1.0f, quad_g2);
+            return quad_setup_3d(r0, r1, rp[2], E, qmask.tan_fovx, qmask.tan_fovy, qmask.W, qmask.H, (float)(tminx * TS_TILE) - 1.0f,
+                                 (float)(tminy * TS_TILE) - 1.0f, (float)(tmaxx * TS_TILE), (float)(tmaxy * TS_TILE));
+        }
         const float E = quad_g2 == 2.0f ? support_scale<true>(r1.z, quad_g2) : support_scale<false>(r1.z, quad_g2);
         return quad_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, E);
     };
@@ -795,16 +802,29 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     // stores a few slots apart from its neighbours' (a 32-64 byte fabric write each on this chip); runs of up to STAGE instances are put
     // together in LDS instead and leave as coalesced rows.
     constexpr uint32_t STAGE = 2048;
-    __shared__ uint32_t stage_t[STAGE], stage_v[STAGE];
+    // stage_t: a staged instance's tile; region B: its value (plain staging) or -- when the masks are formed -- the 256 triangles' affine mask
+    // constants (ts2d_support.h: QuadAffine, 64 bytes each), in which case a staged instance is (dx | dy << 12 | triangle slot << 24)
+    __shared__ uint32_t stage_t[STAGE];
+    __shared__ __attribute__((aligned(16))) float4 region_b[256 * 4];
+    uint32_t *const stage_v = (uint32_t *)region_b;
     const uint32_t run0 = (uint32_t)qbase, run = wtot[0] + wtot[1] + wtot[2] + wtot[3];
     const bool staged = run <= STAGE;
     // Staged runs form their masks in the flush loop below, one lane per INSTANCE, evenly spread over the block (a lane that walks its triangle's
-    // tiles makes the whole wave wait for the triangle with the most tiles); the tile travels through LDS as (x | y << 16).  Measured at 1 M
-    // triangles: 0.052 ms against 0.053 with the test inside the tile loops and 0.029 without masks -- the cost is the test itself (~130 VALU
-    // instructions and a 32-byte record gather per instance), not the imbalance.  Runs too long for the stage (big triangles) test per tile
-    // where they write.
+    // tiles makes the whole wave wait for the triangle with the most tiles).  Round 4 gathered the triangle's record and redid the whole setup
+    // per instance (~130 VALU instructions + a 32-byte gather each: 0.052 ms against 0.029 without masks at 1 M triangles); round 5 does the
+    // setup once per TRIANGLE, leaves its 16 affine constants in LDS, and an instance costs two FMAs per edge + the compares.  Runs too long
+    // for the stage (big triangles) test per tile where they write.
     const bool qstage = qm && staged;
-    if (qm && !staged && tiles > 0 && tiles <= SMALL) qs = setup_of(id);
+    const uint32_t rw = maxx - minx, rh = maxy - miny;
+    if (qm && tiles > 0)
+    {
+        qs = setup_of(id, minx, miny, maxx, maxy);
+        if (qstage)
+        {
+            const QuadAffine qa = quad_anchor(qs, id, minx, miny, rw, rh);
+            region_b[4 * t] = qa.a; region_b[4 * t + 1] = qa.b; region_b[4 * t + 2] = qa.c; region_b[4 * t + 3] = qa.d;
+        }
+    }
     if (tiles > 0 && tiles <= SMALL)
     {
         uint32_t o = off;
@@ -814,8 +834,8 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
             for (uint32_t y = miny; y < maxy; y++)
                 for (uint32_t x = minx; x < maxx; x++)
                 {
-                    stage_t[o] = qstage ? (x | (y << 16)) : y * grid_x + x;
-                    stage_v[o] = id;
+                    stage_t[o] = qstage ? ((x - minx) | ((y - miny) << 12) | ((uint32_t)t << 24)) : y * grid_x + x;
+                    if (!qstage) stage_v[o] = id;
                     o++;
                 }
         }
@@ -833,24 +853,23 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     {
         const int j = __builtin_ctzll(big);
         big &= big - 1;
-        const uint32_t t_minx = __shfl(minx, j), t_miny = __shfl(miny, j), t_maxx = __shfl(maxx, j);
+        const uint32_t t_minx = __shfl(minx, j), t_miny = __shfl(miny, j), t_maxx = __shfl(maxx, j), t_maxy = __shfl(maxy, j);
         const uint32_t t_tiles = __shfl(tiles, j), t_off = __shfl(off, j), t_id = __shfl(id, j);
         const uint32_t w = t_maxx - t_minx;
         QuadSetup tq{};
-        if (qm && !staged) tq = setup_of(t_id); // every lane of the wave for itself: the same record, no 20-value broadcast
+        if (qm && !staged) tq = setup_of(t_id, t_minx, t_miny, t_maxx, t_maxy); // every lane of the wave for itself: the same record, no 20-value broadcast
         for (uint32_t k = lane; k < t_tiles; k += 64)
         {
             const uint32_t y = t_miny + k / w, x = t_minx + k % w;
-            const uint32_t val = (qm && !staged) ? t_id | (quadrant_mask(tq, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS) : t_id;
             if (staged)
             {
-                stage_t[t_off - run0 + k] = qstage ? (x | (y << 16)) : y * grid_x + x;
-                stage_v[t_off - run0 + k] = t_id;
+                stage_t[t_off - run0 + k] = qstage ? ((k % w) | ((k / w) << 12) | ((uint32_t)(wave * 64 + j) << 24)) : y * grid_x + x;
+                if (!qstage) stage_v[t_off - run0 + k] = t_id;
             }
             else
             {
                 tile_out[t_off + k] = y * grid_x + x;
-                val_out[t_off + k] = val;
+                val_out[t_off + k] = qm ? t_id | (quadrant_mask(tq, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS) : t_id;
             }
         }
     }
@@ -859,14 +878,17 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
         __syncthreads();
         for (uint32_t k = t; k < run; k += 256)
         {
-            uint32_t tl = stage_t[k], v = stage_v[k];
+            uint32_t tl = stage_t[k], v;
             if (qstage)
             {
-                const uint32_t x = tl & 0xffffu, y = tl >> 16;
-                const QuadSetup q = setup_of(v);
-                v |= quadrant_mask(q, (float)(x * TS_TILE), (float)(y * TS_TILE)) << TS_ID_BITS;
+                const uint32_t dx = tl & 0xfffu, dy = (tl >> 12) & 0xfffu, slot = tl >> 24;
+                QuadAffine qa;
+                qa.a = region_b[4 * slot]; qa.b = region_b[4 * slot + 1]; qa.c = region_b[4 * slot + 2]; qa.d = region_b[4 * slot + 3];
+                const uint32_t org = __float_as_uint(qa.d.z), x = (org & 0xffffu) + dx, y = (org >> 16) + dy;
+                v = __float_as_uint(qa.d.y) | (quadrant_mask_affine(qa, dx, dy, x, y) << TS_ID_BITS);
                 tl = y * grid_x + x;
             }
+            else v = stage_v[k];
             tile_out[run0 + k] = tl;
             val_out[run0 + k] = v;
         }
@@ -970,11 +992,11 @@ void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 }
 
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
-                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, float quad_g2, hipStream_t s)
+                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, const QuadMaskArgs &qmask, hipStream_t s)
 {
     if (P <= 0) return;
     hipLaunchKernelGGL(scan_emit_kernel, dim3((unsigned)(((P + SB - 1) / SB) * 4)), dim3(256), 0, s, P, grid_x, ntiles, g, b, im.ranges, contrib_sum,
-                       contrib_max, (long long)capacity, status, scan_two_level(P), quad_g2);
+                       contrib_max, (long long)capacity, status, scan_two_level(P), qmask);
 }
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P) { return (const unsigned long long *)(g.blocksum + (P + SB - 1) / SB); }
 

@@ -169,7 +169,7 @@ __global__ void __launch_bounds__(256) render3d_fwd_kernel(RenderArgs a, float t
         float4 r0 = make_float4(0, 0, 1, 0), r1 = make_float4(1, 0, 0, 1), r2 = make_float4(1, 0, 0, 1), r3 = make_float4(0, 0, 0, 0);
         if (valid)
         {
-            id = point_list[range.x + k];
+            id = point_list[range.x + k] & TS_ID_MASK; // id bits (the top four are a quadrant mask, ts2d_support.h)
             const float4 *rp = rec + 4 * (size_t)id;
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
         }
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(256) render3d_bwd_kernel(RenderArgs a, float t
         float4 r0 = make_float4(0, 0, 1, 0), r1 = make_float4(1, 0, 0, 1), r2 = make_float4(1, 0, 0, 1), r3 = make_float4(0, 0, 0, 0);
         if (valid)
         {
-            id = point_list[range.x + k];
+            id = point_list[range.x + k] & TS_ID_MASK; // id bits (the top four are a quadrant mask, ts2d_support.h)
             const float4 *rp = rec + 4 * (size_t)id;
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
         }

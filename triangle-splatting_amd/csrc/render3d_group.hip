@@ -13,11 +13,15 @@
 //     p_vk = v_k - p_view, a1 = cross(p_v2, p_v3).n / n.n, a2 = cross(p_v3, p_v1).n / n.n, and the gradient terms of
 //     backward.cu:376-420 -- round 1 used projective affine forms N_k(q) / Den(q) and moment sums, which deliberately left
 //     the reference's rounding behaviour (its parity tests needed explained-outlier clauses);
+//   * the lists are read in DENSE batches (round 5, as render_group.hip since round 4): the emission kernel marks in the top four bits of an
+//     instance's value which quadrants the triangle's support -- scaled for the backward's G >= 1/255 test, projected -- can reach
+//     (ts2d_support.h: quad_setup_3d), a quadrant wave gathers and culls only those entries, compacted by stream_refill;
 //   * only CULLING uses the affine forms (N_k, Den affine in the in-quadrant pixel offset; a_k >= m  <=>  s (N_k - m Den) >= 0
 //     wherever Den keeps its sign s over the 4x4 block), with the rounding slack added to the acceptance margin.
 #include "ts2d_common.h"
 #include "ts2d_wave.h"
 #include "ts2d_group.h"
+#include "ts2d_support.h"
 
 namespace
 {
@@ -93,7 +97,7 @@ __device__ __forceinline__ Cull3 cull3(V3 v1, V3 v2, V3 v3, V3 n, float op, floa
     return c;
 }
 
-// [19] = the entry's position in its batch; a list entry is the LDS byte offset of its row (render_group.hip, round 3)
+// [19] = the entry's position in the tile's list; a list entry is the LDS byte offset of its row (render_group.hip, round 3)
 // backward row: constants, k1 = n x (v3 - v2) and k2 = n x (v1 - v3) (the ray-independent halves of d a1 / d depth = n . ((v3 - v2) x p_ray)
 // = p_ray . k1 and d a2 / d depth = p_ray . k2, backward.cu:389, 395: two dot products per pixel instead of two differences and two cross
 // products), the entry's 16 gradient sums
@@ -118,7 +122,7 @@ __device__ __forceinline__ void publish_row3(float *row, V3 v1, V3 v2, V3 v3, V3
 __device__ __forceinline__ void republish_row3(float *row, const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec, uint32_t pos,
                                                bool with_id, int jpos)
 {
-    const uint32_t id = point_list[pos];
+    const uint32_t id = point_list[pos] & TS_ID_MASK; // the top bits are the instance's quadrant mask
     const float4 *rp = rec + 4 * (size_t)id;
     const float4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
     const V3 v1 = {r0.x, r0.y, r0.z}, v2 = {r0.w, r1.x, r1.y}, v3 = {r1.z, r1.w, r2.x}, n = {r2.y, r2.z, r2.w};
@@ -133,9 +137,9 @@ __device__ __forceinline__ void write_dummy_row3(float *row, int lane)
 {
     if (lane < ROW)
     {
-        // v1 = (1000, 1000, 1), v2 = (1001, 1000, 1), v3 = (1000, 1001, 1), n = (0, 0, 1), d0 = 1, 1/n.n = 1; batch position 255
+        // v1 = (1000, 1000, 1), v2 = (1001, 1000, 1), v3 = (1000, 1001, 1), n = (0, 0, 1), d0 = 1, 1/n.n = 1
         const float tab[ROW] = {1000.0f, 1000.0f, 1.0f, 1001.0f, 1000.0f, 1.0f, 1000.0f, 1001.0f, 1.0f, 0.0f, 0.0f, 1.0f, 1.0f, 1.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-        row[lane] = lane == 19 ? __int_as_float(255) : tab[lane];
+        row[lane] = lane == 19 ? __int_as_float(0x7fffffff) : tab[lane]; // list position of the dummy: beyond every pixel's range
     }
 }
 
@@ -227,23 +231,26 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
     write_dummy_row3(cst - ROW, lane);
     const char *lds0 = (const char *)cst_all;
     const uint32_t row0 = (uint32_t)(wave * (NR + 1) + 1) * (ROW * 4), dummy = row0 - ROW * 4;
-    const RowSel rsel(lane);
+    const int stat_step = ((lane >> 3) & 1) | ((lane >> 1) & 2) | ((lane << 1) & 4); // the step of a window whose statistics this lane ends up with
 
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, anx = 0.0f, any_ = 0.0f, anz = 0.0f, ad = 0.0f;
     bool done = !inside;
     uint32_t last = (uint32_t)len;
 
-    for (int base = 0; base < len; base += 64)
+    // dense batches: only the entries whose quadrant bit is set are gathered and culled (ts2d_group.h, stream_refill); `pos` = list position
+    uint32_t id = 0;
+    int pos = 0, cursor = 0;
+    for (;;)
     {
         const unsigned long long alive = ballot(!done);
         if (alive == 0) break;
-        const int k = base + lane;
-        const bool valid = k < len;
-        uint32_t id = 0;
+        int nq = 0;
+        stream_refill<false>(id, pos, nq, point_list + range.x, cursor, len, TS_ID_BITS + wave, lane);
+        if (nq == 0) break;
+        const bool valid = lane < nq;
         float4 r0 = make_float4(0, 0, 1, 0), r1 = make_float4(1, 0, 0, 1), r2 = make_float4(1, 0, 0, 1), r3 = make_float4(0, 0, 0, 0);
         if (valid)
         {
-            id = point_list[range.x + k];
             const float4 *rp = rec + 4 * (size_t)id;
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
         }
@@ -259,7 +266,7 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
         const int rank = lane_rank(any), nact = __popcll(any);
         const int r = rank & (NR - 1);
         bool mine = anybit && rank < NR;
-        if (mine) publish_row3(cst + r * ROW, v1, v2, v3, n, c, r3, 0.0f, lane);
+        if (mine) publish_row3(cst + r * ROW, v1, v2, v3, n, c, r3, 0.0f, pos);
         for (int h = 0;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
@@ -276,18 +283,16 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
             for (int t0 = 0; t0 < steps; t0 += 8)
             {
                 float cw[8];
-                uint32_t cjc[8];
                 const uint4 packed = *(const uint4 *)(mylist + (t0 >> 1));
 #pragma unroll
                 for (int st = 0; st < 8; st++)
                 {
                     cw[st] = 0.0f;
-                    cjc[st] = 0u;
                     if (t0 + st < steps)
                     {
                         const uint32_t word = st < 2 ? packed.x : (st < 4 ? packed.y : (st < 6 ? packed.z : packed.w));
                         const float *row = (const float *)(lds0 + ((st & 1) ? (word >> 16) : (word & 0xFFFFu)));
-                        const int jpos = __float_as_int(row[19]); // position in the batch
+                        const int jpos = __float_as_int(row[19]); // position in the tile's list
                         const Hit3 h = hit3<false>(row, ray);
                         const float pw = GAMMA1 ? h.ecc * h.ecc : pow_nonneg(h.ecc, g2);
                         const float alpha = fminf(0.99f, h.op * __builtin_amdgcn_exp2f(pw * -0.7213475204444817f)); // forward.cu:259-260
@@ -304,11 +309,10 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
                             anz = fmaf(h.n.z, contrib, anz);
                             ad = fmaf(h.depth, contrib, ad); // forward.cu:277
                             cw[st] = contrib;
-                            cjc[st] = (uint32_t)jpos;
                         }
                         T *= (1.0f - al);
                         const bool sat = hit && T <= 0.0001f; // forward.cu:280
-                        last = sat ? (uint32_t)(base + jpos + 1) : last;
+                        last = sat ? (uint32_t)(jpos + 1) : last;
                         done = done || sat;
                     }
                 }
@@ -316,15 +320,16 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
                 {
                     // contrib_sum / contrib_max (forward.cu:271-273): reduced per 16-lane group, added to the tile's statistics in LDS
                     // with integer atomics (ts2d_group.h)
-                    const float sm = row_reduce8(cw, rsel, OpAdd());
-                    const float mx = row_reduce8(cw, rsel, OpMax());
-                    const int k = base + (int)row_select8(cjc, rsel);
+                    float sm, mx;
+                    row_reduce8_sum_max(cw, 0xCCCCCCCCCCCCCCCCull, sm, mx);
+                    int k = 0; // the list position of "its" step, from the step's row (render_group.hip)
+                    if ((lane & 1) == 0 && sm > 0.0f) k = __float_as_int(*(const float *)(lds0 + ((const u16a *)list)[grp * NR + t0 + stat_step] + 19 * 4));
                     if ((lane & 1) == 0 && sm > 0.0f) tile_stats_add<TCAP>(tsum, tmax, k, sm, mx, point_list + range.x, contrib_sum, contrib_max);
                 }
             }
             if (++h * NR >= nact) break;
             mine = anybit && rank >= NR;
-            if (mine) republish_row3(cst + r * ROW, point_list, rec, range.x + base + lane, false, lane);
+            if (mine) republish_row3(cst + r * ROW, point_list, rec, range.x + pos, false, pos);
         }
     }
     // the wave's pixels leave first; their stores and the ids of the flush are in flight while the wave waits for the others (render_group.hip)
@@ -353,7 +358,7 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
         for (int j = 0; j < NF; j++)
         {
             const int k = (int)threadIdx.x + 256 * j;
-            ids[j] = k < nflush ? point_list[range.x + k] : 0u;
+            ids[j] = k < nflush ? point_list[range.x + k] & TS_ID_MASK : 0u;
         }
         __syncthreads();
 #pragma unroll
@@ -452,15 +457,18 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
     const int maxlast = max(max(glast[0], glast[1]), max(glast[2], glast[3]));
     if (maxlast <= 0) return;
 
-    for (int base = ((maxlast - 1) >> 6) << 6; base >= 0; base -= 64)
+    // dense batches, walked back to front: lane 0 holds the entry farthest back (ts2d_group.h, stream_refill<true>); `pos` = list position
+    uint32_t id = 0;
+    int pos = 0, cursor = maxlast;
+    for (;;)
     {
-        const int k = base + lane;
-        const bool valid = k < maxlast;
-        uint32_t id = 0;
+        int nq = 0;
+        stream_refill<true>(id, pos, nq, point_list + range.x, cursor, maxlast, TS_ID_BITS + quad, lane);
+        if (nq == 0) break;
+        const bool valid = lane < nq;
         float4 r0 = make_float4(0, 0, 1, 0), r1 = make_float4(1, 0, 0, 1), r2 = make_float4(1, 0, 0, 1), r3 = make_float4(0, 0, 0, 0);
         if (valid)
         {
-            id = point_list[range.x + k];
             const float4 *rp = rec + 4 * (size_t)id;
             r0 = rp[0]; r1 = rp[1]; r2 = rp[2]; r3 = rp[3];
         }
@@ -469,22 +477,16 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
         const Cull3 c = cull3<GAMMA1>(v1, v2, v3, n, 1.0f, g2, ray0, sx, sy);
         unsigned long long M[4];
 #pragma unroll
-        for (int g = 0; g < 4; g++)
-        {
-            const int nn = glast[g] - base;
-            const unsigned long long keep = nn >= 64 ? ~0ull : (nn <= 0 ? 0ull : ((1ull << nn) - 1ull));
-            M[g] = ballot(valid && c.ov[g]) & keep;
-        }
+        for (int g = 0; g < 4; g++) M[g] = ballot(valid && c.ov[g] && pos < glast[g]); // entries at or behind glast[g] are skipped by all of block g's pixels
         const unsigned long long any = M[0] | M[1] | M[2] | M[3];
         if (any == 0) continue;
         const bool anybit = (any >> lane) & 1;
         const int rank = lane_rank(any), nact = __popcll(any);
-        const int lrel = last - base;
         const int r = rank & (NR - 1);
-        bool mine = anybit && (rank / NR) == (nact - 1) / NR;
+        bool mine = anybit && rank < NR; // back to front = the low lanes first
         if (mine)
         {
-            publish_row3(rows + r * BROW3, v1, v2, v3, n, c, r3, __uint_as_float(id), lane);
+            publish_row3(rows + r * BROW3, v1, v2, v3, n, c, r3, __uint_as_float(id), pos);
             publish_k3(rows + r * BROW3, v1, v2, v3, n);
         }
         for (int h = (nact - 1) / NR;;)
@@ -502,7 +504,7 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
             {
                 const unsigned long long Mh = M[g] & mm;
                 const int nn = __popcll(Mh);
-                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + (nn - 1 - lane_rank(Mh))] = (unsigned short)(row0 + r * (BROW3 * 4));
+                if ((Mh >> lane) & 1) ((u16a *)list)[g * NR + lane_rank(Mh)] = (unsigned short)(row0 + r * (BROW3 * 4));
                 steps = max(steps, nn);
             }
             const u16a *mylist = (const u16a *)list + grp * NR;
@@ -529,7 +531,7 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
                 const float G = __builtin_amdgcn_exp2f(pw * -0.7213475204444817f);
                 const float opG = h.op * G;
                 const float alpha = fminf(0.99f, opG);
-                const bool hit = (jpos < lrel) && h.ok && ecc_in_range(h.ecc) && G >= 1.0f / 255.0f; // backward.cu:322-323,328,343,351
+                const bool hit = (jpos < last) && h.ok && ecc_in_range(h.ecc) && G >= 1.0f / 255.0f; // backward.cu:322-323,328,343,351
                 const float al = hit ? alpha : 0.0f;
                 const float oma = 1.0f - al;
                 T = T * __builtin_amdgcn_rcpf(oma); // :354
@@ -593,8 +595,8 @@ __global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderA
                 }
             }
             if (--h < 0) break;
-            mine = anybit && rank < NR;
-            if (mine) republish_row3(rows + r * BROW3, point_list, rec, range.x + base + lane, true, lane);
+            mine = anybit && rank >= NR;
+            if (mine) republish_row3(rows + r * BROW3, point_list, rec, range.x + pos, true, pos);
         }
     }
 }

@@ -217,7 +217,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
     write_dummy_row(cst - ROW, lane);
     const char *lds0 = (const char *)cst_all;                                      // list entries are byte offsets from here
     const uint32_t row0 = (uint32_t)(wave * (NR + 1) + 1) * (ROW * 4), dummy = row0 - ROW * 4; // row r of this wave: row0 + r * 80
-    const RowSel rsel(lane);
+    const int stat_step = ((lane >> 3) & 1) | ((lane >> 1) & 2) | ((lane << 1) & 4); // the step of a window whose statistics this lane ends up with
 
     float T = 1.0f, ar = 0.0f, ag = 0.0f, ab = 0.0f, anx = 0.0f, any_ = 0.0f, anz = 0.0f, ad = 0.0f;
     bool done = !inside;
@@ -293,13 +293,11 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
             for (int t0 = 0; t0 < steps; t0 += 8)
             {
                 float c[8];
-                uint32_t cjc[8];
                 const uint4 packed = *(const uint4 *)(mylist + t0); // this group's next 8 entries (row byte offsets)
 #pragma unroll
                 for (int st = 0; st < 8; st++)
                 {
                     c[st] = 0.0f;
-                    cjc[st] = 0u;
                     if (t0 + st < steps)
                     {
                         const uint32_t word = st < 2 ? packed.x : (st < 4 ? packed.y : (st < 6 ? packed.z : packed.w));
@@ -316,7 +314,6 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
                             const float4 q4 = *(const float4 *)(row + 16);
                             vd3 = q4.x;
                             jpos = __float_as_int(q4.z);
-                            cjc[st] = (uint32_t)jpos;
                         }
                         else jpos = __float_as_int(row[18]);
                         const float pw = GAMMA1 ? b.ecc * b.ecc : pow_nonneg(b.ecc, g2);
@@ -352,9 +349,12 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
                     // (sum, max, batch position) of step `b3 + 2 b2 + 4 b1` of their group, and the even lanes add them to the TILE's
                     // statistics in LDS with INTEGER atomics (ts2d_group.h: ds_add_u64 / ds_max_i32 cost 5-7 cycles per wave
                     // instruction, ds_add_f32 193) -- no ordering between groups or waves is needed.
-                    const float sm = row_reduce8(c, rsel, OpAdd());
-                    const float mx = row_reduce8(c, rsel, OpMax());
-                    const int k = (int)row_select8(cjc, rsel);
+                    float sm, mx;
+                    row_reduce8_sum_max(c, 0xCCCCCCCCCCCCCCCCull, sm, mx);
+                    // the list position of "its" step: from the step's row (two LDS reads on the few lanes that have something to add) rather
+                    // than carried through the window in eight registers and selected with seven v_cndmask
+                    int k = 0;
+                    if ((lane & 1) == 0 && sm > 0.0f) k = __float_as_int(*(const float *)(lds0 + mylist[t0 + stat_step] + 18 * 4));
                     if ((lane & 1) == 0 && sm > 0.0f) tile_stats_add<TCAP>(tsum, tmax, k, sm, mx, point_list + range.x, contrib_sum, contrib_max);
                 }
 #endif

@@ -225,8 +225,19 @@ void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const Geo
 void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s); // first histogram + N + key-bit census
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s);          // the rest: (depth bits, id) -> sorted ids
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s);                  // tiles_sorted, block sums + their groups' sums
+// How the emission kernel forms the quadrant masks in the values' top bits (ts2d_support.h).  2D: the screen triangle of the render record, its
+// support scaled by E(opacity, 2 gamma).  3D: the view-space triangle scaled by E(opacity = 1) -- the 3D backward's skip test is on G, not on
+// alpha (R3D backward.cu:351) -- about its centroid IN ITS PLANE, projected to pixels; a ray meets the plane inside the scaled triangle exactly
+// where the pixel lies inside that projection, so the 2D test with E = 1 on the projected triangle is the 3D test.
+struct QuadMaskArgs
+{
+    int variant;    // 2 or 3
+    float g2;       // 2 gamma (< 1e-6: the whole ecc <= 10 region)
+    float tan_fovx, tan_fovy;
+    int W, H;
+};
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
-                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, float quad_g2, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path; quad_g2 >= 0: quadrant masks in the values' top bits (ts2d_support.h)
+                         float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, const QuadMaskArgs &qm, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P);                        // where the scan leaves N
 void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s); // stable, tile bits only
 void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s);

@@ -93,6 +93,43 @@ __device__ __forceinline__ float row_reduce8(const float (&c)[8], const RowSel &
     const float v = pair_xor2(t0, t1, r.b1, op);
     return op(v, dpp<DPP_XOR1>(v));
 }
+// Sum AND maximum of 8 values over the 16 lanes of each DPP row in one pass (the forward's contribution statistics): the transposed network of
+// row_reduce8 with the write masks of row_reduce16 -- levels 1 and 2 pair lanes of different DPP banks, so "which half keeps which value" is the
+// instruction's own bank mask (two v_add/v_max_f32_dpp per pair instead of two v_cndmask + one; every one of them half rate on gfx950): 32
+// instructions for both results against 44.  The two chains are interleaved so that no DPP operand is read within two wait states of its
+// write; level 1 writes fresh registers (the inputs stay intact for the caller).  Lanes l and l ^ 1 end up with step (b3 + 2 b2 + 4 b1).
+__device__ __forceinline__ void row_reduce8_sum_max(const float (&c)[8], unsigned long long mask_b1, float &sum, float &mx)
+{
+    float s0, s1, s2, s3, m0, m1, m2, m3;
+#define TSG8_L1(OP, T, X, Y)                                                              \
+    OP " " T ", " Y ", " Y " row_ror:8 row_mask:0xf bank_mask:0xc\n"                      \
+    OP " " T ", " X ", " X " row_ror:8 row_mask:0xf bank_mask:0x3\n"
+#define TSG8_L2(OP, X, Y)                                                                 \
+    OP " " Y ", " Y ", " Y " row_half_mirror row_mask:0xf bank_mask:0xa\n"                \
+    OP " " Y ", " X ", " X " row_half_mirror row_mask:0xf bank_mask:0x5\n"
+#define TSG8_QP(OP, X, QP) OP " " X ", " X ", " X " quad_perm:" QP " row_mask:0xf bank_mask:0xf\n"
+    asm volatile("s_nop 1\n"
+                 TSG8_L1("v_add_f32_dpp", "%0", "%8", "%9") TSG8_L1("v_add_f32_dpp", "%1", "%10", "%11")
+                 TSG8_L1("v_add_f32_dpp", "%2", "%12", "%13") TSG8_L1("v_add_f32_dpp", "%3", "%14", "%15")
+                 TSG8_L1("v_max_f32_dpp", "%4", "%8", "%9") TSG8_L1("v_max_f32_dpp", "%5", "%10", "%11")
+                 TSG8_L1("v_max_f32_dpp", "%6", "%12", "%13") TSG8_L1("v_max_f32_dpp", "%7", "%14", "%15")
+                 TSG8_L2("v_add_f32_dpp", "%0", "%1") TSG8_L2("v_max_f32_dpp", "%4", "%5")
+                 TSG8_L2("v_add_f32_dpp", "%2", "%3") TSG8_L2("v_max_f32_dpp", "%6", "%7")
+                 TSG8_QP("v_add_f32_dpp", "%1", "[2,3,0,1]") TSG8_QP("v_max_f32_dpp", "%5", "[2,3,0,1]")
+                 TSG8_QP("v_add_f32_dpp", "%3", "[2,3,0,1]") TSG8_QP("v_max_f32_dpp", "%7", "[2,3,0,1]")
+                 "v_cndmask_b32_e64 %3, %1, %3, %16\n"
+                 "v_cndmask_b32_e64 %7, %5, %7, %16\n"
+                 "s_nop 0\n"
+                 TSG8_QP("v_add_f32_dpp", "%3", "[1,0,3,2]") TSG8_QP("v_max_f32_dpp", "%7", "[1,0,3,2]")
+                 "s_nop 1\n"
+                 : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(m0), "=&v"(m1), "=&v"(m2), "=&v"(m3)
+                 : "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]), "s"(mask_b1));
+#undef TSG8_L1
+#undef TSG8_L2
+#undef TSG8_QP
+    sum = s3;
+    mx = m3;
+}
 __device__ __forceinline__ uint32_t row_select8(const uint32_t (&c)[8], const RowSel &r)
 {
     const uint32_t s0 = r.b3 ? c[1] : c[0], s1 = r.b3 ? c[3] : c[2], s2 = r.b3 ? c[5] : c[4], s3 = r.b3 ? c[7] : c[6];
