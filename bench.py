@@ -123,6 +123,11 @@ def main():
     ap.add_argument("--sync-free", action="store_true",
                     help="use the sync-free forward (ts2d_forward, capacity = 1.25 x the instance count of the cold step) instead of the "
                          "reference's sequence with its blocking read of num_rendered; overflow is checked after the timed region")
+    ap.add_argument("--sparse-exchange", action="store_true",
+                    help="N > 1: only the gradient rows of triangles SOME rank saw this step travel (parallel.VisibleRows: a MAX all-reduce of P bytes "
+                         "behind the forward, compact bucket, compact colour factors).  Pays where a view sees a fraction of the scene (BASELINE "
+                         "configs[4]); on the synthetic headline scene every triangle is in the frustum (config.exchange.visible_fraction ~ 1) and "
+                         "the dense exchange -- the default -- moves the same bytes without the two gathers")
     ap.add_argument("--hip-graph", action="store_true",
                     help="NOT the driver's command: the step (sync-free forward, loss gradients, backward) is captured ONCE into a HIP graph "
                          "(torch.cuda.CUDAGraph on the rasterizer's launches; the sync-free forward has no host read to break the capture) and the "
@@ -195,6 +200,7 @@ def main():
             shx.append(parallel.FactoredShExchange(sh_group, dev))
         bucket = buckets[0]
     sink = parallel.ShGradSink()
+    vis_rows = parallel.VisibleRows(bucket_group if world > 1 else None, dev) if (world > 1 and args.sparse_exchange) else None
 
     state = {"step": 0, "overlap": overlap, "pending": None}
     optimizer = None
@@ -225,10 +231,14 @@ def main():
             b, x = buckets[i % len(buckets)], shx[i % len(shx)]
             with b.capture(), parallel.factored_sh_grads(sink, enabled=factored):
                 out = raster(vertex, center2D, opacity, shs=shs)
+                if vis_rows is not None:
+                    vis_rows.begin([out[1]])  # the union of radii > 0 over the ranks: queued behind the forward, read after the backward is queued
                 torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
-            b.reduce_async()
+            b.reduce_async(rows=vis_rows)
             if factored:
-                x.start(sink, vertex, D, M, uniform=True)
+                x.start(sink, vertex, D, M, uniform=True, rows=vis_rows)
+            if vis_rows is not None:
+                state["visible_rows"] = int(vis_rows.index().numel())
             prev, state["pending"] = state["pending"], i
             if not state["overlap"]:
                 collect(i)       # synchronous (default): this step's reduced gradients before anything of the next step is queued
@@ -289,6 +299,11 @@ def main():
             raise SystemExit("--hip-graph is a single-GPU measurement")
         if events:
             _C.profile_enable(False)  # the profile hook records HIP events: not inside a capture
+        # the autograd graph of the last eager step (kept alive by state["image"]) holds AccumulateGrad nodes created on the DEFAULT stream; a node
+        # that outlives its step is reused by the next one, and a default-stream node inside a capture is an illegal dependency: drop it first
+        state["image"] = None
+        vertex.grad = shs.grad = opacity.grad = None
+        gc.collect()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # torch's capture recipe: a few eager iterations on the side stream first
@@ -398,6 +413,9 @@ def main():
                    "exchange": ({"mode": "delayed: double-buffered buckets, step i's exchange is waited for behind step i+1's kernels (one-step-delayed application)"
                                          if overlap else "synchronous: step i's reduced gradients are waited for inside step i (north_star's all-reduce semantics)",
                                  "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
+                                 "rows": ("visible rows only (parallel.VisibleRows)" if vis_rows is not None else "all rows (dense)"),
+                                 "visible_fraction": (round(state.get("visible_rows", 0) / max(P, 1), 4) if vis_rows is not None else None),
+                                 "bucket_bytes_per_rank_and_step": (buckets[0].last_exchanged_bytes if buckets and hasattr(buckets[0], "last_exchanged_bytes") else None),
                                  "other_mode": other, "process_groups": 2} if world > 1 else None),
                    # spread of the host-side time per queued step: a stalled host (allocator growth, garbage collection, a descheduled thread)
                    # shows up here as a maximum far above the median, and in `value` (the contract times all K steps, stalls included)

@@ -101,6 +101,7 @@ def test_a_training_step_replays_from_one_hip_graph(variant):
     keep = {}
 
     def step():
+        keep.clear()  # the previous step's autograd graph (and its AccumulateGrad nodes) must not outlive it into the capture
         c2d = torch.zeros((P, 2), device="cuda", requires_grad=True)
         out = raster(vertex, c2d, opacity, shs=shs)
         torch.autograd.backward([out[0], out[2], out[3]], [gi, gd, gn])

@@ -225,15 +225,19 @@ def test_3d_variant_sits_inside_the_references_own_spread(P, W, H, D, gamma):
         else:
             _same_integer_state(hf, rf, b)
 
-    def dist(k, x, y):
+    bad_depth = {}
+
+    def dist(k, x, y, who=None):
         if k == "depth":
             # a pixel whose ray lies nearly in a triangle's plane (|p_ray.n| small but above the reference's absolute 1e-8 guard,
             # R3D forward.cu:241-243) gets depth = v1.n / p_ray.n of 1e4 ... 1e11 in EVERY build, each with its own rounding noise,
-            # and one such pixel outweighs the rest of the map in an L2 norm: at most 1e-4 of the pixels may differ by more than
-            # 1e-3 of their (or the typical) depth; the norm is taken over the others
+            # and one such pixel outweighs the rest of the map in an L2 norm: the pixels that differ by more than 1e-3 of their (or the
+            # typical) depth are COUNTED -- at gamma = 1 at most 1e-4 of the map between any two evaluations; with gamma > 1 the window's edge
+            # is a cliff (ecc^(2 gamma)), more alpha >= 1/255 decisions flip between the reference's own builds (3.5e-3 of the pixels at
+            # gamma = 50), and the product's count is held against theirs below -- and the norm is taken over the others
             scale = np.maximum(np.abs(y), np.median(np.abs(y)))
             bad = ~(np.abs(x - y) <= 1e-3 * scale)
-            assert bad.mean() <= 1e-4, (k, int(bad.sum()))
+            bad_depth.setdefault(who, []).append(float(bad.mean()))
             x, y = x[~bad], y[~bad]
         return helpers.rel_l2(x, y)
 
@@ -250,11 +254,13 @@ def test_3d_variant_sits_inside_the_references_own_spread(P, W, H, D, gamma):
     near = (lambda own: min(own)) if gamma == 1.0 else (lambda own: float(np.median(own)))
     failures = []
     for k, tol in bars.items():
-        own = [dist(k, builds[a][k], builds[b][k]) for i, a in enumerate(names) for b in names[i + 1:]]
-        mine = [dist(k, hf[k], builds[b][k]) for b in names]
+        own = [dist(k, builds[a][k], builds[b][k], "own") for i, a in enumerate(names) for b in names[i + 1:]]
+        mine = [dist(k, hf[k], builds[b][k], "mine") for b in names]
         print(f"{k}: reference builds among themselves {['%.2e' % x for x in own]}, product against them {['%.2e' % x for x in mine]}")
         if not max(mine) <= max(tol, 1.25 * max(own)): failures.append((k, "max", mine, own))
         if not min(mine) <= max(tol, near(own)): failures.append((k, "min", mine, own))
+    print(f"depth pixels set aside (fraction): builds among themselves {bad_depth['own']}, product against them {bad_depth['mine']}")
+    if not max(bad_depth["mine"]) <= max(1e-4, 1.25 * max(bad_depth["own"])): failures.append(("depth pixels set aside", bad_depth))
     for k in ("dL_dvertex", "dL_dcenter2D"):
         own = [helpers.rel_l2(builds[a][k], builds[b][k]) for i, a in enumerate(names) for b in names[i + 1:]]
         mine = [helpers.rel_l2(hf[k], builds[b][k]) for b in names]

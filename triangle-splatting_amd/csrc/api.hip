@@ -395,7 +395,7 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     {
         {
             // quadrant masks for the blend kernels of both variants (ts2d_support.h, ts2d_common.h: QuadMaskArgs)
-            const QuadMaskArgs quad{(flags & TS2D_FLAG_3D) ? 3 : 2, fmaxf(0.0f, 2.0f * geom->gamma), cam->tan_fovx, cam->tan_fovy, W, H};
+            const QuadMaskArgs quad{(flags & TS2D_FLAG_3D) ? 3 : 2, fmaxf(0.0f, 2.0f * geom->gamma), cam->tan_fovx, cam->tan_fovy, W, H, 1.0f / (float)W, 1.0f / (float)H};
             ProfScope ps("emit_keys", s);
             ts_launch_emit_keys(P, r.grid_x, ntiles, g, b, im, rich ? out->contrib_sum : nullptr, rich ? out->contrib_max : nullptr,
                                 n_dev ? N : -1, im.status, quad, s);

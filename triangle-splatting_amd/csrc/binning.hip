@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
 // (rasterizer.cu:63-73); the later sort is by tile id, so only the order BETWEEN triangles matters.
 constexpr uint32_t SMALL = 32;
 
-__global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
+__global__ void __launch_bounds__(256, 6) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
                                                          float *contrib_sum, float *contrib_max, long long capacity, int32_t *status, bool two_level,
                                                          QuadMaskArgs qmask)
 {
@@ -736,6 +736,18 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     const bool valid = i < P;
     uint32_t tiles = valid ? g.tiles_sorted[i] : 0u;
     const uint32_t id_ahead = valid ? sorted_ids(g)[i] : 0u; // wanted after the scan: requested now, one round trip less behind it
+    // ... and what hangs on it -- the tile rectangle and the head of the render record (the quadrant-mask setup) -- is requested as soon as the id
+    // is there, so that their round trip runs under the block sums and the scan instead of behind them (round 5)
+    uint2 rect = {0u, 0u};
+    float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
+    if (tiles > 0)
+    {
+        rect = g.rect[id_ahead];
+        const float4 *rp = g.rec + 4 * (size_t)id_ahead;
+        rec0 = rp[0];
+        rec1 = rp[1];
+        if (qmask.variant == 3) rec2 = rp[2];
+    }
     // Everything in front of this block, requested together and reduced once: the earlier quarters of this scan block (scan blocks are 1024
     // triangles = four of these 256-lane blocks), the raw sums of the scan blocks of its group of 64, the group sums in front of that.
     const int sblock = blockIdx.x >> 2, quarter = blockIdx.x & 3;
@@ -771,31 +783,27 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     const unsigned long long qbase = wpart[0] + wpart[1] + wpart[2] + wpart[3];
     const uint32_t incl = (uint32_t)(qbase + before + inc); // N < 2^31 is checked on the host before anything is emitted
     if (valid) g.offsets[i] = incl;
-    uint2 rect = {0u, 0u};
-    uint32_t id = 0;
+    const uint32_t id = tiles > 0 ? id_ahead : 0u;
     const uint32_t off = incl - tiles; // exclusive prefix
-    if (tiles > 0)
-    {
-        id = id_ahead;
-        rect = g.rect[id];
-    }
     const uint32_t minx = rect.x & 0xffffu, miny = rect.x >> 16, maxx = rect.y & 0xffffu, maxy = rect.y >> 16;
     uint32_t *tile_out = b.k[0], *val_out = b.v[0];
     // the four spare bits of an instance's value say which 8x8 quadrants of its tile the triangle's support can reach (ts2d_support.h; both
     // variants since round 5, ts2d_common.h: QuadMaskArgs); the blend kernels' quadrant waves then skip the other entries unseen
     constexpr bool qm = true;
     const float quad_g2 = qmask.g2;
-    auto setup_of = [&](uint32_t tri, uint32_t tminx, uint32_t tminy, uint32_t tmaxx, uint32_t tmaxy) { // the triangle and its tile rectangle
-        const float4 *rp = g.rec + 4 * (size_t)tri;
-        const float4 r0 = rp[0], r1 = rp[1];
-        if (qmask.variant == 3)
+    auto setup_from = [&](const float4 &r0, const float4 &r1, const float4 &r2, uint32_t tminx, uint32_t tminy, uint32_t tmaxx, uint32_t tmaxy) {
+        if (qmask.variant == 3) // the head of the triangle's record and its tile rectangle
         {
             const float E = quad_g2 == 2.0f ? support_scale<true>(1.0f, quad_g2) : support_scale<false>(1.0f, quad_g2);
-            return quad_setup_3d(r0, r1, rp[2], E, qmask.tan_fovx, qmask.tan_fovy, qmask.W, qmask.H, (float)(tminx * TS_TILE) - 1.0f,
+            return quad_setup_3d(r0, r1, r2, E, qmask.tan_fovx, qmask.tan_fovy, qmask.W, qmask.H, qmask.inv_W, qmask.inv_H, (float)(tminx * TS_TILE) - 1.0f,
                                  (float)(tminy * TS_TILE) - 1.0f, (float)(tmaxx * TS_TILE), (float)(tmaxy * TS_TILE));
         }
         const float E = quad_g2 == 2.0f ? support_scale<true>(r1.z, quad_g2) : support_scale<false>(r1.z, quad_g2);
         return quad_setup(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, E);
+    };
+    auto setup_of = [&](uint32_t tri, uint32_t tminx, uint32_t tminy, uint32_t tmaxx, uint32_t tmaxy) { // another lane's triangle: gathered here
+        const float4 *rp = g.rec + 4 * (size_t)tri;
+        return setup_from(rp[0], rp[1], qmask.variant == 3 ? rp[2] : make_float4(0, 0, 0, 0), tminx, tminy, tmaxx, tmaxy);
     };
     QuadSetup qs{};
     // The block's instances are one contiguous run of the list.  A lane writing its triangle's few slots straight to memory issues 4-byte
@@ -818,7 +826,7 @@ __global__ void __launch_bounds__(256) scan_emit_kernel(int P, int grid_x, int n
     const uint32_t rw = maxx - minx, rh = maxy - miny;
     if (qm && tiles > 0)
     {
-        qs = setup_of(id, minx, miny, maxx, maxy);
+        qs = setup_from(rec0, rec1, rec2, minx, miny, maxx, maxy);
         if (qstage)
         {
             const QuadAffine qa = quad_anchor(qs, id, minx, miny, rw, rh);

@@ -235,6 +235,7 @@ struct QuadMaskArgs
     float g2;       // 2 gamma (< 1e-6: the whole ecc <= 10 region)
     float tan_fovx, tan_fovy;
     int W, H;
+    float inv_W, inv_H; // 1 / W, 1 / H (the 3D setup's pixel -> ray conversions; the masks' margins absorb their rounding)
 };
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                          float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, const QuadMaskArgs &qm, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path

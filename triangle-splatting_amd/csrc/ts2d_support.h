@@ -84,12 +84,13 @@ constexpr float PAD3D = 0.02f;
 // reason).  p_ray . n is affine in the pixel, so its extremes over the rectangle [px0, px1] x [py0, py1] sit at the corners: all quadrants
 // unless it keeps its sign there with |.| >= 1e-3 of its largest corner value (the slack cull3 uses).  ~2 % of randomly oriented triangles.
 __device__ __forceinline__ QuadSetup quad_setup_3d(const float4 &r0, const float4 &r1, const float4 &r2, float E, float tan_fovx, float tan_fovy, int W, int H,
-                                                   float px0, float py0, float px1, float py1)
+                                                   float inv_W, float inv_H, float px0, float py0, float px1, float py1)
 {
     {
         const float nx = r2.y, ny = r2.z, nz = r2.w;
-        const float rx0 = tan_fovx * ((2.0f * px0 - (float)W + 1.0f) / (float)W), rx1 = tan_fovx * ((2.0f * px1 - (float)W + 1.0f) / (float)W);
-        const float ry0 = tan_fovy * ((2.0f * py0 - (float)H + 1.0f) / (float)H), ry1 = tan_fovy * ((2.0f * py1 - (float)H + 1.0f) / (float)H);
+        const float sx = tan_fovx * inv_W, sy = tan_fovy * inv_H; // multiplications by the reciprocals: a sign / magnitude test with a 1e-3 slack
+        const float rx0 = sx * (2.0f * px0 - (float)W + 1.0f), rx1 = sx * (2.0f * px1 - (float)W + 1.0f);
+        const float ry0 = sy * (2.0f * py0 - (float)H + 1.0f), ry1 = sy * (2.0f * py1 - (float)H + 1.0f);
         const float d00 = rx0 * nx + ry0 * ny + nz, d10 = rx1 * nx + ry0 * ny + nz, d01 = rx0 * nx + ry1 * ny + nz, d11 = rx1 * nx + ry1 * ny + nz;
         const float lo = fminf(fminf(d00, d10), fminf(d01, d11)), hi = fmaxf(fmaxf(d00, d10), fmaxf(d01, d11));
         const float big = fmaxf(fabsf(lo), fabsf(hi));
@@ -100,8 +101,9 @@ __device__ __forceinline__ QuadSetup quad_setup_3d(const float4 &r0, const float
     const float w1z = cz + E * (v1z - cz), w2z = cz + E * (v2z - cz), w3z = cz + E * (v3z - cz);
     const float zmin = 0.05f * cz;
     if (!(E > 0.0f && cz > 0.0f && w1z >= zmin && w2z >= zmin && w3z >= zmin)) return quad_setup_all();
-    const float kx = 0.5f * (float)W / tan_fovx, ky = 0.5f * (float)H / tan_fovy, ox = 0.5f * (float)W - 0.5f, oy = 0.5f * (float)H - 0.5f;
-    const float i1 = 1.0f / w1z, i2 = 1.0f / w2z, i3 = 1.0f / w3z;
+    const float kx = 0.5f * (float)W * __builtin_amdgcn_rcpf(tan_fovx), ky = 0.5f * (float)H * __builtin_amdgcn_rcpf(tan_fovy);
+    const float ox = 0.5f * (float)W - 0.5f, oy = 0.5f * (float)H - 0.5f;
+    const float i1 = __builtin_amdgcn_rcpf(w1z), i2 = __builtin_amdgcn_rcpf(w2z), i3 = __builtin_amdgcn_rcpf(w3z); // 1 ulp: far inside PAD3D
     const float s1x = (cx + E * (v1x - cx)) * i1 * kx + ox, s1y = (cy + E * (v1y - cy)) * i1 * ky + oy;
     const float s2x = (cx + E * (v2x - cx)) * i2 * kx + ox, s2y = (cy + E * (v2y - cy)) * i2 * ky + oy;
     const float s3x = (cx + E * (v3x - cx)) * i3 * kx + ox, s3y = (cy + E * (v3y - cy)) * i3 * ky + oy;

@@ -30,6 +30,75 @@ def shard_views(num_views: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, num_views, world_size))
 
 
+class VisibleRows:
+    """The triangles that ANY rank saw in this step: the union over the ranks of `radii > 0` (a triangle no view of the step
+    sees has an all-zero gradient row on every rank, so its row need not travel).
+
+        rows = VisibleRows(group, device)
+        out = raster(...)                       # forward of this rank's view(s)
+        rows.begin([out[1], ...])               # radii of every view of this rank: one small MAX all-reduce (P bytes) on a side stream
+        ... loss, backward (queued on the compute stream) ...
+        bucket.reduce_async(rows=rows)          # gathers the visible rows into a compact buffer, reduces THAT, scatters the sums back
+        shx.start(sink, vertex, D, M, rows=rows)
+
+    `begin` is queued right behind the forward and costs the compute stream nothing; `index()` -- called by the consumers AFTER the backward
+    has been queued -- waits for the side stream only (the mask has long arrived: it depended on the forward alone) and returns the sorted
+    row indices, identical on every rank.  The one host read it needs (the number of visible rows sizes the collectives) therefore happens
+    while the compute stream still holds the whole backward.  wire volume = (visible fraction) x the dense exchange; at the headline's
+    synthetic scene every triangle lies in the frustum (fraction ~1: nothing saved, two extra 48 MB gathers ~ 40 us), at BASELINE configs[4]'s
+    kind of scene (a city, 5 M triangles, a view sees a fraction of it) the exchange shrinks by that fraction."""
+
+    def __init__(self, group=None, device=None):
+        self.group = group
+        self.device = torch.device(device) if device is not None else None
+        self._stream = torch.cuda.Stream(device=device) if (self.device is not None and self.device.type == "cuda") else None
+        self._mask = None
+        self._idx = None
+        self._work = None
+
+    def begin(self, radii_views: Sequence[torch.Tensor]):
+        self._idx = None
+        dev = radii_views[0].device
+
+        def issue():
+            m = radii_views[0] > 0
+            for r in radii_views[1:]:
+                m = m | (r > 0)
+            m = m.to(torch.uint8)
+            self._mask = m
+            if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+                return dist.all_reduce(m, op=dist.ReduceOp.MAX, group=self.group, async_op=True)
+            return None
+
+        if self._stream is not None:
+            self._stream.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(self._stream):
+                self._work = issue()
+                for r in radii_views:
+                    r.record_stream(self._stream)
+        else:
+            self._work = issue()
+
+    def index(self) -> torch.Tensor:
+        """Sorted indices (int64) of the rows visible on any rank -- the same tensor on every rank.  One host read (the count)."""
+        if self._idx is None:
+            if self._mask is None:
+                raise RuntimeError("VisibleRows.index() before begin()")
+            if self._work is not None:
+                self._work.wait()
+                self._work = None
+            if self._stream is not None:
+                with torch.cuda.stream(self._stream):
+                    self._idx = torch.nonzero(self._mask).reshape(-1)  # synchronises the SIDE stream only
+            else:
+                self._idx = torch.nonzero(self._mask).reshape(-1)
+        return self._idx
+
+    @property
+    def stream(self):
+        return self._stream
+
+
 class GradBucket:
     """One contiguous fp32 buffer for a fixed list of gradient tensors, summed over the ranks on a side stream.
 
@@ -90,25 +159,53 @@ class GradBucket:
         """Context manager: rasterizer backward passes inside it write their gradients into this bucket (see class doc)."""
         return _BucketCapture(self)
 
-    def reduce_async(self):
-        """Starts the cross-rank sum of the bucket; on GPUs it runs on a side stream ordered after the current stream."""
+    def reduce_async(self, rows: Optional["VisibleRows"] = None):
+        """Starts the cross-rank sum of the bucket; on GPUs it runs on a side stream ordered after the current stream.  With `rows`
+        (VisibleRows of this step) only the rows some rank saw travel: they are gathered into a compact buffer -- tensor after tensor like
+        the bucket itself --, that buffer is reduced, and the sums are scattered back; every other row is an exact zero on every rank already."""
         self._filled = False
         if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.force_collectives):
             return
         world = dist.get_world_size(self.group)
 
-        def issue():
+        def reduce_flat(flat, padded):
             # gloo (the CPU / functional-test backend) has no reduce_scatter_tensor: it takes the single all-reduce
             if self.mode == "rs_ag" and dist.get_backend(self.group) != "gloo":
                 rank = dist.get_rank(self.group)
-                n = self.padded // world
-                mine = self.flat[rank * n:(rank + 1) * n]
-                dist.reduce_scatter_tensor(mine, self.flat, op=dist.ReduceOp.SUM, group=self.group)
-                return dist.all_gather_into_tensor(self.flat, mine, group=self.group, async_op=True)
-            return dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                n = padded // world
+                mine = flat[rank * n:(rank + 1) * n]
+                dist.reduce_scatter_tensor(mine, flat, op=dist.ReduceOp.SUM, group=self.group)
+                return dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)
+            return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
+        def issue():
+            if rows is None:
+                return reduce_flat(self.flat, self.padded)
+            idx = rows.index()
+            V = int(idx.numel())
+            views = self.views()
+            P = views[0].shape[0]
+            widths = [n // P for n in self.numels]
+            total = V * sum(widths)
+            padded = -(-max(total, 1) // (4 * world)) * (4 * world)
+            compact = torch.zeros(padded, device=self.flat.device, dtype=self.flat.dtype)
+            segs, off = [], 0
+            for v, w in zip(views, widths):
+                seg = compact[off:off + V * w].view(V, w)
+                torch.index_select(v.reshape(P, w), 0, idx, out=seg)
+                segs.append(seg)
+                off += V * w
+            work = reduce_flat(compact, padded)
+            self._sparse = (work, idx, segs, views, widths, compact)
+            self.last_exchanged_bytes = padded * self.flat.element_size()
+            return None
+
+        self._sparse = None
+        self.last_exchanged_bytes = self.padded * self.flat.element_size()
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream(self.flat.device))
+            if rows is not None and rows.stream is not None:
+                self._stream.wait_stream(rows.stream)
             with torch.cuda.stream(self._stream):
                 self._work = issue()
         else:
@@ -117,6 +214,18 @@ class GradBucket:
     all_reduce_async = reduce_async  # round-1 name
 
     def wait(self) -> List[torch.Tensor]:
+        sparse = getattr(self, "_sparse", None)
+        if sparse is not None:
+            # the compact buffer's sums go back to their rows (on the side stream: the collective's wait() orders it behind the exchange)
+            work, idx, segs, views, widths, _keep = sparse
+            ctx = torch.cuda.stream(self._stream) if self._stream is not None else _null_context()
+            with ctx:
+                work.wait()
+                for v, w, seg in zip(views, widths, segs):
+                    v.reshape(v.shape[0], w).index_copy_(0, idx, seg)
+            self._sparse = None
+            if self._stream is not None:
+                torch.cuda.current_stream(self.flat.device).wait_stream(self._stream)
         if self._work is not None:
             self._work.wait()
             self._work = None
@@ -130,6 +239,14 @@ class GradBucket:
         self.pack(grads)
         self.reduce_async()
         return self.wait()
+
+
+class _null_context:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
 
 
 class _BucketCapture:
@@ -244,15 +361,18 @@ class FactoredShExchange:
         self._out = None
         self._keep = None
 
-    def start(self, sink: ShGradSink, vertex: torch.Tensor, sh_degree: int, M: int, mean: bool = False, expand_fn=None, uniform: bool = True):
+    def start(self, sink: ShGradSink, vertex: torch.Tensor, sh_degree: int, M: int, mean: bool = False, expand_fn=None, uniform: bool = True,
+              rows: Optional["VisibleRows"] = None):
         if self._stream is None:
-            self._out = exchange_factored_sh_grads(sink, vertex, sh_degree, M, self.group, mean, expand_fn, uniform)
+            self._out = exchange_factored_sh_grads(sink, vertex, sh_degree, M, self.group, mean, expand_fn, uniform, rows)
             return
         colors, campos = list(sink.colors), list(sink.campos)
         self._keep = (colors, campos, vertex)
         self._stream.wait_stream(torch.cuda.current_stream(vertex.device))
+        if rows is not None and rows.stream is not None:
+            self._stream.wait_stream(rows.stream)
         with torch.cuda.stream(self._stream):
-            self._out = exchange_factored_sh_grads(sink, vertex, sh_degree, M, self.group, mean, expand_fn, uniform)
+            self._out = exchange_factored_sh_grads(sink, vertex, sh_degree, M, self.group, mean, expand_fn, uniform, rows)
             for tns in colors + [vertex]:
                 tns.record_stream(self._stream)  # allocated on the compute stream, last used on this one
 
@@ -265,13 +385,15 @@ class FactoredShExchange:
 
 
 def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree: int, M: int, group=None,
-                               mean: bool = False, expand_fn=None, uniform: bool = False) -> torch.Tensor:
+                               mean: bool = False, expand_fn=None, uniform: bool = False, rows: Optional["VisibleRows"] = None) -> torch.Tensor:
     """All-gathers the sink's factors over the ranks and returns the dense dL_dshs (P, M, 3) summed over every view of
     every rank (divided by the world size with mean=True, like GradBucket).  Ranks may hold different numbers of views
     (the shorter ones are padded with zero-colour rows).  `expand_fn(vertex, campos (V,3), dL_dcolor (V,P,3), sh_degree, M)` defaults to the HIP kernel behind
     `_C.sh_grad_expand`; the CPU tests inject a reference implementation to exercise the protocol over gloo.
     `uniform=True` is the caller's promise that every rank holds the same number of views of the same P triangles (the usual
-    training step): the agreement round -- a small all-reduce and a blocking read per step -- is skipped."""
+    training step): the agreement round -- a small all-reduce and a blocking read per step -- is skipped.
+    `rows` (VisibleRows of this step): only the colour rows of triangles some rank saw are gathered (the others are exact zeros in every
+    view); they are put back into a zero (world * V, P, 3) array in front of the expansion kernel."""
     if not sink.colors:
         raise RuntimeError("no SH-mode backward pass ran under factored_sh_grads()")
     if expand_fn is None:
@@ -302,7 +424,17 @@ def exchange_factored_sh_grads(sink: ShGradSink, vertex: torch.Tensor, sh_degree
             local = torch.cat([local, torch.zeros((vmax - V, P, 3), device=dev, dtype=torch.float32)], dim=0)
             local_cam = torch.cat([local_cam, torch.zeros((vmax - V, 4), device=dev, dtype=torch.float32)], dim=0)
             V = vmax
-    if world > 1:
+    if world > 1 and rows is not None:
+        idx = rows.index()
+        nvis = int(idx.numel())
+        packed = local.index_select(1, idx).contiguous()  # (V, nvis, 3)
+        gathered = torch.empty((world * V, nvis, 3), device=dev, dtype=torch.float32)
+        cams = torch.empty((world * V, 4), device=dev, dtype=torch.float32)
+        dist.all_gather_into_tensor(gathered, packed, group=group)
+        dist.all_gather_into_tensor(cams, local_cam, group=group)
+        colors = torch.zeros((world * V, P, 3), device=dev, dtype=torch.float32)
+        colors.index_copy_(1, idx, gathered)
+    elif world > 1:
         colors = torch.empty((world * V, P, 3), device=dev, dtype=torch.float32)
         cams = torch.empty((world * V, 4), device=dev, dtype=torch.float32)
         dist.all_gather_into_tensor(colors, local, group=group)
