@@ -136,3 +136,63 @@ def test_a_training_step_replays_from_one_hip_graph(variant):
         assert pkg.forward_overflowed() == (False, want["num_rendered"])
     finally:
         pkg.set_instance_capacity(None)
+
+
+def test_graphed_step_trains_like_the_eager_loop():
+    """diff_recon_hip.GraphedStep around (render -> loss gradients -> backward) with FusedAdam.step() eager behind every replay (its learning rates and
+    bias corrections are host scalars, rewritten every iteration -- VanillaTS_model.py:583 -- so it stays outside the graph): five iterations, two
+    cameras alternating through copy_ into the settings' tensors, leave the parameters where the eager loop leaves them; an instance capacity that
+    is too small is reported, not silently rendered."""
+    import torch
+    from diff_recon_hip import FusedAdam, GraphedStep
+    from diff_triangle_rasterization_2D import TriangleRasterizer
+    P = 9000
+    s = synthetic.scene(P, 224, 160, 1, seed=71)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    cams = [synthetic.camera(224, 160), synthetic.camera(224, 160)]
+    cams[1]["viewmatrix"] = cams[1]["viewmatrix"].copy()
+    cams[1]["viewmatrix"][3, 0] += 1.5  # a second camera: shifted sideways
+    cams[1]["projmatrix"] = (cams[1]["viewmatrix"] @ synthetic.projection_matrix(cams[1]["tanfovx"], cams[1]["tanfovy"]).T).astype(np.float32)
+    gi, gd, gn = t(s["dL_dout_feature"]), t(s["dL_dout_depth"]), t(s["dL_dout_normal"])
+
+    def run(graphed, capacity=None):
+        rs = helpers.hip_settings(s, True)
+        params = {k: t(s[k]).requires_grad_(True) for k in ("vertex", "opacity", "shs")}
+        opt = FusedAdam([{"params": [params["vertex"]], "lr": 2e-3}, {"params": [params["opacity"]], "lr": 1e-2}, {"params": [params["shs"]], "lr": 5e-3}],
+                        lr=0.0, eps=1e-15)
+        seen = {}
+
+        def fwd_bwd():
+            c2d = torch.zeros((P, 2), device="cuda", requires_grad=True)
+            out = TriangleRasterizer(rs)(params["vertex"], c2d, params["opacity"], shs=params["shs"])
+            torch.autograd.backward([out[0], out[2], out[3]], [gi, gd, gn])
+            seen["n"] = out[0].grad_fn.num_rendered
+
+        def set_camera(c):
+            with torch.no_grad():
+                rs.viewmatrix.copy_(t(c["viewmatrix"])); rs.projmatrix.copy_(t(c["projmatrix"])); rs.campos.copy_(t(c["campos"]))
+
+        step = None
+        if graphed:
+            set_camera(cams[0])
+            step = GraphedStep(lambda: (opt.zero_grad(set_to_none=True), fwd_bwd())[1], instance_capacity=capacity)
+        for it in range(5):
+            set_camera(cams[it % 2])
+            if graphed:
+                step.replay()  # overwrites the (static) .grad tensors the capture left behind
+            else:
+                opt.zero_grad(set_to_none=True)
+                fwd_bwd()
+            opt.step()
+        torch.cuda.synchronize()
+        return {k: v.detach().clone() for k, v in params.items()}, seen.get("n"), (step.overflowed() if graphed else None)
+
+    want, n_eager, _ = run(False)
+    got, _, status = run(True, capacity=2 * n_eager + 4096)
+    assert not status[0] and abs(status[1] - n_eager) <= 0.5 * n_eager  # the true count of the last replay, read back on demand
+    for k in want:
+        scale = float(want[k].abs().max())
+        assert float((got[k] - want[k]).abs().max()) <= 2e-4 * scale, k  # same kernels; the backward's atomic adds are the only freedom
+        assert not torch.equal(got[k], t(s[k])), k                       # ... and it trained
+    _, _, status = run(True, capacity=max(n_eager // 4, 1))
+    assert status[0]  # too small a capacity: reported

@@ -713,7 +713,18 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
 // (rasterizer.cu:63-73); the later sort is by tile id, so only the order BETWEEN triangles matters.
 constexpr uint32_t SMALL = 32;
 
-__global__ void __launch_bounds__(256, 6) scan_emit_kernel(int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
+#ifndef TS_EMIT_WAVES // occupancy / prefetch experiments of round 5 (tools/r05_call4.sh): register budget for N waves per SIMD (0: the compiler's choice)
+#define TS_EMIT_WAVES 0
+#endif
+#ifndef TS_EMIT_PREFETCH
+#define TS_EMIT_PREFETCH 1
+#endif
+#if TS_EMIT_WAVES > 0
+__global__ void __launch_bounds__(256, TS_EMIT_WAVES) scan_emit_kernel(
+#else
+__global__ void __launch_bounds__(256) scan_emit_kernel(
+#endif
+int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *ranges,
                                                          float *contrib_sum, float *contrib_max, long long capacity, int32_t *status, bool two_level,
                                                          QuadMaskArgs qmask)
 {
@@ -740,6 +751,7 @@ __global__ void __launch_bounds__(256, 6) scan_emit_kernel(int P, int grid_x, in
     // is there, so that their round trip runs under the block sums and the scan instead of behind them (round 5)
     uint2 rect = {0u, 0u};
     float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
+#if TS_EMIT_PREFETCH
     if (tiles > 0)
     {
         rect = g.rect[id_ahead];
@@ -748,6 +760,7 @@ __global__ void __launch_bounds__(256, 6) scan_emit_kernel(int P, int grid_x, in
         rec1 = rp[1];
         if (qmask.variant == 3) rec2 = rp[2];
     }
+#endif
     // Everything in front of this block, requested together and reduced once: the earlier quarters of this scan block (scan blocks are 1024
     // triangles = four of these 256-lane blocks), the raw sums of the scan blocks of its group of 64, the group sums in front of that.
     const int sblock = blockIdx.x >> 2, quarter = blockIdx.x & 3;
@@ -785,6 +798,16 @@ __global__ void __launch_bounds__(256, 6) scan_emit_kernel(int P, int grid_x, in
     if (valid) g.offsets[i] = incl;
     const uint32_t id = tiles > 0 ? id_ahead : 0u;
     const uint32_t off = incl - tiles; // exclusive prefix
+#if !TS_EMIT_PREFETCH
+    if (tiles > 0)
+    {
+        rect = g.rect[id];
+        const float4 *rp = g.rec + 4 * (size_t)id;
+        rec0 = rp[0];
+        rec1 = rp[1];
+        if (qmask.variant == 3) rec2 = rp[2];
+    }
+#endif
     const uint32_t minx = rect.x & 0xffffu, miny = rect.x >> 16, maxx = rect.y & 0xffffu, maxy = rect.y >> 16;
     uint32_t *tile_out = b.k[0], *val_out = b.v[0];
     // the four spare bits of an instance's value say which 8x8 quadrants of its tile the triangle's support can reach (ts2d_support.h; both

@@ -23,6 +23,9 @@
 #include "ts2d_group.h"
 #include "ts2d_support.h"
 
+#ifndef TS3G_BWD_WAVES // resident waves per SIMD the backward's register budget is declared for (occupancy experiments: tools/build_variant.sh)
+#define TS3G_BWD_WAVES 5
+#endif
 namespace
 {
 // Row of the constants table (ROW = 20 floats):
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
 //   dL_ddepth = dL_ddepth_pixel contrib + w1 da1_ddepth + w2 da2_ddepth, da1_ddepth = n.cross(v3 - v2, p_ray) / n.n, ...   (:389, 395, 401)
 //   dL/dn  = dL_dnormal_pixel contrib + (w1 (c1 - 2 a1 n) + w2 (c2 - 2 a2 n)) / n.n + dL_ddepth p_v1 / (p_ray.n)   (:388, 394, 403, 406)
 template <bool RICH, bool GAMMA1, int WPB> // WPB = quadrant waves per workgroup (1: single-wave workgroups, see render_group.hip)
-__global__ void __launch_bounds__(64 * WPB, 5) render3d_bwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
+__global__ void __launch_bounds__(64 * WPB, TS3G_BWD_WAVES) render3d_bwd_group_kernel(RenderArgs a, float tan_fovx, float tan_fovy, const uint2 *__restrict__ ranges,
                                                                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
                                                                      const float *__restrict__ final_T, const uint32_t *__restrict__ n_contrib,
                                                                      const float *__restrict__ dL_dout_feature,

@@ -17,6 +17,8 @@
                           (reference: src/diff_recon/models/VanillaTS_model.py:108-124, src/diff_recon/trainers/VanillaTS_trainer.py:119-122)
     model_forward.py      render_view = the argument construction of VanillaTSModel.forward
                           (reference: src/diff_recon/models/VanillaTS_model.py:585-694)
+    graphed.py            GraphedStep: a whole training step (sync-free forward, loss, backward, optimizer) captured once into a HIP graph and
+                          replayed with one launch -- no counterpart in the reference, whose forward reads num_rendered back every step
 
 Native code: libts2d.so (include/ts_loss.h, include/ts_model.h, include/ts_optim.h, include/ts2d.h).  No CPU / eager fallback anywhere.
 """
@@ -28,3 +30,4 @@ from .model_update import (DensificationStats, prune_points, densification, opac
 from . import schedulers  # noqa: F401
 from .raw_triangle import RawTriangle  # noqa: F401
 from .optim import FusedAdam, ShardedAdam  # noqa: F401
+from .graphed import GraphedStep  # noqa: F401
