@@ -402,7 +402,7 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
         }
         TS_CHECK(flags, s, "emit_keys");
     }
-    else TS_HIP(hipMemsetAsync(im.ranges, 0, sizeof(uint2) * (size_t)ntiles, s));
+    else ts_launch_zero_words((uint32_t *)im.ranges, 2 * (size_t)ntiles, s); // no triangles: nobody else clears the ranges (a kernel: see ts2d_backward)
     if (N > 0)
     {
         {
@@ -614,7 +614,10 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
 
     {
         ProfScope ps("zero_grad_records", s);
-        TS_HIP(hipMemsetAsync(grad_rec, 0, sizeof(float) * TS_GRAD_FLOATS * (size_t)P, s)); // rasterizer.cu:290-300
+        // rasterizer.cu:290-300.  A KERNEL, not hipMemsetAsync: captured into a HIP graph (GraphedStep, bench.py --hip-graph) the memset became a
+        // memset NODE, and on this ROCm (7.2, torch 2.10) replays then produced gradients off by up to 1e28 -- the node does not run where the
+        // stream order put it -- while every kernel-only capture is exact (profiles/r05_graph_memset_triage.txt: same script, two libraries)
+        ts_launch_zero_words((uint32_t *)grad_rec, (size_t)TS_GRAD_FLOATS * (size_t)P, s);
     }
     if (N > 0)
     {

@@ -713,11 +713,15 @@ __global__ void __launch_bounds__(256) gather_blocksum_kernel(int P, GeometrySta
 // (rasterizer.cu:63-73); the later sort is by tile id, so only the order BETWEEN triangles matters.
 constexpr uint32_t SMALL = 32;
 
-#ifndef TS_EMIT_WAVES // occupancy / prefetch experiments of round 5 (tools/r05_call4.sh): register budget for N waves per SIMD (0: the compiler's choice)
-#define TS_EMIT_WAVES 0
+// Round 5, measured on three scenes with the five combinations alternating on one box (profiles/r05_emission_variants.txt; tools/r05_call4.sh):
+// a register budget for 6 waves per SIMD (80 registers, 3 spilled; the compiler's own choice is 94 = 5 waves) is worth 0-3 %, and requesting
+// the rectangle / record gather EARLY, under the block sums and the scan, costs 10 % (1 M triangles: 0.054 -> 0.064 ms; 5 M: 0.245 -> 0.277):
+// the gather's 96-128 bytes per lane sit in registers across the scan and the loads queue in front of the block sums the scan waits for.
+#ifndef TS_EMIT_WAVES // register budget for N waves per SIMD (0: the compiler's choice)
+#define TS_EMIT_WAVES 6
 #endif
 #ifndef TS_EMIT_PREFETCH
-#define TS_EMIT_PREFETCH 1
+#define TS_EMIT_PREFETCH 0
 #endif
 #if TS_EMIT_WAVES > 0
 __global__ void __launch_bounds__(256, TS_EMIT_WAVES) scan_emit_kernel(
@@ -747,8 +751,8 @@ int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *r
     const bool valid = i < P;
     uint32_t tiles = valid ? g.tiles_sorted[i] : 0u;
     const uint32_t id_ahead = valid ? sorted_ids(g)[i] : 0u; // wanted after the scan: requested now, one round trip less behind it
-    // ... and what hangs on it -- the tile rectangle and the head of the render record (the quadrant-mask setup) -- is requested as soon as the id
-    // is there, so that their round trip runs under the block sums and the scan instead of behind them (round 5)
+    // (-DTS_EMIT_PREFETCH=1: what hangs on it -- the tile rectangle and the head of the render record -- requested as soon as the id is there; a
+    // measured negative, see above)
     uint2 rect = {0u, 0u};
     float4 rec0 = make_float4(0, 0, 0, 0), rec1 = rec0, rec2 = rec0;
 #if TS_EMIT_PREFETCH
@@ -1088,4 +1092,18 @@ int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, in
 }
 
 void ts_force_ticket_passes(bool on) { g_force_tickets = on; }
+namespace
+{
+__global__ void __launch_bounds__(256) zero_words4_kernel(uint4 *p, size_t n4)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+} // namespace
+void ts_launch_zero_words(uint32_t *p, size_t n, hipStream_t s) // n 32-bit words; 16-byte stores where the range allows
+{
+    if (n == 0) return;
+    if (n % 4 == 0 && ((size_t)p & 15) == 0) hipLaunchKernelGGL(zero_words4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (uint4 *)p, n / 4);
+    else hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, (int)n);
+}
 void ts_force_depth_pass4(bool on) { g_force_pass4 = on; }

@@ -24,7 +24,7 @@
 #include "ts2d_support.h"
 
 #ifndef TS3G_BWD_WAVES // resident waves per SIMD the backward's register budget is declared for (occupancy experiments: tools/build_variant.sh)
-#define TS3G_BWD_WAVES 5
+#define TS3G_BWD_WAVES 6 // round 5: 80 registers with 3-4 spilled dwords outside the step loop; 1.128 vs 1.141 ms at the headline, 0.142 vs 0.148 at 93 k (profiles/r05_emission_variants.txt)
 #endif
 namespace
 {

@@ -237,6 +237,7 @@ struct QuadMaskArgs
     int W, H;
     float inv_W, inv_H; // 1 / W, 1 / H (the 3D setup's pixel -> ray conversions; the masks' margins absorb their rounding)
 };
+void ts_launch_zero_words(uint32_t *p, size_t n, hipStream_t s); // binning.hip
 void ts_launch_emit_keys(int P, int grid_x, int ntiles, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                          float *contrib_sum, float *contrib_max, int64_t capacity, int32_t *status, const QuadMaskArgs &qm, hipStream_t s); // offsets + instances (+ output clears); capacity < 0: synchronous path
 const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int P);                        // where the scan leaves N
