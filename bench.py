@@ -459,6 +459,7 @@ def main():
                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom) if headline else None,
                                   "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(dom_avg, 4),
                                   "launches_timed": dom_n, "compute": compute_side(dom, dom_avg, headline),
+                                  "counter_source": counter_source() if headline else None,
                                   "note": "the blend kernels are bound by VALU issue, not by HBM (DESIGN.md section 4): `compute` is the "
                                           "roofline they sit on; every duration is this run's timed-region HIP events"}
         else:
@@ -483,14 +484,15 @@ FP32_VECTOR_PEAK = 157.3e12                                   # MI355X_MICROARCH
 def compute_side(kernel, avg_ms, headline):
     """The roofline the blend kernels actually sit on (they are bound by VALU issue), from the committed SQ-counter
     pass of the same workload (profiles/blend_pmc.json, tools/collect_blend_pmc.sh), the static instruction mix of the kernel's step
-    loop (profiles/r03_valu_mix.json, tools/isa_mix.py) and the lane-group statistics (profiles/blend_stats.json).  Two bounds on the
+    loop (profiles/r05_valu_mix.json, tools/isa_mix.py) and the lane-group statistics (profiles/blend_stats.json).  Two bounds on the
     VALU time, both in the kernel's own cycles (GRBM_GUI_ACTIVE of the launch):
       valu_busy_frac_lower = SQ_INSTS_VALU x 2 cycles (every instruction at the full wave64-on-SIMD32 rate) / (SIMDs x cycles);
       valu_busy_frac_upper = SQ_INSTS_VALU x the step loop's mix priced with the issue costs measured in REAL shader cycles
                              (tools/valu_bench3.hip: 2 / 4 / 8 cycles for full-rate / half-rate / transcendental instructions; half-rate
                              instructions interleaved with FMAs issue faster than that, hence an upper estimate).
     Plus blended (pixel, triangle) pairs per second and the useful fp32 rate as a fraction of the 157 TFLOP/s vector peak.
-    Durations: the timed-region HIP events of THIS run."""
+    Durations: the timed-region HIP events of THIS run; everything counter-derived comes from the committed passes named in
+    profiles/counters_manifest.json (copied into the line as roofline.counter_source)."""
     out = {}
     if not headline:  # the counter passes were collected on the 2D headline workload only: nothing to quote for another one
         return None
@@ -501,7 +503,7 @@ def compute_side(kernel, avg_ms, headline):
                        transcendental_insts_per_launch=v.get("SQ_INSTS_VALU_TRANS_F32"), lds_busy_frac=v.get("lds_busy_frac"),
                        avg_waves_per_simd=v.get("avg_waves_per_simd"), wave_cycle_split=v.get("wave_cycle_split"),
                        kernel_cycles=v.get("kernel_cycles"))
-            mix = json.load(open(os.path.join(ROOT, "profiles", "r03_valu_mix.json"))).get(kernel)
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r05_valu_mix.json"))).get(kernel)
             if mix and v.get("kernel_cycles"):
                 out.update(step_loop_mix={k: mix[k] for k in ("full", "half", "trans")},
                            priced_cycles_per_valu_instruction=mix["priced_cycles_per_valu_instruction"],
@@ -517,6 +519,17 @@ def compute_side(kernel, avg_ms, headline):
     except Exception:
         pass
     return out or None
+
+
+def counter_source():
+    """Which committed profile passes `traffic` and `compute` were read from: the manifest names the commit of the
+    library sources they were collected on; the line's durations are this run's own."""
+    try:
+        m = json.load(open(os.path.join(ROOT, "profiles", "counters_manifest.json")))
+        return {"collected_on_commit": m.get("collected_on_commit"), "round": m.get("round"), "files": sorted(m.get("files", {})),
+                "note": "counters = committed builder-box passes (profiles/counters_manifest.json); durations = this run"}
+    except Exception:
+        return None
 
 
 def hbm_traffic(kernel):
