@@ -57,15 +57,22 @@ def innermost_loops(lines):
 
 
 def main():
-    src = os.path.join(ROOT, "triangle-splatting_amd", "csrc", "render_group.hip")
+    text = ""
     with tempfile.TemporaryDirectory() as tmp:
-        asm = os.path.join(tmp, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-DNDEBUG", "-mllvm",
-                        "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src,
-                        "-o", asm], check=True, capture_output=True)
-        text = open(asm).read()
+        for name in ("render_group.hip", "render3d_group.hip"):
+            src = os.path.join(ROOT, "triangle-splatting_amd", "csrc", name)
+            asm = os.path.join(tmp, "k.s")
+            subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-DNDEBUG", "-mllvm",
+                            "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src,
+                            "-o", asm], check=True, capture_output=True)
+            text += open(asm).read() + "\n"
     res = {}
-    for kernel, key, steps_per_body in (("render_fwd_group_kernelILb1ELb1E", "render_fwd", 8), ("render_bwd_group_kernelILb1ELb1E", "render_bwd", 1)):
+    # <rich_info, gamma == 1>: the headline instantiations first (bench.py reads render_fwd / render_bwd); then gamma != 1 (pow_nonneg = v_log + v_exp
+    # + the reciprocal of backward.cu:443-447: round 5) and the 3D variant's kernels
+    for kernel, key, steps_per_body in (("23render_fwd_group_kernelILb1ELb1E", "render_fwd", 8), ("23render_bwd_group_kernelILb1ELb1E", "render_bwd", 1),
+                                        ("23render_fwd_group_kernelILb1ELb0E", "render_fwd_gamma_ne_1", 8), ("23render_bwd_group_kernelILb1ELb0E", "render_bwd_gamma_ne_1", 1),
+                                        ("25render3d_fwd_group_kernelILb1ELb1E", "render3d_fwd", 8), ("25render3d_bwd_group_kernelILb1ELb1E", "render3d_bwd", 1),
+                                        ("25render3d_bwd_group_kernelILb1ELb0E", "render3d_bwd_gamma_ne_1", 1)):
         m = re.search(r"^(_ZN\S*" + kernel + r"\S*):.*?s_endpgm", text, re.S | re.M)
         lines = m.group(0).split("\n")
         loops = innermost_loops(lines)
