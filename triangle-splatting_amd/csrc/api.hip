@@ -110,6 +110,10 @@ void prof_drain()
     g_prof_pending.clear();
 }
 
+#ifdef TS2D_LAB
+bool g_lab_all_quadrants = false; // ts2d_lab_force_all_quadrants (csrc/ts2d_lab.h)
+#endif
+
 int validate(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags)
 {
     if (!cam || !geom) return fail(TS2D_ERR_INVALID, "null camera/geometry");
@@ -395,7 +399,10 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
     {
         {
             // quadrant masks for the blend kernels of both variants (ts2d_support.h, ts2d_common.h: QuadMaskArgs)
-            const QuadMaskArgs quad{(flags & TS2D_FLAG_3D) ? 3 : 2, fmaxf(0.0f, 2.0f * geom->gamma), cam->tan_fovx, cam->tan_fovy, W, H, 1.0f / (float)W, 1.0f / (float)H};
+            QuadMaskArgs quad{(flags & TS2D_FLAG_3D) ? 3 : 2, fmaxf(0.0f, 2.0f * geom->gamma), cam->tan_fovx, cam->tan_fovy, W, H, 1.0f / (float)W, 1.0f / (float)H};
+#ifdef TS2D_LAB
+            if (g_lab_all_quadrants) quad.variant = 0; // every instance reaches every quadrant: what the masks must not change (tests/test_qmask_gpu.py)
+#endif
             ProfScope ps("emit_keys", s);
             ts_launch_emit_keys(P, r.grid_x, ntiles, g, b, im, rich ? out->contrib_sum : nullptr, rich ? out->contrib_max : nullptr,
                                 n_dev ? N : -1, im.status, quad, s);
@@ -1000,6 +1007,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
 
 // ts2d_test_sort_pairs / ts2d_test_inclusive_scan_rocprim: csrc/lab_hooks.hip (the rocPRIM comparators live there, outside the product's objects)
 void ts2d_lab_force_ticket_passes(int on) { ts_force_ticket_passes(on != 0); }
+void ts2d_lab_force_all_quadrants(int on) { g_lab_all_quadrants = on != 0; }
 void ts2d_lab_force_depth_pass4(int on) { ts_force_depth_pass4(on != 0); }
 #endif // TS2D_LAB
 

@@ -819,6 +819,7 @@ int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *r
     constexpr bool qm = true;
     const float quad_g2 = qmask.g2;
     auto setup_from = [&](const float4 &r0, const float4 &r1, const float4 &r2, uint32_t tminx, uint32_t tminy, uint32_t tmaxx, uint32_t tmaxy) {
+        if (qmask.variant == 0) return quad_setup_all(); // lab library only: every quadrant (ts2d_lab_force_all_quadrants)
         if (qmask.variant == 3) // the head of the triangle's record and its tile rectangle
         {
             const float E = quad_g2 == 2.0f ? support_scale<true>(1.0f, quad_g2) : support_scale<false>(1.0f, quad_g2);

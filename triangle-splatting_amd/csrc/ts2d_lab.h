@@ -40,6 +40,10 @@ void ts2d_lab_force_ticket_passes(int on);
  * share the top key byte (sign + 7 exponent bits: depths within a factor of four -- every synthetic scene of bench.py; not a real scene
  * that spans more): bench.py --force-depth-pass4 reports the headline without that data-dependent shortcut. */
 void ts2d_lab_force_depth_pass4(int on);
+/* on != 0: the emission kernel of later forwards in this library flags EVERY quadrant of every instance (the masks' machinery runs, the test
+ * always passes).  The masks are pure culling of work that contributes nothing, so every output must be what it is with them on:
+ * tests/test_qmask_gpu.py compares the two, bit for bit where the arithmetic is ordered. */
+void ts2d_lab_force_all_quadrants(int on);
 
 #ifdef __cplusplus
 }
