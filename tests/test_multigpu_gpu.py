@@ -201,6 +201,23 @@ def _rccl_world1_worker(port, q):
             torch.cuda.synchronize()
             errs[mode] = [rel(g, w) for g, w in zip(list(got) + [got_shs], want)]
             assert bucket.flat.numel() % 4 == 0 and vertex.grad is None
+            # round 5: the visible-rows exchange (parallel.VisibleRows) on the device -- mask all-reduce on its own side stream right behind the
+            # forward, compact bucket / compact colour factors through RCCL, sums scattered back; three steps without host synchronisation
+            # other than the row count the exchange itself needs
+            rows = parallel.VisibleRows(None, dev)
+            for it in range(3):
+                sink = parallel.ShGradSink()
+                out, _ = _render(s, _view(0), 2, dev, vertex, shs, opacity, bucket, sink)
+                rows.begin([out[1]])
+                bucket.reduce_async(rows=rows)
+                shx.start(sink, vertex, D, M, uniform=True, rows=rows)
+                got = bucket.wait()
+                got_shs = shx.wait()
+                got[0].mul_(1.0)
+            torch.cuda.synchronize()
+            errs[mode + "+visible_rows"] = [rel(g, w) for g, w in zip(list(got) + [got_shs], want)]
+            nvis = int((out[1] > 0).sum())
+            assert 0 < nvis <= P and int(rows.index().numel()) == nvis and bucket.last_exchanged_bytes <= bucket.padded * 4
         ok = all(e < 2e-5 for v in errs.values() for e in v)
         q.put((bool(ok), errs))
     finally:

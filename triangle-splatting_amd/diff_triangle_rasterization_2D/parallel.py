@@ -80,18 +80,23 @@ class VisibleRows:
             self._work = issue()
 
     def index(self) -> torch.Tensor:
-        """Sorted indices (int64) of the rows visible on any rank -- the same tensor on every rank.  One host read (the count)."""
+        """Sorted indices (int64) of the rows visible on any rank -- the same tensor on every rank.  One host read (the count).  The tensor is
+        produced on this object's side stream; the stream that is current when index() is called (the consumer's) is made to wait for it."""
+        if self._mask is None:
+            raise RuntimeError("VisibleRows.index() before begin()")
+        consumer = torch.cuda.current_stream(self._mask.device) if self._stream is not None else None
         if self._idx is None:
-            if self._mask is None:
-                raise RuntimeError("VisibleRows.index() before begin()")
             if self._work is not None:
                 self._work.wait()
                 self._work = None
             if self._stream is not None:
                 with torch.cuda.stream(self._stream):
-                    self._idx = torch.nonzero(self._mask).reshape(-1)  # synchronises the SIDE stream only
+                    self._idx = torch.nonzero(self._mask).reshape(-1)  # synchronises the SIDE stream only (nonzero reads its count back)
             else:
                 self._idx = torch.nonzero(self._mask).reshape(-1)
+        if consumer is not None:
+            consumer.wait_stream(self._stream)  # nonzero's second kernel (the indices) may still be in flight on the side stream
+            self._idx.record_stream(consumer)
         return self._idx
 
     @property
