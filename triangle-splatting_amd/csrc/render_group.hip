@@ -39,6 +39,12 @@
 #ifndef TSG_BWD_WAVES
 #define TSG_BWD_WAVES 7
 #endif
+#ifndef TSG_FWD_CAP // entries per dense batch (ts2d_group.h: stream_refill)
+#define TSG_FWD_CAP 64
+#endif
+#ifndef TSG_BWD_CAP
+#define TSG_BWD_CAP 64
+#endif
 #ifndef TSG_TCAP
 #define TSG_TCAP 960
 #endif
@@ -234,7 +240,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
         const unsigned long long alive = ballot(!done);
         if (alive == 0) break;
         int nq = 0;
-        stream_refill<false>(id, pos, nq, point_list + range.x, cursor, len, TS_ID_BITS + wave, lane);
+        stream_refill<false, TSG_FWD_CAP>(id, pos, nq, point_list + range.x, cursor, len, TS_ID_BITS + wave, lane);
         if (nq == 0) break;
         const bool valid = lane < nq;
         const int ent = pos;
@@ -519,7 +525,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
     for (;;)
     {
         int nq = 0;
-        stream_refill<true>(id, pos, nq, point_list + range.x, cursor, maxlast, TS_ID_BITS + quad, lane);
+        stream_refill<true, TSG_BWD_CAP>(id, pos, nq, point_list + range.x, cursor, maxlast, TS_ID_BITS + quad, lane);
         if (nq == 0) break;
         const bool valid = lane < nq;
         const int ent = pos;

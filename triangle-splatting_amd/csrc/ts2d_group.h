@@ -26,10 +26,12 @@ __device__ __forceinline__ bool ecc_in_range(float ecc) { return __float_as_uint
 // that does not fit is consumed only up to the last entry that does (the cursor moves by that many candidates).
 // DESC = false: candidates cursor, cursor + 1, ... (< end), cursor moves up.  DESC = true: cursor - 1, cursor - 2, ... (>= 0), cursor moves down
 // (the backward walks the list back to front; lane 0 is then the entry farthest back).
-template <bool DESC>
+// CAP = entries per batch (64; 32 = every batch is ONE pass of the 32-row table and no record is gathered twice -- measured in round 5,
+// profiles/r05_notes.md: the extra block culls cost what the re-gathers save).
+template <bool DESC, int CAP = 64>
 __device__ __forceinline__ void stream_refill(uint32_t &id, int &pos, int &n, const uint32_t *__restrict__ list, int &cursor, int end, int qbit, int lane)
 {
-    while (n < 64 && (DESC ? cursor > 0 : cursor < end))
+    while (n < CAP && (DESC ? cursor > 0 : cursor < end))
     {
         const int k = DESC ? cursor - 1 - lane : cursor + lane;
         const bool valid = DESC ? k >= 0 : k < end;
@@ -37,7 +39,7 @@ __device__ __forceinline__ void stream_refill(uint32_t &id, int &pos, int &n, co
         const bool want = valid && ((v >> qbit) & 1u);
         unsigned long long mt = ballot(want);
         int adv = 64;
-        const int room = 64 - n;
+        const int room = CAP - n;
         bool taken = want;
         if (__popcll(mt) > room) // keep the first `room` of them; the next refill starts behind the last one kept
         {
