@@ -57,6 +57,34 @@ int tsl_depth_normal_backward(const float *depth, const float *normal, int32_t h
                               double scale_factor, const void *workspace, size_t workspace_bytes, const float *grad_out, float *dL_ddepth,
                               float *dL_dnormal, void *stream);
 
+/* ---- the two auxiliary image losses -------------------------------------------------------------------------------------------
+ * DoGLoss(freq, scale_factor) and SmoothnessLoss(quantile, scale_factor), src/diff_recon/trainers/trainer_utils.py:105-148, 181-201 (w_dog,
+ * w_smoothness of VanillaTS_trainer.py:26-29, 82-83, 111; 0 in every shipped configuration).  Images are planar float32 (C, H, W), C <= 8;
+ * a mask is ONE plane (H, W) of 0 / 1 floats formed from the TARGET image without gradient:
+ *   tsl_dog_mask:        grey = mean_c(gt); d = bilinear(grey, scale_factor); DoG = gauss(d, sigma1, ksize1) - gauss(d, sigma2, ksize2)
+ *                        (zero padding); U = bilinear(DoG, (H, W)); n = (U - min U) / (max U - min U), 1 - n when `invert` (freq >= 50);
+ *                        mask = n >= 0.5.  The caller passes the kernel sizes (Python: int(2 * round(3 * sigma) + 1)).
+ *   tsl_smoothness_mask: d = bilinear(gt, scale_factor) per channel; g = |Scharr(d)|_2 over the 2 C gradient planes; U = bilinear(g, (H, W));
+ *                        mask = U < quantile(U, q) (torch.quantile, linear).
+ * scale_factor as in tsl_depth_normal_* (a double; <= 0 or 1 = no resampling).  One workspace size serves all six calls. */
+size_t tsl_aux_loss_workspace_bytes(int32_t channels, int32_t height, int32_t width, double scale_factor);
+int tsl_dog_mask(const float *gt, int32_t channels, int32_t height, int32_t width, double sigma1, int32_t ksize1, double sigma2, int32_t ksize2,
+                 int32_t invert, double scale_factor, void *workspace, size_t workspace_bytes, float *mask, void *stream);
+int tsl_smoothness_mask(const float *gt, int32_t channels, int32_t height, int32_t width, double scale_factor, float quantile, void *workspace,
+                        size_t workspace_bytes, float *mask, void *stream);
+/* out[0] = L1(image * mask, gt * mask) = mean over C H W of |image m - gt m| (trainer_utils.py:147-148); backward: dL_dimage fully written
+ * (sign(0) = 0 like torch's abs), `grad_out` a device scalar or NULL for 1. */
+int tsl_masked_l1_forward(const float *image, const float *gt, const float *mask, int32_t channels, int32_t height, int32_t width, void *workspace,
+                          size_t workspace_bytes, float *out, void *stream);
+int tsl_masked_l1_backward(const float *image, const float *gt, const float *mask, int32_t channels, int32_t height, int32_t width,
+                           const float *grad_out, float *dL_dimage, void *stream);
+/* out[0] = mean over H W of |Scharr(image)|_2 * mask (trainer_utils.py:196-200; zero-padded Scharr pair per channel, norm over the 2 C planes,
+ * gradient 0 where the norm is 0 like torch's norm); backward: dL_dimage (C, H, W) fully written. */
+int tsl_scharr_smoothness_forward(const float *image, const float *mask, int32_t channels, int32_t height, int32_t width, void *workspace,
+                                  size_t workspace_bytes, float *out, void *stream);
+int tsl_scharr_smoothness_backward(const float *image, const float *mask, int32_t channels, int32_t height, int32_t width, void *workspace,
+                                   size_t workspace_bytes, const float *grad_out, float *dL_dimage, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -361,9 +361,46 @@ def depth_normal():
     print("depth_normal.npz:", [float(out[f"loss{i}"]) for i in range(len(cases))])
 
 
+def aux_losses():
+    """DoGLoss / SmoothnessLoss of trainer_utils.py:105-201: the reference's classes + torch autograd on seeded image pairs.  Stored: the inputs, the
+    masks the classes form from the target (their private _dog_mask / _low_grad_mask), the losses and the gradients with respect to the image."""
+    tu = load_trainer_utils()
+    rng = np.random.default_rng(23)
+    out = {}
+    cases = [(3, 48, 64, 0.5, 90, 0.3), (3, 37, 53, 0.5, 80, 0.5), (1, 40, 40, 0.25, 90, 0.3), (3, 30, 50, None, 20, 0.7), (2, 50, 40, 0.7, 90, 0.3)]
+    out["cases"] = np.array([[C, H, W, -1.0 if s is None else s, f, q] for C, H, W, s, f, q in cases], np.float64)
+    for i, (C, H, W, s, freq, q) in enumerate(cases):
+        yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+        base = 0.5 + 0.3 * np.sin(7 * xx + 2 * yy) * np.cos(5 * yy) + 0.2 * (xx > 0.55) - 0.15 * (yy > 0.4)
+        gt = np.clip(base[None] + 0.05 * rng.standard_normal((C, H, W)) + 0.1 * np.arange(C)[:, None, None], 0, 1)
+        img = np.clip(gt + 0.08 * rng.standard_normal((C, H, W)), 0, 1)
+        img[:, :3, :3] = gt[:, :3, :3]  # pixels where image == target: torch's sign(0) = 0
+        # (no exactly flat patch: where the Scharr response cancels to an exact 0 torch's norm backward gives 0, but the reference's float32
+        # convolution leaves ~1e-9 of rounding noise there instead, and its gradient is then a unit vector in the direction of that noise --
+        # not a property anything can be pinned to; the kernels' exact-0 behaviour is tested on a constant image in tests/test_loss_gpu.py)
+        g = torch.tensor(gt, dtype=torch.float32)
+        dog = tu.DoGLoss(freq=freq, scale_factor=s) if s is not None else tu.DoGLoss(freq=freq, scale_factor=1.0)
+        smo = tu.SmoothnessLoss(quantile=q, scale_factor=s) if s is not None else tu.SmoothnessLoss(quantile=q, scale_factor=1.0)
+        x = torch.tensor(img, dtype=torch.float32, requires_grad=True)
+        l1 = dog(x, g)
+        l1.backward()
+        out[f"img{i}"], out[f"gt{i}"] = x.detach().numpy(), g.numpy()
+        out[f"dog_mask{i}"] = dog._dog_mask(g[None])[0, 0].numpy()
+        out[f"dog_loss{i}"], out[f"dog_grad{i}"] = np.float32(l1.item()), x.grad.numpy().copy()
+        x.grad = None
+        l2 = smo(x, g)
+        l2.backward()
+        out[f"smooth_mask{i}"] = smo._low_grad_mask(g[None])[0, 0].numpy()
+        out[f"smooth_loss{i}"], out[f"smooth_grad{i}"] = np.float32(l2.item()), x.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "aux_losses.npz"), **out)
+    print("aux_losses.npz:", [(float(out[f"dog_loss{i}"]), float(out[f"smooth_loss{i}"])) for i in range(len(cases))])
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "depth_normal":
         depth_normal()
+    elif len(sys.argv) > 1 and sys.argv[1] == "aux_losses":
+        aux_losses()
     elif len(sys.argv) > 1 and sys.argv[1] == "model_update":
         model_update(np.random.default_rng(1))  # only this fixture (the others are unchanged since round 1)
     elif len(sys.argv) > 1 and sys.argv[1] == "schedules":

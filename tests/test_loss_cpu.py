@@ -78,3 +78,31 @@ def test_depth_normal_oracle_matches_the_reference_class():
         loss, dd, dn = O.depth_normal_loss(z[f"depth{i}"], z[f"normal{i}"], tx, ty, None if s < 0 else float(s), q)
         assert abs(loss - float(z[f"loss{i}"])) < 2e-6 * abs(float(z[f"loss{i}"]))
         assert rel(dd, z[f"ddepth{i}"]) < 2e-5 and rel(dn, z[f"dnormal{i}"]) < 2e-5
+
+
+def test_aux_loss_oracles_match_the_reference_classes():
+    """oracle/ts_loss_oracle.py: dog_mask / dog_loss / smoothness_mask / smoothness_loss against tests/golden/aux_losses.npz = the reference's
+    DoGLoss and SmoothnessLoss (trainer_utils.py:105-148, 181-201) + torch autograd, executed by tests/golden/make_golden.py aux_losses: scale
+    factors 0.5 (the default), 0.25, 0.7 (non-dyadic) and 1, freq on both sides of 50, one to three channels, pixels where image == target
+    (sign(0) = 0).  The masks are threshold decisions of float32 pipelines: a pixel may differ from the float64
+    restatement only where its value sits within 1e-5 of the threshold."""
+    import os
+    import numpy as np
+    from oracle import ts_loss_oracle as O
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aux_losses.npz"))
+    rel = lambda a, b: np.linalg.norm(a - b) / np.linalg.norm(b)
+    for i, (C, H, W, s, freq, q) in enumerate(z["cases"]):
+        s = None if s < 0 else float(s)
+        img, gt = z[f"img{i}"], z[f"gt{i}"]
+        aux = {}
+        m = O.dog_mask(gt, int(freq), s, aux)
+        differ = m != z[f"dog_mask{i}"]
+        assert (np.abs(aux["normalized"][differ] - 0.5) < 1e-5).all() and differ.mean() < 2e-3, i
+        loss, grad = O.dog_loss(img, gt, int(freq), s, mask=z[f"dog_mask{i}"])   # the losses on the reference's own mask
+        assert abs(loss - float(z[f"dog_loss{i}"])) < 2e-6 * float(z[f"dog_loss{i}"]) and rel(grad, z[f"dog_grad{i}"]) < 1e-6, i
+        aux = {}
+        m = O.smoothness_mask(gt, float(q), s, aux)
+        differ = m != z[f"smooth_mask{i}"]
+        assert (np.abs(aux["U"][differ] - aux["threshold"]) < 1e-5).all() and differ.mean() < 2e-3, i
+        loss, grad = O.smoothness_loss(img, gt, float(q), s, mask=z[f"smooth_mask{i}"])
+        assert abs(loss - float(z[f"smooth_loss{i}"])) < 2e-6 * float(z[f"smooth_loss{i}"]) and rel(grad, z[f"smooth_grad{i}"]) < 2e-5, i

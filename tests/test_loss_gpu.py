@@ -236,3 +236,72 @@ def test_depth_normal_loss_full_size_against_oracle_and_flags():
     assert d2.grad is None and rel(n2.grad.cpu().numpy()[:, ~tie], dn[:, ~tie]) < 1e-4
     with pytest.raises(RuntimeError):
         DepthNormalLoss(scale_factor=0.5)(torch.from_numpy(depth), torch.from_numpy(normal), 0.3, 0.2)
+
+
+@pytest.mark.parametrize("i", range(5))
+def test_aux_losses_match_reference_golden(i):
+    """DoGLoss / SmoothnessLoss (csrc/aux_losses.hip through include/ts_loss.h) against the reference's own classes + autograd
+    (tests/golden/aux_losses.npz): the masks pixel for pixel except where a float32 pipeline may put a value on the other side of its
+    threshold (a handful of pixels, counted), the losses and gradients ON the reference's mask to 1e-5 / 1e-4, and the classes end to end."""
+    import torch
+    from diff_recon_hip import DoGLoss, SmoothnessLoss
+    from diff_recon_hip.losses import _MaskedL1, _ScharrSmoothness
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "aux_losses.npz"))
+    C, H, W, s, freq, q = z["cases"][i]
+    C, H, W, freq = int(C), int(H), int(W), int(freq)
+    s = None if s < 0 else float(s)
+    gt = torch.from_numpy(z[f"gt{i}"]).cuda()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    dog, smo = DoGLoss(freq=freq, scale_factor=s), SmoothnessLoss(quantile=float(q), scale_factor=s)
+    for name, mod, fn in (("dog", dog, _MaskedL1), ("smooth", smo, _ScharrSmoothness)):
+        m = mod.mask(gt).cpu().numpy()
+        ref_m = z[f"{name}_mask{i}"]
+        assert set(np.unique(m)) <= {0.0, 1.0} and (m != ref_m).mean() < 3e-3, (name, float((m != ref_m).mean()))
+        # loss and gradient on the reference's mask: the differentiable part alone
+        x = torch.from_numpy(z[f"img{i}"]).cuda().requires_grad_(True)
+        ws, _ = mod._workspace(gt, C, H, W)
+        rm = torch.from_numpy(ref_m).cuda()
+        loss = fn.apply(x, gt, rm, C, H, W, ws) if name == "dog" else fn.apply(x, rm, C, H, W, ws)
+        (1.5 * loss).backward()
+        want = float(z[f"{name}_loss{i}"])
+        assert abs(float(loss) - want) < 1e-5 * want, (name, float(loss), want)
+        assert rel(x.grad.cpu().numpy() / 1.5, z[f"{name}_grad{i}"]) < 1e-4, name
+        # the class end to end (its own mask): within what the few differing mask pixels can move
+        x2 = torch.from_numpy(z[f"img{i}"]).cuda().requires_grad_(True)
+        l2 = mod(x2, gt)
+        l2.backward()
+        assert abs(float(l2) - want) < 5e-3 * want and rel(x2.grad.cpu().numpy(), z[f"{name}_grad{i}"]) < 8e-2, name
+
+
+def test_aux_losses_full_size_against_oracle_and_surface():
+    """1080p against the float64 oracle (on the kernels' own masks), the reference's call surface (batch dimension, module-level instances), and the
+    refusals: CPU tensors, a target that requires grad, more than 8 folded channels."""
+    import torch
+    from diff_recon_hip import DoGLoss, SmoothnessLoss, dogLoss, smoothnessLoss
+    rng = np.random.default_rng(5)
+    H, W = 1080, 1920
+    yy, xx = np.meshgrid(np.linspace(0, 1, H), np.linspace(0, 1, W), indexing="ij")
+    gt = np.clip(0.5 + 0.3 * np.sin(40 * xx) * np.cos(25 * yy) + 0.05 * rng.standard_normal((3, H, W)), 0, 1).astype(np.float32)
+    img = np.clip(gt + 0.05 * rng.standard_normal((3, H, W)), 0, 1).astype(np.float32)
+    g = torch.from_numpy(gt).cuda()
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    for mod, ofn in ((dogLoss, LO.dog_loss), (smoothnessLoss, LO.smoothness_loss)):
+        x = torch.from_numpy(img).cuda().requires_grad_(True)
+        loss = mod(x[None], g[None])  # (B, C, H, W) like the trainer's call
+        loss.backward()
+        m = mod.mask(g).cpu().numpy().astype(np.float64)
+        assert set(np.unique(m)) <= {0.0, 1.0} and 0.0 < m.mean() < 1.0  # (the DoG mask of a smooth image is mostly 1: the zero padding puts the extremes at the border)
+        want, wgrad = ofn(img, gt, mask=m)
+        assert abs(float(loss) - want) < 1e-5 * want and rel(x.grad.cpu().numpy(), wgrad) < 1e-4
+    # a constant image: every Scharr response cancels to an exact 0 in the kernels' fixed summation order, the norm's gradient there is 0 (torch's
+    # norm backward; the reference's own float32 convolution leaves rounding noise in such regions and differentiates THAT)
+    flat = torch.full((3, 64, 96), 0.37, device="cuda", requires_grad=True)
+    l = SmoothnessLoss()(flat, g[:, :64, :96].contiguous())
+    l.backward()
+    assert float(flat.grad[:, 3:-3, 3:-3].abs().max()) == 0.0  # (the zero padding gives the image's border a real gradient)
+    with pytest.raises(RuntimeError, match="HIP device"):
+        DoGLoss()(torch.zeros(3, 8, 8), torch.zeros(3, 8, 8))
+    with pytest.raises(RuntimeError, match="must not require grad"):
+        SmoothnessLoss()(torch.zeros(3, 8, 8, device="cuda"), torch.zeros(3, 8, 8, device="cuda", requires_grad=True))
+    with pytest.raises(RuntimeError, match="at most 8 channels"):
+        DoGLoss()(torch.zeros(3, 3, 8, 8, device="cuda"), torch.zeros(3, 3, 8, 8, device="cuda"))

@@ -36,6 +36,7 @@ SOURCES = {
     "shgrad.hip": ["-ffp-contract=off"],
     "photometric.hip": [],
     "depth_normal.hip": ["-ffp-contract=off"],
+    "aux_losses.hip": ["-ffp-contract=off"],
     "knn.hip": [],
     "model_update.hip": [],
     "optim.hip": ["-ffp-contract=off"],
@@ -52,7 +53,7 @@ LAB_SOURCES = {  # measurement kernels: libts2d_lab.so only
     "api.hip": ["-DTS2D_LAB"],
 }
 LAB_LIB = os.path.join(os.path.dirname(HERE), "tools", "bin", "libts2d_lab.so")
-HEADERS = ["ts2d_common.h", "ts2d_lab.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_support.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", os.path.join("..", "..", "include", "ts2d.h"),
+HEADERS = ["ts2d_common.h", "ts2d_lab.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_support.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", "ts2d_imgops.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
            os.path.join("..", "..", "include", "ts_knn.h"),
            os.path.join("..", "..", "include", "ts_model.h"),

@@ -755,6 +755,85 @@ int tsl_depth_normal_backward(const float *depth, const float *normal, int32_t h
     return TS2D_OK;
 }
 
+// ---- DoGLoss / SmoothnessLoss (aux_losses.hip) ------------------------------------------------------------------------------------
+size_t tsl_aux_loss_workspace_bytes(int32_t channels, int32_t height, int32_t width, double scale_factor)
+{
+    return ts_aux_loss_workspace_bytes(channels, height, width, scale_factor);
+}
+static int aux_args_ok(int32_t C, int32_t H, int32_t W, double scale, const void *ws, size_t ws_bytes, bool need_ws)
+{
+    if (C <= 0 || C > 8) return fail(TS2D_ERR_INVALID, "channels must be in 1..8");
+    if (H <= 0 || W <= 0) return fail(TS2D_ERR_INVALID, "height and width must be positive");
+    if ((int64_t)H * W > (int64_t)16 * 1000 * 1000) return fail(TS2D_ERR_INVALID, "quantile() input tensor is too large");
+    if (scale > 0.0 && scale != 1.0 && ((int)floor((double)H * scale) < 1 || (int)floor((double)W * scale) < 1))
+        return fail(TS2D_ERR_INVALID, "scale_factor leaves no pixel");
+    if (need_ws && (!ws || ws_bytes < ts_aux_loss_workspace_bytes(C, H, W, scale))) return fail(TS2D_ERR_CAPACITY, "workspace too small");
+    return TS2D_OK;
+}
+int tsl_dog_mask(const float *gt, int32_t C, int32_t H, int32_t W, double sigma1, int32_t ksize1, double sigma2, int32_t ksize2, int32_t invert,
+                 double scale_factor, void *workspace, size_t workspace_bytes, float *mask, void *stream)
+{
+    if (int rc = aux_args_ok(C, H, W, scale_factor, workspace, workspace_bytes, true)) return rc;
+    if (!gt || !mask) return fail(TS2D_ERR_INVALID, "null pointer");
+    if (!(sigma1 > 0.0) || !(sigma2 > 0.0) || ksize1 < 1 || ksize2 < ksize1 || ksize2 > 33 || !(ksize1 & 1) || !(ksize2 & 1))
+        return fail(TS2D_ERR_INVALID, "need 0 < sigma, odd kernel sizes with ksize1 <= ksize2 <= 33");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("dog_mask", s);
+    TS_HIP(ts_dog_mask(gt, C, H, W, sigma1, ksize1, sigma2, ksize2, invert, scale_factor, workspace, mask, s));
+    return TS2D_OK;
+}
+int tsl_smoothness_mask(const float *gt, int32_t C, int32_t H, int32_t W, double scale_factor, float quantile, void *workspace, size_t workspace_bytes,
+                        float *mask, void *stream)
+{
+    if (int rc = aux_args_ok(C, H, W, scale_factor, workspace, workspace_bytes, true)) return rc;
+    if (!gt || !mask) return fail(TS2D_ERR_INVALID, "null pointer");
+    if (!(quantile >= 0.0f && quantile <= 1.0f)) return fail(TS2D_ERR_INVALID, "quantile() q values must be in the range [0, 1]");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("smoothness_mask", s);
+    TS_HIP(ts_smoothness_mask(gt, C, H, W, scale_factor, quantile, workspace, mask, s));
+    return TS2D_OK;
+}
+int tsl_masked_l1_forward(const float *image, const float *gt, const float *mask, int32_t C, int32_t H, int32_t W, void *workspace, size_t workspace_bytes,
+                          float *out, void *stream)
+{
+    if (int rc = aux_args_ok(C, H, W, 1.0, workspace, workspace_bytes, true)) return rc;
+    if (!image || !gt || !mask || !out) return fail(TS2D_ERR_INVALID, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("masked_l1_fwd", s);
+    TS_HIP(ts_masked_l1_forward(image, gt, mask, C, H, W, workspace, out, s));
+    return TS2D_OK;
+}
+int tsl_masked_l1_backward(const float *image, const float *gt, const float *mask, int32_t C, int32_t H, int32_t W, const float *grad_out,
+                           float *dL_dimage, void *stream)
+{
+    if (int rc = aux_args_ok(C, H, W, 1.0, nullptr, 0, false)) return rc;
+    if (!image || !gt || !mask || !dL_dimage) return fail(TS2D_ERR_INVALID, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("masked_l1_bwd", s);
+    TS_HIP(ts_masked_l1_backward(image, gt, mask, C, H, W, grad_out, dL_dimage, s));
+    return TS2D_OK;
+}
+int tsl_scharr_smoothness_forward(const float *image, const float *mask, int32_t C, int32_t H, int32_t W, void *workspace, size_t workspace_bytes,
+                                  float *out, void *stream)
+{
+    if (int rc = aux_args_ok(C, H, W, 1.0, workspace, workspace_bytes, true)) return rc;
+    if (!image || !mask || !out) return fail(TS2D_ERR_INVALID, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("smoothness_fwd", s);
+    TS_HIP(ts_scharr_smoothness_forward(image, mask, C, H, W, workspace, out, s));
+    return TS2D_OK;
+}
+int tsl_scharr_smoothness_backward(const float *image, const float *mask, int32_t C, int32_t H, int32_t W, void *workspace, size_t workspace_bytes,
+                                   const float *grad_out, float *dL_dimage, void *stream)
+{
+    if (int rc = aux_args_ok(C, H, W, 1.0, workspace, workspace_bytes, true)) return rc;
+    if (!image || !mask || !dL_dimage) return fail(TS2D_ERR_INVALID, "null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("smoothness_bwd", s);
+    TS_HIP(ts_scharr_smoothness_backward(image, mask, C, H, W, workspace, grad_out, dL_dimage, s));
+    return TS2D_OK;
+}
+
 // ---- include/ts_knn.h -------------------------------------------------------------------------------------------------
 size_t tsk_workspace_bytes(int32_t P) { return ts_knn_workspace_bytes(P); }
 

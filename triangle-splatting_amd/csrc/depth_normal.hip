@@ -15,29 +15,10 @@
 // atomics: every adjoint is a gather, so results are run-to-run identical.  All of it is HBM-bound.
 #include "../../include/ts_loss.h"
 #include "ts2d_common.h"
+#include "ts2d_imgops.h"
 
 namespace
 {
-// PyTorch's bilinear source index (align_corners = False; aten/native/UpSample.h area_pixel_compute_source_index + guard_index_and_lambda)
-struct Tap { int i0, i1; float l0, l1; };
-__device__ __forceinline__ Tap tap_of(int p, float r, int S)
-{
-    float src = r * ((float)p + 0.5f) - 0.5f;
-    if (src < 0.0f) src = 0.0f;
-    Tap t;
-    t.i0 = min((int)src, S - 1);
-    t.i1 = t.i0 + (t.i0 < S - 1 ? 1 : 0);
-    t.l1 = fminf(fmaxf(src - (float)t.i0, 0.0f), 1.0f);
-    t.l0 = 1.0f - t.l1;
-    return t;
-}
-// destination indices whose taps can touch source index i (a superset; the caller tests each)
-__device__ __forceinline__ void dst_range(int i, float r, int D, int &lo, int &hi)
-{
-    lo = max(0, (int)floorf(((float)i - 0.5f) / r - 0.5f) - 1);
-    hi = min(D - 1, (int)ceilf(((float)i + 1.5f) / r - 0.5f) + 1);
-}
-
 struct Dims { int H, W, h, w; float r_down, r_up_y, r_up_x, A, B; }; // A = w / (2 tan_fovx), B = h / (2 tan_fovy)
 
 __global__ void __launch_bounds__(256) dn_downsample_kernel(Dims m, const float *__restrict__ depth, float *__restrict__ d)
@@ -49,16 +30,6 @@ __global__ void __launch_bounds__(256) dn_downsample_kernel(Dims m, const float 
     const Tap ty = tap_of(i, m.r_down, m.H), tx = tap_of(j, m.r_down, m.W);
     const float *r0 = depth + (size_t)ty.i0 * m.W, *r1 = depth + (size_t)ty.i1 * m.W;
     d[k] = ty.l0 * (tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1]) + ty.l1 * (tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1]);
-}
-
-__device__ __forceinline__ float at0(const float *a, int i, int j, int h, int w) { return (i >= 0 && i < h && j >= 0 && j < w) ? a[(size_t)i * w + j] : 0.0f; }
-__device__ __forceinline__ void scharr(const float *d, int i, int j, int h, int w, float &gx, float &gy)
-{
-    const float a = at0(d, i - 1, j - 1, h, w), b = at0(d, i - 1, j, h, w), c = at0(d, i - 1, j + 1, h, w);
-    const float e = at0(d, i, j - 1, h, w), f = at0(d, i, j + 1, h, w);
-    const float g = at0(d, i + 1, j - 1, h, w), hh = at0(d, i + 1, j, h, w), k = at0(d, i + 1, j + 1, h, w);
-    gx = (-3.0f * a + 3.0f * c - 10.0f * e + 10.0f * f - 3.0f * g + 3.0f * k) * (1.0f / 32.0f);
-    gy = (-3.0f * a - 10.0f * b - 3.0f * c + 3.0f * g + 10.0f * hh + 3.0f * k) * (1.0f / 32.0f);
 }
 
 // raw normal (3 planes) and gradient norm at low resolution
@@ -76,11 +47,6 @@ __global__ void __launch_bounds__(256) dn_lowres_kernel(Dims m, const float *__r
     gnorm[k] = sqrtf(gx * gx + gy * gy);
 }
 
-__device__ __forceinline__ float bilerp(const float *a, int w, const Tap &ty, const Tap &tx)
-{
-    const float *r0 = a + (size_t)ty.i0 * w, *r1 = a + (size_t)ty.i1 * w;
-    return ty.l0 * (tx.l0 * r0[tx.i0] + tx.l1 * r0[tx.i1]) + ty.l1 * (tx.l0 * r1[tx.i0] + tx.l1 * r1[tx.i1]);
-}
 __device__ __forceinline__ void fullres_normal(const Dims &m, const float *nraw, int y, int x, float &Nx, float &Ny, float &Nz)
 {
     const int hw = m.h * m.w;
@@ -116,15 +82,6 @@ __global__ void __launch_bounds__(256) dn_fullres_kernel(Dims m, const float *__
     G[k] = g;
     Gkey[k] = __float_as_uint(g); // G >= 0: the bit pattern is monotone
     t[k] = 1.0f - dot;
-}
-
-// torch.quantile(G, q), interpolation = "linear": rank = q (n - 1) in float32 like torch, lerp between the two neighbours
-__global__ void dn_threshold_kernel(const uint32_t *__restrict__ sorted, int n, float q, float *__restrict__ thr)
-{
-    const float rank = q * (float)(n - 1);
-    const int lo = (int)floorf(rank), hi = min((int)ceilf(rank), n - 1);
-    const float a = __uint_as_float(sorted[lo]), b = __uint_as_float(sorted[hi]), wgt = rank - (float)lo;
-    *thr = (wgt < 0.5f) ? a + wgt * (b - a) : b - (b - a) * (1.0f - wgt); // at::lerp
 }
 
 __global__ void __launch_bounds__(256) dn_sum_kernel(int HW, const float *__restrict__ t, const float *__restrict__ G, const float *__restrict__ thr,
@@ -344,7 +301,7 @@ hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int 
     hipLaunchKernelGGL(dn_lowres_kernel, lo, dim3(256), 0, s, m, c.d, c.nraw, c.gnorm);
     hipLaunchKernelGGL(dn_fullres_kernel, hi, dim3(256), 0, s, m, c.nraw, c.gnorm, normal, c.G, c.k[0], c.t);
     const int src = ts_radix_sort_pairs(c.k, c.v, (size_t)HW, 32, c.scratch, s);
-    hipLaunchKernelGGL(dn_threshold_kernel, dim3(1), dim3(1), 0, s, c.k[src], HW, quantile, c.thr);
+    hipLaunchKernelGGL(quantile_threshold_kernel, dim3(1), dim3(1), 0, s, c.k[src], HW, quantile, c.thr);
     const int nb = min(SUM_BLOCKS, (HW + 255) / 256);
     hipLaunchKernelGGL(dn_sum_kernel, dim3((unsigned)nb), dim3(256), 0, s, HW, c.t, c.G, c.thr, c.partial);
     hipLaunchKernelGGL(dn_finish_kernel, dim3(1), dim3(64), 0, s, nb, HW, c.partial, out);

@@ -315,6 +315,16 @@ hipError_t ts_loss_backward(const float *image, const float *gt, int C, int H, i
                             const float *grad_out, float *dL_dimage, hipStream_t s);
 
 // ---- fused depth / normal consistency loss (depth_normal.hip, include/ts_loss.h) --------------------------------------------------
+// aux_losses.hip -- DoGLoss / SmoothnessLoss (include/ts_loss.h)
+size_t ts_aux_loss_workspace_bytes(int C, int H, int W, double scale);
+hipError_t ts_dog_mask(const float *gt, int C, int H, int W, double sigma1, int ksize1, double sigma2, int ksize2, int invert, double scale, void *workspace,
+                       float *mask, hipStream_t s);
+hipError_t ts_smoothness_mask(const float *gt, int C, int H, int W, double scale, float quantile, void *workspace, float *mask, hipStream_t s);
+hipError_t ts_masked_l1_forward(const float *img, const float *gt, const float *mask, int C, int H, int W, void *workspace, float *out, hipStream_t s);
+hipError_t ts_masked_l1_backward(const float *img, const float *gt, const float *mask, int C, int H, int W, const float *grad_out, float *dimg, hipStream_t s);
+hipError_t ts_scharr_smoothness_forward(const float *img, const float *mask, int C, int H, int W, void *workspace, float *out, hipStream_t s);
+hipError_t ts_scharr_smoothness_backward(const float *img, const float *mask, int C, int H, int W, void *workspace, const float *grad_out, float *dimg,
+                                         hipStream_t s);
 size_t ts_depth_normal_workspace_bytes(int H, int W, double scale);
 hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, double scale, float quantile,
                                    void *workspace, float *out, hipStream_t s);

@@ -1,6 +1,7 @@
 """MI355X-native counterparts of the reference code on either side of the rasterizer:
 
-    losses.py             L1, SSIMLoss / ssimLoss, the fused PhotometricLoss, and DepthNormalLoss (the producer of dL_dout_depth / dL_dout_normal)
+    losses.py             L1, SSIMLoss / ssimLoss, the fused PhotometricLoss, DepthNormalLoss (the producer of dL_dout_depth / dL_dout_normal), and the
+                          two auxiliary image losses DoGLoss / SmoothnessLoss (weight 0 in every shipped configuration; trainer_utils.py:105-201)
                           (reference: src/diff_recon/trainers/trainer_utils.py:9-103, 323-324, 349;
                            combined as in src/diff_recon/trainers/VanillaTS_trainer.py:80-81,111)
     triangle_renderer.py  TriangleRenderer (reference: src/diff_recon/renderer/triangle_renderer.py:15-95)
@@ -22,7 +23,7 @@
 
 Native code: libts2d.so (include/ts_loss.h, include/ts_model.h, include/ts_optim.h, include/ts2d.h).  No CPU / eager fallback anywhere.
 """
-from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss, DepthNormalLoss  # noqa: F401
+from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss, DepthNormalLoss, DoGLoss, SmoothnessLoss, dogLoss, smoothnessLoss  # noqa: F401
 from .triangle_renderer import TriangleRenderer  # noqa: F401
 from .model_forward import gamma_rescale_ratio, rescale_triangles, ste_opacity, render_view  # noqa: F401
 from .model_update import (DensificationStats, prune_points, densification, opacity_pruning, opacity_clipping, scale_pruning,  # noqa: F401

@@ -189,3 +189,147 @@ class DepthNormalLoss(nn.Module):
         if not self.normal_grad:
             normal = normal.detach()
         return _DepthNormal.apply(depth, normal, tan_fovx, tan_fovy, self.scale_factor, self.depth_grad_filter_quantile)
+
+
+# ---- DoGLoss / SmoothnessLoss (round 5; csrc/aux_losses.hip) -------------------------------------------------------------------------
+_lib.tsl_aux_loss_workspace_bytes.restype = C.c_size_t
+_lib.tsl_aux_loss_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_double]
+_lib.tsl_dog_mask.restype = C.c_int
+_lib.tsl_dog_mask.argtypes = [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double, _fp, C.c_size_t, _fp, _fp]
+_lib.tsl_smoothness_mask.restype = C.c_int
+_lib.tsl_smoothness_mask.argtypes = [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_float, _fp, C.c_size_t, _fp, _fp]
+_lib.tsl_masked_l1_forward.restype = C.c_int
+_lib.tsl_masked_l1_forward.argtypes = [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp, _fp]
+_lib.tsl_masked_l1_backward.restype = C.c_int
+_lib.tsl_masked_l1_backward.argtypes = [_fp, _fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp]
+_lib.tsl_scharr_smoothness_forward.restype = C.c_int
+_lib.tsl_scharr_smoothness_forward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp, _fp]
+_lib.tsl_scharr_smoothness_backward.restype = C.c_int
+_lib.tsl_scharr_smoothness_backward.argtypes = [_fp, _fp, C.c_int32, C.c_int32, C.c_int32, _fp, C.c_size_t, _fp, _fp, _fp]
+
+
+def _aux_prepare(img: torch.Tensor, img_gt: torch.Tensor, what: str):
+    _check_inputs(img, img_gt)
+    c, h, w = _chw(img, img_gt)
+    if c > 8:
+        raise RuntimeError(f"{what} (MI355X build) takes at most 8 channels (batch x channels)")
+    if img_gt.requires_grad:
+        raise RuntimeError(f"{what}: the target image must not require grad (its mask is formed without gradient, as in the reference)")
+    return c, h, w, img.contiguous(), img_gt.contiguous()
+
+
+class _MaskedL1(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, gt, mask, c, h, w, ws):
+        out = torch.empty((1,), device=img.device, dtype=torch.float32)
+        with torch.cuda.device(img.device):
+            _native._check(_lib.tsl_masked_l1_forward(img.data_ptr(), gt.data_ptr(), mask.data_ptr(), c, h, w, ws.data_ptr(), ws.numel(), out.data_ptr(),
+                                                      torch.cuda.current_stream().cuda_stream), "DoGLoss")
+        ctx.shape = (c, h, w)
+        ctx.save_for_backward(img, gt, mask)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img, gt, mask = ctx.saved_tensors
+        c, h, w = ctx.shape
+        g = torch.empty_like(img)
+        go = grad_out.contiguous().to(torch.float32)
+        with torch.cuda.device(img.device):
+            _native._check(_lib.tsl_masked_l1_backward(img.data_ptr(), gt.data_ptr(), mask.data_ptr(), c, h, w, go.data_ptr(), g.data_ptr(),
+                                                       torch.cuda.current_stream().cuda_stream), "DoGLoss backward")
+        return g, None, None, None, None, None, None
+
+
+class _ScharrSmoothness(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, mask, c, h, w, ws):
+        out = torch.empty((1,), device=img.device, dtype=torch.float32)
+        with torch.cuda.device(img.device):
+            _native._check(_lib.tsl_scharr_smoothness_forward(img.data_ptr(), mask.data_ptr(), c, h, w, ws.data_ptr(), ws.numel(), out.data_ptr(),
+                                                              torch.cuda.current_stream().cuda_stream), "SmoothnessLoss")
+        ctx.shape = (c, h, w)
+        ctx.save_for_backward(img, mask, ws)
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        img, mask, ws = ctx.saved_tensors
+        c, h, w = ctx.shape
+        g = torch.empty_like(img)
+        go = grad_out.contiguous().to(torch.float32)
+        with torch.cuda.device(img.device):
+            _native._check(_lib.tsl_scharr_smoothness_backward(img.data_ptr(), mask.data_ptr(), c, h, w, ws.data_ptr(), ws.numel(), go.data_ptr(), g.data_ptr(),
+                                                               torch.cuda.current_stream().cuda_stream), "SmoothnessLoss backward")
+        return g, None, None, None, None, None
+
+
+class DoGLoss(nn.Module):
+    """trainer_utils.py:124-148 with the reference's constructor and call surface: `DoGLoss(freq=90, scale_factor=0.5)(img, img_gt)` =
+    L1(img * mask, img_gt * mask), mask = the thresholded, normalised difference of Gaussians of the down-sampled grey target (no gradient).
+    `mask(img_gt)` returns the (H, W) mask alone (it depends on the target only: a caller that keeps its targets can keep their masks)."""
+
+    def __init__(self, freq: int = 90, scale_factor: float = 0.5):
+        super().__init__()
+        self.freq = freq
+        self.scale_factor = scale_factor
+        sigma = 0.1 + (100 - freq) * 0.1 if freq >= 50 else 0.1 + freq * 0.1  # DoGFilter's argument, trainer_utils.py:129
+        self.sigma1, self.sigma2 = sigma, 2 * sigma                          # :108-109
+        self.kernel_size1 = int(2 * round(3 * self.sigma1) + 1)              # :110-111 (Python's round)
+        self.kernel_size2 = int(2 * round(3 * self.sigma2) + 1)
+        if self.kernel_size2 > 33:
+            raise ValueError("DoGLoss (MI355X build): kernel sizes up to 33 (sigma <= 2.6, i.e. freq >= 75 or freq <= 25)")
+
+    def _workspace(self, ref: torch.Tensor, c: int, h: int, w: int):
+        scale = float(self.scale_factor) if self.scale_factor is not None else 1.0
+        with torch.cuda.device(ref.device):
+            return torch.empty((_lib.tsl_aux_loss_workspace_bytes(c, h, w, scale),), device=ref.device, dtype=torch.uint8), scale
+
+    @torch.no_grad()
+    def mask(self, img_gt: torch.Tensor, _ws=None) -> torch.Tensor:
+        c, h, w, gt, _ = _aux_prepare(img_gt, img_gt.detach(), "DoGLoss")
+        ws, scale = _ws if _ws is not None else self._workspace(gt, c, h, w)
+        m = torch.empty((h, w), device=gt.device, dtype=torch.float32)
+        with torch.cuda.device(gt.device):
+            _native._check(_lib.tsl_dog_mask(gt.data_ptr(), c, h, w, self.sigma1, self.kernel_size1, self.sigma2, self.kernel_size2, int(self.freq >= 50), scale,
+                                             ws.data_ptr(), ws.numel(), m.data_ptr(), torch.cuda.current_stream().cuda_stream), "DoGLoss mask")
+        return m
+
+    def forward(self, img: torch.Tensor, img_gt: torch.Tensor) -> torch.Tensor:
+        c, h, w, x, gt = _aux_prepare(img, img_gt, "DoGLoss")
+        ws = self._workspace(gt, c, h, w)
+        return _MaskedL1.apply(x, gt, self.mask(gt, ws), c, h, w, ws[0])
+
+
+class SmoothnessLoss(nn.Module):
+    """trainer_utils.py:181-201: `SmoothnessLoss(quantile=0.3, scale_factor=0.5)(img, img_gt)` = mean(|Scharr(img)|_2 * mask), mask = where the
+    up-sampled gradient norm of the down-sampled target lies below its `quantile` (no gradient)."""
+
+    def __init__(self, quantile: float = 0.3, scale_factor: float = 0.5):
+        super().__init__()
+        self.quantile = quantile
+        self.scale_factor = scale_factor
+
+    def _workspace(self, ref: torch.Tensor, c: int, h: int, w: int):
+        scale = float(self.scale_factor) if self.scale_factor is not None else 1.0
+        with torch.cuda.device(ref.device):
+            return torch.empty((_lib.tsl_aux_loss_workspace_bytes(c, h, w, scale),), device=ref.device, dtype=torch.uint8), scale
+
+    @torch.no_grad()
+    def mask(self, img_gt: torch.Tensor, _ws=None) -> torch.Tensor:
+        c, h, w, gt, _ = _aux_prepare(img_gt, img_gt.detach(), "SmoothnessLoss")
+        ws, scale = _ws if _ws is not None else self._workspace(gt, c, h, w)
+        m = torch.empty((h, w), device=gt.device, dtype=torch.float32)
+        with torch.cuda.device(gt.device):
+            _native._check(_lib.tsl_smoothness_mask(gt.data_ptr(), c, h, w, scale, float(self.quantile), ws.data_ptr(), ws.numel(), m.data_ptr(),
+                                                    torch.cuda.current_stream().cuda_stream), "SmoothnessLoss mask")
+        return m
+
+    def forward(self, img: torch.Tensor, img_gt: torch.Tensor) -> torch.Tensor:
+        c, h, w, x, gt = _aux_prepare(img, img_gt, "SmoothnessLoss")
+        ws = self._workspace(gt, c, h, w)
+        return _ScharrSmoothness.apply(x, self.mask(gt, ws), c, h, w, ws[0])
+
+
+dogLoss = DoGLoss()                  # the module-level instances of trainer_utils.py:350-351
+smoothnessLoss = SmoothnessLoss()
