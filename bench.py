@@ -128,6 +128,10 @@ def main():
                          "behind the forward, compact bucket, compact colour factors).  Pays where a view sees a fraction of the scene (BASELINE "
                          "configs[4]); on the synthetic headline scene every triangle is in the frustum (config.exchange.visible_fraction ~ 1) and "
                          "the dense exchange -- the default -- moves the same bytes without the two gathers")
+    ap.add_argument("--range-exchange", type=int, default=0, metavar="K",
+                    help="N > 1: the backward's per-triangle kernel runs as K launches over consecutive triangle ranges and the bucket is all-reduced "
+                         "range by range as they finish (GradBucket.prepare_ranges / reduce_ranges_async, ts2d_backward_ranged): what it can hide is "
+                         "bounded by that kernel (0.107 ms of the 1.59 ms step); compare config.exchange.exposed_ms_per_step with the default's")
     ap.add_argument("--hip-graph", action="store_true",
                     help="NOT the driver's command: the step (sync-free forward, loss gradients, backward) is captured ONCE into a HIP graph "
                          "(torch.cuda.CUDAGraph on the rasterizer's launches; the sync-free forward has no host read to break the capture) and the "
@@ -197,6 +201,10 @@ def main():
         bucket_group, sh_group = parallel.exchange_groups()
         for _ in range(2 if two_buckets else 1):
             buckets.append(GradBucket(shapes, dev, group=bucket_group, names=["vertex", "opacity", "center2D"] + ([] if factored else ["color"])))
+            if args.range_exchange > 1:
+                if args.sparse_exchange:
+                    raise SystemExit("--range-exchange and --sparse-exchange are alternatives")
+                buckets[-1].prepare_ranges(args.range_exchange)
             shx.append(parallel.FactoredShExchange(sh_group, dev))
         bucket = buckets[0]
     sink = parallel.ShGradSink()
@@ -234,7 +242,10 @@ def main():
                 if vis_rows is not None:
                     vis_rows.begin([out[1]])  # the union of radii > 0 over the ranks: queued behind the forward, read after the backward is queued
                 torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
-            b.reduce_async(rows=vis_rows)
+            if args.range_exchange > 1:
+                b.reduce_ranges_async()
+            else:
+                b.reduce_async(rows=vis_rows)
             if factored:
                 x.start(sink, vertex, D, M, uniform=True, rows=vis_rows)
             if vis_rows is not None:
@@ -413,7 +424,8 @@ def main():
                    "exchange": ({"mode": "delayed: double-buffered buckets, step i's exchange is waited for behind step i+1's kernels (one-step-delayed application)"
                                          if overlap else "synchronous: step i's reduced gradients are waited for inside step i (north_star's all-reduce semantics)",
                                  "exposed_ms_per_step": None if exposed_ms is None else round(exposed_ms, 4),
-                                 "rows": ("visible rows only (parallel.VisibleRows)" if vis_rows is not None else "all rows (dense)"),
+                                 "rows": ("visible rows only (parallel.VisibleRows)" if vis_rows is not None else
+                                          f"all rows, in {args.range_exchange} triangle ranges behind the ranged backward" if args.range_exchange > 1 else "all rows (dense)"),
                                  "visible_fraction": (round(state.get("visible_rows", 0) / max(P, 1), 4) if vis_rows is not None else None),
                                  "bucket_bytes_per_rank_and_step": (buckets[0].last_exchanged_bytes if buckets and hasattr(buckets[0], "last_exchanged_bytes") else None),
                                  "other_mode": other, "process_groups": 2} if world > 1 else None),

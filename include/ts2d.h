@@ -162,6 +162,16 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
 int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t num_rendered,
                   const int32_t *radii, const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch,
                   size_t scratch_bytes, const ts2d_backward_out *out, void *stream);
+/* The same backward with its last kernel (the per-triangle one, BACKWARD::preprocessCUDA's counterpart) launched over `num_ranges` (1..64)
+ * consecutive triangle ranges -- range k = triangles [k * per, min(P, (k + 1) * per)), per = ceil(P / num_ranges) rounded up to a multiple of
+ * 64 (ts2d_backward_range_rows) -- and, when `range_done_events` is not NULL, hipEventRecord(range_done_events[k], stream) behind range k: the
+ * rows of that range in EVERY gradient output are final when the event fires.  Multi-GPU callers start the exchange of range k while range
+ * k + 1 is computed.  Results are those of ts2d_backward (= num_ranges 1, no events). */
+int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t num_rendered, const int32_t *radii,
+                         const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch, size_t scratch_bytes,
+                         const ts2d_backward_out *out, int32_t num_ranges, void *const *range_done_events, void *stream);
+/* Rows per range of ts2d_backward_ranged for P triangles split into num_ranges. */
+int32_t ts2d_backward_range_rows(int32_t P, int32_t num_ranges);
 
 /* Sync-free forward (no counterpart in the reference, whose Rasterizer::forward blocks on a cudaMemcpy of num_rendered,
  * R2D/src/rasterizer.cu:191): preprocess, depth order, instance count, emission, tile sort, ranges and blend are enqueued in ONE call

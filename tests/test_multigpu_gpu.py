@@ -218,6 +218,21 @@ def _rccl_world1_worker(port, q):
             errs[mode + "+visible_rows"] = [rel(g, w) for g, w in zip(list(got) + [got_shs], want)]
             nvis = int((out[1] > 0).sum())
             assert 0 < nvis <= P and int(rows.index().numel()) == nvis and bucket.last_exchanged_bytes <= bucket.padded * 4
+            # round 5: the ranged exchange -- the per-triangle kernel of the backward in 4 launches with an event behind each (ts2d_backward_ranged),
+            # the bucket reduced range by range on the side stream as the events fire
+            rb = parallel.GradBucket([vertex.shape, opacity.shape, torch.Size((P, 2))], dev, names=["vertex", "opacity", "center2D"], force_collectives=True)
+            rb.prepare_ranges(4)
+            for it in range(3):
+                sink = parallel.ShGradSink()
+                _render(s, _view(0), 2, dev, vertex, shs, opacity, rb, sink)
+                assert rb._ranges_recorded
+                rb.reduce_ranges_async()
+                shx.start(sink, vertex, D, M, uniform=True)
+                got = rb.wait()
+                got_shs = shx.wait()
+                got[0].mul_(1.0)
+            torch.cuda.synchronize()
+            errs[mode + "+ranges"] = [rel(g, w) for g, w in zip(list(got) + [got_shs], want)]
         ok = all(e < 2e-5 for v in errs.values() for e in v)
         q.put((bool(ok), errs))
     finally:

@@ -429,6 +429,14 @@ def _visible_rows_worker(rank, world, port, q):
             ok = ok and torch.equal(a, b) and torch.equal(b, w)
         ok = ok and sparse.last_exchanged_bytes < dense.last_exchanged_bytes
         ok = ok and sparse.last_exchanged_bytes <= (idx.numel() * 12 + 4 * world) * 4
+        # the ranged exchange (GradBucket.prepare_ranges / reduce_ranges_async): range after range, the same sums
+        ranged = GradBucket(shapes, "cpu")
+        ranged.prepare_ranges(3)
+        ranged.pack(grads)
+        ranged.reduce_ranges_async()
+        for b, w in zip(ranged.wait(), want):
+            ok = ok and torch.equal(b, w)
+        ok = ok and ranged.range_rows == 128 and ranged.num_ranges == 3  # ceil(203 / 3) = 68 -> 128 rows per range (multiples of 64)
         # a second step with other rows visible reuses the objects
         rows.begin([radii[0]])
         sparse.pack(grads)

@@ -343,3 +343,30 @@ def test_backward_when_the_loss_ignores_the_rich_outputs():
     out[2].sum().backward()
     assert torch.isfinite(vertex.grad).all() and float(vertex.grad.abs().sum()) > 0.0
     assert float(shs.grad.abs().sum()) == 0.0  # the colours do not influence the depth map
+
+
+@pytest.mark.parametrize("variant,P,K", [(2, 5000, 4), (2, 130, 3), (3, 5000, 7), (2, 60, 2)])
+def test_ranged_backward_equals_the_single_launch(variant, P, K):
+    """ts2d_backward_ranged (round 5): the per-triangle kernel of the backward in K launches over consecutive triangle ranges, an event behind each.
+    Same results as ts2d_backward -- the per-triangle arithmetic does not know about ranges; only the atomic sums of the blend kernel in front of it
+    vary from run to run -- for range sizes that do and do not divide P, ranges beyond P (P = 60, K = 2: the second range is empty), both variants."""
+    import torch
+    from diff_triangle_rasterization_2D import _C
+    s = synthetic.scene(P, 160, 128, 2, seed=900 + P)
+    hf = helpers.hip_forward_backward(s, True, variant=variant)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    g, b, im = hf["buffers"]
+    args = (s["tanfovx"], s["tanfovy"], t(s["viewmatrix"]), t(s["projmatrix"]), t(s["campos"]), s["sh_degree"], 1.0, 1.0, float(s["background_depth"]),
+            t(s["background"]), t(s["vertex"]), t(s["shs"]), torch.Tensor([]), t(s["opacity"]), hf["num_rendered"], t(hf["radii"]), g, b, im,
+            t(s["dL_dout_feature"]), t(s["dL_dout_depth"]), t(s["dL_dout_normal"]), True, False)
+    events = [torch.cuda.Event() for _ in range(K)]
+    for e in events:
+        e.record()
+    rows = _C.backward_range_rows(P, K)
+    assert rows % 64 == 0 and rows * K >= P and rows * (K - 1) < P + 64 * K
+    got = _C.rasterize_triangles_backward(*args, variant=variant, range_events=events)
+    for e in events:
+        e.synchronize()  # every event was recorded behind its range (an empty range records too)
+    for name, x in zip(("dL_dvertex", "dL_dcenter2D", "dL_dshs", None, "dL_dopacity"), got):
+        if name:
+            assert helpers.rel_l2(x.cpu().numpy().reshape(hf[name].shape), hf[name]) < 1e-6, name

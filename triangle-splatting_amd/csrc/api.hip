@@ -593,6 +593,20 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
                   const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch, size_t scratch_bytes,
                   const ts2d_backward_out *out, void *stream)
 {
+    return ts2d_backward_ranged(cam, geom, flags, N, radii, state, loss, scratch, scratch_bytes, out, 1, nullptr, stream);
+}
+
+int32_t ts2d_backward_range_rows(int32_t P, int32_t num_ranges)
+{
+    if (P <= 0 || num_ranges < 1) return 0;
+    return ((P + num_ranges - 1) / num_ranges + 63) & ~63;
+}
+
+int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t N, const int32_t *radii,
+                         const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch, size_t scratch_bytes,
+                         const ts2d_backward_out *out, int32_t num_ranges, void *const *range_done_events, void *stream)
+{
+    if (num_ranges < 1 || num_ranges > 64) return fail(TS2D_ERR_INVALID, "num_ranges must be in 1..64");
     if (int rc = validate(cam, geom, flags)) return rc;
     if (!state || !loss || !out) return fail(TS2D_ERR_INVALID, "null state/loss/output");
     const bool rich = flags & TS2D_FLAG_RICH_INFO, use_shs = flags & TS2D_FLAG_USE_SHS;
@@ -649,12 +663,36 @@ int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fl
     {
         ProfScope ps("preprocess_bwd", s);
         const PreprocessArgs a = make_pre(cam, geom, flags);
-        if (flags & TS2D_FLAG_3D)
-            ts_launch_preprocess3d_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, factored ? nullptr : out->dL_dshs,
-                                       out->dL_dfeature, out->dL_dopacity, s);
-        else
-            ts_launch_preprocess_bwd(a, radii, g, grad_rec, out->dL_dvertex, out->dL_dcenter2D, factored ? nullptr : out->dL_dshs,
-                                     out->dL_dfeature, out->dL_dopacity, s);
+        // The per-triangle kernel in num_ranges launches over consecutive triangle ranges (boundaries at multiples of 64 = its workgroups; every
+        // per-triangle array is addressed through its base pointer, so a range is the same launch on shifted pointers) with an event behind each:
+        // the rows [first, first + count) of every gradient output are final when its event fires, and an exchange of range k can start while
+        // range k + 1 runs (parallel.GradBucket.reduce_ranges_async).  num_ranges = 1: the one launch of rounds 1-4.
+        const int per = ((P + num_ranges - 1) / num_ranges + 63) & ~63;
+        for (int k = 0; k < num_ranges; k++)
+        {
+            const int first = k * per, count = first < P ? (P - first < per ? P - first : per) : 0;
+            if (count > 0)
+            {
+                PreprocessArgs ak = a;
+                ak.P = count;
+                ak.vertex += 9 * (size_t)first;
+                if (ak.shs) ak.shs += (size_t)first * a.M * 3;
+                if (ak.feature) ak.feature += (size_t)first * a.C;
+                ak.opacity += first;
+                GeometryStateView gk = g;
+                gk.clamped += first; // the per-triangle state the backward reads besides the gradient records: the clamp flags and, in the
+                if (gk.rec) gk.rec += 4 * (size_t)first; // 3D variant, the triangle's render record
+                float *dshs = (factored || !out->dL_dshs) ? nullptr : out->dL_dshs + (size_t)first * a.M * 3;
+                float *dfeat = out->dL_dfeature ? out->dL_dfeature + (size_t)first * a.C : nullptr;
+                if (flags & TS2D_FLAG_3D)
+                    ts_launch_preprocess3d_bwd(ak, radii + first, gk, grad_rec + TS_GRAD_FLOATS * (size_t)first, out->dL_dvertex + 9 * (size_t)first,
+                                               out->dL_dcenter2D + 2 * (size_t)first, dshs, dfeat, out->dL_dopacity + first, s);
+                else
+                    ts_launch_preprocess_bwd(ak, radii + first, gk, grad_rec + TS_GRAD_FLOATS * (size_t)first, out->dL_dvertex + 9 * (size_t)first,
+                                             out->dL_dcenter2D + 2 * (size_t)first, dshs, dfeat, out->dL_dopacity + first, s);
+            }
+            if (range_done_events && range_done_events[k]) TS_HIP(hipEventRecord((hipEvent_t)range_done_events[k], s));
+        }
     }
     TS_CHECK(flags, s, "preprocess_bwd");
     return TS2D_OK;

@@ -97,6 +97,11 @@ _lib.ts2d_forward_status.argtypes = [C.POINTER(_State), C.c_int32, C.c_int32, C.
 _lib.ts2d_backward.restype = C.c_int
 _lib.ts2d_backward.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, C.c_int64, _fp,
                                C.POINTER(_State), C.POINTER(_LossGrads), _fp, C.c_size_t, C.POINTER(_BackwardOut), _fp]
+_lib.ts2d_backward_ranged.restype = C.c_int
+_lib.ts2d_backward_ranged.argtypes = [C.POINTER(_Camera), C.POINTER(_Geometry), C.c_uint32, C.c_int64, _fp,
+                                      C.POINTER(_State), C.POINTER(_LossGrads), _fp, C.c_size_t, C.POINTER(_BackwardOut), C.c_int32, C.POINTER(_fp), _fp]
+_lib.ts2d_backward_range_rows.restype = C.c_int32
+_lib.ts2d_backward_range_rows.argtypes = [C.c_int32, C.c_int32]
 _lib.ts2d_sh_grad_expand.restype = C.c_int
 _lib.ts2d_sh_grad_expand.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp]
 _lib.ts2d_binning_capacity.restype = C.c_int64
@@ -290,11 +295,13 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
 def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                                  background_depth, background, vertex, shs, feature, opacity, num_rendered, radii,
                                  geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
-                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False, out=None):
+                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False, out=None, range_events=None):
     """`sh_factored=True` (SH mode only; TS2D_FLAG_SH_FACTORED): dL_dshs is not formed (returned as None) and the fourth
     result holds the clamp-masked colour gradient dL_dRGB (P, 3) for `sh_grad_expand` -- see parallel.py.
     `out`: optional dict of preallocated contiguous float32 device tensors ("vertex" (P,3,3), "center2D" (P,2), "opacity" (P,1),
-    "color" = dL_dshs (P,M,3) or dL_dfeature (P,C)) that the library writes instead of fresh allocations (parallel.GradBucket)."""
+    "color" = dL_dshs (P,M,3) or dL_dfeature (P,C)) that the library writes instead of fresh allocations (parallel.GradBucket).
+    `range_events`: a list of K torch.cuda.Event (each recorded at least once before): the per-triangle kernel runs as K launches over
+    consecutive triangle ranges of `backward_range_rows(P, K)` rows and event k is recorded behind range k (ts2d_backward_ranged)."""
     P = vertex.size(0)
     H, W = dL_dout_feature.size(1), dL_dout_feature.size(2)  # extension_interface.cu:182-183
     use_shs = _use_shs(shs, feature)
@@ -346,10 +353,20 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
                           _ptr(dL_dout_normal) if rich_info else None)
         scratch = torch.empty((_lib.ts2d_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
         out = _BackwardOut(_ptr(dL_dvertex), _ptr(dL_dcenter2D), _ptr(dL_dshs), _ptr(dL_dfeature), _ptr(dL_dopacity))
-        _check(_lib.ts2d_backward(C.byref(cam), C.byref(geom), flags, int(num_rendered), _ptr(radii), C.byref(st),
-                                  C.byref(loss), _ptr(scratch), scratch.numel(), C.byref(out), stream),
-               "rasterize_triangles_backward")
+        if range_events:
+            handles = (_fp * len(range_events))(*[int(e.cuda_event) for e in range_events])
+            _check(_lib.ts2d_backward_ranged(C.byref(cam), C.byref(geom), flags, int(num_rendered), _ptr(radii), C.byref(st), C.byref(loss), _ptr(scratch),
+                                             scratch.numel(), C.byref(out), len(range_events), handles, stream), "rasterize_triangles_backward")
+        else:
+            _check(_lib.ts2d_backward(C.byref(cam), C.byref(geom), flags, int(num_rendered), _ptr(radii), C.byref(st),
+                                      C.byref(loss), _ptr(scratch), scratch.numel(), C.byref(out), stream),
+                   "rasterize_triangles_backward")
     return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
+
+
+def backward_range_rows(P: int, num_ranges: int) -> int:
+    """Rows per triangle range of a ranged backward (ts2d_backward_range_rows): ceil(P / K) rounded up to a multiple of 64."""
+    return int(_lib.ts2d_backward_range_rows(int(P), int(num_ranges)))
 
 
 def forward_status(P, W, H, geometryBuffer, imageBuffer):

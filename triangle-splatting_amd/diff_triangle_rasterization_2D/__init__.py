@@ -198,8 +198,13 @@ class _RasterizeTriangles(torch.autograd.Function):
                                            "(pass opt.params[...] itself; an operation between the parameter and the rasterizer would make the "
                                            "bucket hold the wrong gradient)")
             place = bucket.named_views() if (bucket is not None and not bucket._filled) else None
+            # a bucket prepared for a ranged exchange (GradBucket.prepare_ranges): the per-triangle kernel runs range by range with an event behind
+            # each, so that the exchange of range k overlaps range k + 1 -- only for the backward that WRITES the bucket (the first under a capture)
+            ranged = place is not None and getattr(bucket, "range_events", None)
             g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(
-                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place)
+                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place, range_events=ranged or None)
+            if ranged:
+                bucket._ranges_recorded = True
             if sink is not None:
                 sink.append(g_feat, rs.campos)
             if bucket is not None:
