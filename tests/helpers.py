@@ -115,6 +115,14 @@ def lab_library():
         L.ts2d_test_inclusive_scan_rocprim.restype = C.c_int
         L.ts2d_test_inclusive_scan_rocprim.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.ts2d_lab_force_ticket_passes.argtypes = [C.c_int]
+        # same layout code as the product library?  (a lab library left over from before a change of csrc/ts2d_common.h decodes other offsets)
+        from diff_triangle_rasterization_2D import _C as product
+        for f, args in (("ts2d_geometry_state_bytes", (C.c_int32(12345),)), ("ts2d_binning_state_bytes", (C.c_int64(54321), C.c_int32(640), C.c_int32(480))),
+                        ("ts2d_binning_state_bytes", (C.c_int64(7654321), C.c_int32(1920), C.c_int32(1080))), ("ts2d_image_state_bytes", (C.c_int32(640), C.c_int32(480)))):
+            mine, theirs = getattr(L, f), getattr(product._lib, f)
+            mine.restype = theirs.restype = C.c_size_t
+            if mine(*args) != theirs(*args):
+                raise RuntimeError(f"{LAB_LIB} is stale ({f} differs from the product library's): rebuild it with `python triangle-splatting_amd/build.py --lab`")
         _lab = L
     return _lab
 

@@ -105,17 +105,21 @@ static inline void ts_carve(char *&p, T *&out, size_t count)
     p += count * sizeof(T);
 }
 
-static inline void ts_carve_radix(char *&p, size_t n, RadixScratchView &r, int chunk = TS_RS_CHUNK)
+// `reserve_chunk`: the chunk length the tables are SIZED for (<= chunk) -- the instance sort picks its chunk length from the capacity, and the
+// bytes of a binning state must grow with the capacity (ts_binning_capacity inverts them), so its tables always have the short chunks' size.
+static inline void ts_carve_radix(char *&p, size_t n, RadixScratchView &r, int chunk = TS_RS_CHUNK, int reserve_chunk = 0)
 {
     r.chunk = chunk;
     r.chunks = (int)((n + chunk - 1) / chunk);
     r.slabs = (r.chunks + 63) / 64;
-    ts_carve(p, r.table, (size_t)r.chunks * TS_RS_BINS);
-    ts_carve(p, r.slabtot, (size_t)r.slabs * TS_RS_BINS);
+    const int rc = reserve_chunk > 0 ? reserve_chunk : chunk;
+    const size_t chunks = (n + rc - 1) / rc, slabs = (chunks + 63) / 64;
+    ts_carve(p, r.table, chunks * TS_RS_BINS);
+    ts_carve(p, r.slabtot, slabs * TS_RS_BINS);
     ts_carve(p, r.binbase, (size_t)TS_RS_BINS);
-    ts_carve(p, r.tickets, (size_t)r.slabs + TS_RS_TICKET_EXTRA);
-    ts_carve(p, r.slabacc[0], (size_t)r.slabs * TS_RS_BINS);
-    ts_carve(p, r.slabacc[1], (size_t)r.slabs * TS_RS_BINS);
+    ts_carve(p, r.tickets, slabs + TS_RS_TICKET_EXTRA);
+    ts_carve(p, r.slabacc[0], slabs * TS_RS_BINS);
+    ts_carve(p, r.slabacc[1], slabs * TS_RS_BINS);
 }
 
 static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView &v)
@@ -155,6 +159,15 @@ static inline int ts_higher_msb(uint32_t n) // R2D/src/rasterizer.cu:20-35 (same
     return (int)msb;
 }
 
+// Chunk length of the instance sort, from the CAPACITY of the binning state (so that the forward and the backward, which both carve from the
+// buffer's size, agree): lists of up to TS_INSTANCE_SMALL_BELOW instances are a few hundred workgroups of 4096 -- all resident at once, the launch
+// lasts as long as ONE workgroup's chain of 16 ranking steps per lane; 2048-pair chunks halve that chain (tile sort 40 -> 28 us at 44 k instances, 50 -> 35 at 1 M, 54 -> 43 at 1.4 M;
+// equal at the headline's 4.6 M: profiles/r05_instance_chunk_ab.txt).
+#ifndef TS_INSTANCE_SMALL_BELOW
+#define TS_INSTANCE_SMALL_BELOW 2500000
+#endif
+static inline int ts_instance_chunk(size_t n) { return n <= (size_t)TS_INSTANCE_SMALL_BELOW ? TS_RS_CHUNK_SMALL : TS_RS_CHUNK; }
+
 static inline size_t ts_carve_binning(char *base, int64_t N, int32_t W, int32_t H, BinningStateView &v)
 {
     char *p = base;
@@ -167,7 +180,7 @@ static inline size_t ts_carve_binning(char *base, int64_t N, int32_t W, int32_t 
     v.passes = (ts_higher_msb((uint32_t)(gx * gy)) + 7) / 8; // tile bits only (see binning.hip)
     v.tile = v.k[v.passes & 1];
     v.vals = v.v[v.passes & 1];
-    ts_carve_radix(p, n, v.rs);
+    ts_carve_radix(p, n, v.rs, ts_instance_chunk(n), TS_RS_CHUNK_SMALL);
     return (size_t)(p - base) + TS_ALIGN;
 }
 
