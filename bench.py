@@ -71,6 +71,8 @@ def algorithmic_bytes(P, N, W, H, D, ntiles):
     k["total"] = sum(k.values())
     # our two-stage ordering (binning.hip) moves fewer bytes than the SURVEY row; listed for the per-kernel table only
     k["depth_sort"] = P * 16 * 4
+    k["depth_census"] = P * 8          # first histogram: keys + tile counts (small scenes: the whole depth order in this one launch)
+    k["zero_grad_records"] = P * 64
     k["tile_sort"] = N * 16 * -(-msb_bits(ntiles) // 8)
     return k
 
@@ -465,11 +467,11 @@ def main():
                 result["config"]["gpu_idle_ms_per_step"] = round(sum(device_steps) / len(device_steps) - busy, 4)
             dom, dom_ms, dom_n = rows[0]
             dom_avg = dom_ms / max(dom_n, 1)
-            ach = alg[dom] / (dom_avg * 1e-3) / 1e9
+            ach = alg.get(dom, 0) / (dom_avg * 1e-3) / 1e9
             headline = (P, W, H, D, args.rasterizer) == (1_000_000, 1920, 1080, 3, "2D")
             result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom) if headline else None,
-                                  "algorithmic_bytes_per_launch": alg[dom], "avg_launch_ms": round(dom_avg, 4),
+                                  "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_ms": round(dom_avg, 4),
                                   "launches_timed": dom_n, "compute": compute_side(dom, dom_avg, headline),
                                   "counter_source": counter_source() if headline else None,
                                   "note": "the blend kernels are bound by VALU issue, not by HBM (DESIGN.md section 4): `compute` is the "

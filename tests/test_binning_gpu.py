@@ -81,6 +81,33 @@ def test_instance_offsets_match_rocprim_scan(P, W, H):
     assert np.array_equal(ranges[:, 1] - ranges[:, 0], np.bincount(keys >> 32, minlength=ranges.shape[0]))
 
 
+@pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 1024, 1025, 4097, 10_000, 16_383, 16_384, 16_385, 20_000])
+@pytest.mark.parametrize("spread", [False, True])
+def test_depth_order_of_small_scenes_is_the_stable_sort(P, spread):
+    """Up to 16 384 triangles ONE launch orders the triangles (binning.hip: depth_order_small_kernel -- one workgroup, the pairs in registers, LDS
+    between the passes) and leaves what the census and the block-sum launch leave at larger sizes; above, the multi-launch sort.  Either way:
+    ids in (depth bits, id) order = numpy's stable argsort of the keys (culled triangles carry key 0), offsets = the running sum of the tile
+    counts in that order, N = its last value.  `spread`: depths over a factor > 4, so the top key byte varies and the fourth pass runs."""
+    s = synthetic.scene(P, 192, 160, 0, seed=4000 + P)
+    if spread:
+        rng = np.random.default_rng(P)
+        cam = np.asarray(s["campos"], np.float32).reshape(1, 1, 3)  # every triangle moved along its ray from the camera: same pixels, other depth
+        s["vertex"] = (cam + (s["vertex"] - cam) * rng.uniform(0.2, 3.0, size=(P, 1, 1))).astype(np.float32)
+    hf = helpers.hip_forward_backward(s, rich_info=True, backward=False)
+    depth = helpers.hip_state(hf, s, "depth").view(np.uint32)
+    radii = hf["radii"].reshape(-1)
+    keys = np.where(radii > 0, depth, 0).astype(np.uint32)
+    perm = helpers.hip_state(hf, s, "depth_perm").astype(np.int64)
+    assert np.array_equal(perm, np.argsort(keys, kind="stable"))
+    tt = helpers.hip_state(hf, s, "tiles_touched").astype(np.int64)
+    off = helpers.hip_state(hf, s, "point_offsets").view(np.uint32).astype(np.int64)
+    assert np.array_equal(off, np.cumsum(tt[perm]))
+    assert int(off[-1]) == hf["num_rendered"]
+    if spread:
+        vis = keys[keys != 0]
+        assert vis.size == 0 or (vis.max() >> 24) != (vis.min() >> 24) or P < 64  # the fourth pass had something to order
+
+
 @pytest.mark.parametrize("P", [1, 3, 8, 9, 40])
 @pytest.mark.parametrize("variant", [2, 3])
 def test_tiny_scene_in_recycled_state_buffers(P, variant):

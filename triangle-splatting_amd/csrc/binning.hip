@@ -960,15 +960,175 @@ __global__ void zero_words_kernel(uint32_t *p, int n)
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
+// ---- small scenes: the whole depth order in ONE launch ------------------------------------------------------------------------------
+// Up to TS_DEPTH_SMALL_MAX triangles the eight launches of the depth sort and the launch of the block sums order a few thousand keys in 4-9 us
+// each -- dependent launches, each one a load -> LDS -> barrier -> store chain with a handful of workgroups on the chip (BASELINE configs[0],
+// 10 k triangles: 47 + 7 of the step's 166 us).  Here ONE workgroup of 16 waves keeps the (key, id) pairs in registers (wave w: a contiguous
+// range of `per` <= 1024 positions, 64 consecutive pairs per step), ranks them with the same wave-local match as rs_scatter_body, exchanges
+// them through LDS after every pass, and then does what the census, publish_census and gather_blocksum_kernel do: N to the device word and
+// the pinned host word, tiles_sorted, the raw block sums.  Same passes (the fourth skipped under the same condition), same stable order,
+// so sv[1] holds exactly the ids the multi-launch path leaves in sorted_ids(); top_const stays 0 (the order is always in sk[1] / sv[1]).
+constexpr int TS_DEPTH_SMALL_MAX = 16384;
+constexpr int DS_WAVES = 16, DS_KB = TS_DEPTH_SMALL_MAX / (64 * DS_WAVES);
+__global__ void __launch_bounds__(64 * DS_WAVES) depth_order_small_kernel(int P, GeometryStateView g, unsigned long long *host_out)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stage_k[TS_DEPTH_SMALL_MAX], stage_v[TS_DEPTH_SMALL_MAX];
+    __shared__ uint32_t wcnt[DS_WAVES][NB]; // per-wave digit counts, then the start of the (wave, digit) run
+    __shared__ uint32_t wtot[4];
+    __shared__ unsigned long long csum[DS_WAVES], bsum[TS_DEPTH_SMALL_MAX / SB];
+    __shared__ uint32_t cor[DS_WAVES], cnand[DS_WAVES];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int per = ((P + 64 * DS_WAVES - 1) / (64 * DS_WAVES)) * 64; // positions per wave
+    const int base = wave * per;
+    const int mine = P - base < per ? (P - base > 0 ? P - base : 0) : per;
+    const uint32_t *keys = (const uint32_t *)g.depth;
+    uint32_t key[DS_KB], val[DS_KB], rk[DS_KB];
+    unsigned long long tsum = 0;
+    uint32_t kor = 0u, knand = 0u;
+    if (t < TS_DEPTH_SMALL_MAX / SB) bsum[t] = 0ull;
+#pragma unroll
+    for (int b = 0; b < DS_KB; b++) // branch-free: the register arrays stay scalars the compiler can place one by one
+    {
+        const int i = 64 * b + lane;
+        const bool in = i < mine;
+        const int src = in ? base + i : 0;
+        const uint32_t k = keys[src], tt = g.tiles_touched[src];
+        key[b] = in ? k : 0xFFFFFFFFu;
+        val[b] = (uint32_t)src;
+        tsum += in ? tt : 0u;
+        const bool vis = in && k != 0u; // culled triangles (key 0) do not count: rs_hist_census_direct_kernel
+        kor |= vis ? k : 0u;
+        knand |= vis ? ~k : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        tsum += __shfl_xor(tsum, o);
+        kor |= __shfl_xor(kor, o);
+        knand |= __shfl_xor(knand, o);
+    }
+    if (lane == 0) { csum[wave] = tsum; cor[wave] = kor; cnand[wave] = knand; }
+    __syncthreads();
+    unsigned long long N = 0;
+    uint32_t o_all = 0u, n_all = 0u;
+#pragma unroll
+    for (int w = 0; w < DS_WAVES; w++) { N += csum[w]; o_all |= cor[w]; n_all |= cnand[w]; }
+    const uint32_t varying = o_all ^ ~n_all;             // publish_census: or ^ and, and = ~(or of the complements)
+    const int passes = (varying >> 24) == 0u ? 3 : 4;    // no visible triangle: or = 0, and = ~0 -> four passes, like the flag there
+    uint32_t *cnt = wcnt[wave];
+#pragma nounroll
+    for (int pass = 0; pass < passes; pass++)
+    {
+        const int shift = 8 * pass;
+#pragma unroll
+        for (int k = 0; k < NB / 64; k++) cnt[lane + 64 * k] = 0u;
+        wave_lds_order();
+#pragma unroll
+        for (int b = 0; b < DS_KB; b++)
+        {
+            if (64 * b >= per) continue; // wave-uniform
+            const bool valid = 64 * b + lane < mine;
+            const uint32_t d = (key[b] >> shift) & 0xFFu;
+            // lanes whose digit differs from mine in some bit: (ballot of bit i) xor (my bit i, sign-extended), or-ed over the bits -- two
+            // 32-bit halves, three instructions per bit and half (the select form of rs_scatter_body costs ~100 instructions per step; this
+            // kernel runs on ONE compute unit and is bound by exactly these)
+            const unsigned long long vm = ballot64(valid);
+            uint32_t mis_lo = ~(uint32_t)vm, mis_hi = ~(uint32_t)(vm >> 32);
+#pragma unroll
+            for (int bit = 0; bit < 8; bit++)
+            {
+                const unsigned long long bb = ballot64((d >> bit) & 1u);
+                const uint32_t e = (uint32_t)__builtin_amdgcn_sbfe((int)d, bit, 1); // all ones when my bit is set
+                mis_lo |= (uint32_t)bb ^ e;
+                mis_hi |= (uint32_t)(bb >> 32) ^ e;
+            }
+            const uint32_t m_lo = ~mis_lo, m_hi = ~mis_hi; // valid lanes with my digit
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+            const uint32_t c = (uint32_t)(__popc(m_lo) + __popc(m_hi));
+            uint32_t seen = 0;
+            if (valid) seen = cnt[d];
+            wave_lds_order(); // every lane has read its digit's count before the group leaders advance it
+            if (valid && rank == c - 1u) cnt[d] = seen + c;
+            wave_lds_order();
+            rk[b] = seen + rank;
+        }
+        __syncthreads();
+        uint32_t c[DS_WAVES], tot = 0u, inc = 0u;
+        if (t < NB) // thread d = digit d
+        {
+#pragma unroll
+            for (int w = 0; w < DS_WAVES; w++) { c[w] = wcnt[w][t]; tot += c[w]; }
+            inc = wave_inclusive_scan(tot, lane);
+            if (lane == 63) wtot[wave] = inc;
+        }
+        __syncthreads();
+        if (t < NB)
+        {
+            uint32_t run = inc - tot;
+            for (int w = 0; w < wave; w++) run += wtot[w];
+#pragma unroll
+            for (int w = 0; w < DS_WAVES; w++) { wcnt[w][t] = run; run += c[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < DS_KB; b++)
+            if (64 * b + lane < mine)
+            {
+                const uint32_t p = cnt[(key[b] >> shift) & 0xFFu] + rk[b];
+                stage_k[p] = key[b];
+                stage_v[p] = val[b];
+            }
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < DS_KB; b++) // (positions past `mine` hold stale pairs that nothing uses)
+        {
+            key[b] = stage_k[base + 64 * b + lane];
+            val[b] = stage_v[base + 64 * b + lane];
+        }
+    }
+    // the order, the tile counts in that order, their raw sums per scan block (64 consecutive positions never straddle a block of SB)
+#pragma unroll
+    for (int b = 0; b < DS_KB; b++)
+    {
+        if (64 * b >= per) continue;
+        const int i = base + 64 * b + lane;
+        unsigned long long tiles = 0;
+        if (64 * b + lane < mine)
+        {
+            const uint32_t tt = g.tiles_touched[val[b]];
+            g.sk[1][i] = key[b];
+            g.sv[1][i] = val[b];
+            g.tiles_sorted[i] = tt;
+            tiles = tt;
+        }
+        for (int o = 32; o > 0; o >>= 1) tiles += __shfl_xor(tiles, o);
+        if (lane == 0 && tiles) atomicAdd(&bsum[(base + 64 * b) / SB], tiles);
+    }
+    __syncthreads();
+    const int nblocks = (P + SB - 1) / SB;
+    if (t < nblocks) g.blocksum[t] = bsum[t];
+    if (t == 0)
+    {
+        g.blocksum[nblocks] = N; // = DepthCensus::n_out
+        *g.top_const = 0u;
+        if (host_out) __hip_atomic_store(host_out, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 } // namespace
 
 // Step 1: (depth bits, id) -> sorted ids.  Depth keys are view-space z of visible triangles (> 0, so the unsigned bit
 // pattern is monotone) and 0 for culled ones, which emit nothing wherever they land.  `begin` = the launches that produce N (to `host_out`
 // as well when given) and the key-bit census: the first histogram, and on the ticket-free path the first scatter too; `finish` = the other
 // launches (the 4th pass returns at once when the census found the top byte constant: then sk[0] / sv[0] hold the order).
+// The one-launch form (depth_order_small_kernel) -- never under the lab library's switches, which exist to run the multi-launch forms on small scenes.
+static bool depth_small_ok(int32_t P) { return P <= TS_DEPTH_SMALL_MAX && !g_force_tickets && !g_force_pass4; }
 void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s)
 {
     if (P <= 0) return;
+    if (depth_small_ok(P))
+    {
+        hipLaunchKernelGGL(depth_order_small_kernel, dim3(1), dim3(64 * DS_WAVES), 0, s, P, g, host_out);
+        return;
+    }
     DepthCensus c;
     c.tiles_touched = g.tiles_touched;
     c.chunk_sum = (unsigned long long *)g.blocksum; // scratch: rewritten by gather_blocksum_kernel (chunks <= ceil(P / 1024))
@@ -1004,7 +1164,7 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
 }
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
-    if (P <= 0) return;
+    if (P <= 0 || depth_small_ok(P)) return;
     if (!radix_direct_ok(g.rs))
     {
         radix_scatter((const uint32_t *)g.depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s);
@@ -1023,7 +1183,7 @@ void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t 
 static bool scan_two_level(int32_t P) { return g_force_tickets || (P + SB - 1) / SB > 2048; }
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
-    if (P <= 0) return;
+    if (P <= 0 || depth_small_ok(P)) return; // small scenes: depth_order_small_kernel left tiles_sorted and the block sums behind
     hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)((P + SB - 1) / SB)), dim3(256), 0, s, P, g, scan_two_level(P));
 }
 
@@ -1040,7 +1200,7 @@ const unsigned long long *ts_instance_count_dev(const GeometryStateView &g, int 
 void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long long *n_dev, int ntiles, hipStream_t s)
 {
     if (N <= 0) return;
-    const int bits = ts_higher_msb((uint32_t)ntiles);
+    const int bits = ts_tile_bits(ntiles);
     // the key bits are shared out evenly over the passes (1080p: 13 bits = 7 + 6, not 8 + 5): fewer digits in the first pass mean longer
     // runs per digit in a chunk (32 pairs instead of 16), i.e. better coalesced stores, and one ballot less per ranking step
     const int per = (bits + b.passes - 1) / b.passes;

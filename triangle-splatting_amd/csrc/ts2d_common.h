@@ -168,6 +168,10 @@ static inline int ts_higher_msb(uint32_t n) // R2D/src/rasterizer.cu:20-35 (same
 #endif
 static inline int ts_instance_chunk(size_t n) { return n <= (size_t)TS_INSTANCE_SMALL_BELOW ? TS_RS_CHUNK_SMALL : TS_RS_CHUNK; }
 
+// Key bits of the instance sort: the tile ids are 0 .. ntiles - 1.  (The reference sorts 32 + getHigherMsb(ntiles) bits, rasterizer.cu:211-222 -- one
+// more than needed when ntiles is a power of two, e.g. 9 for the 256 tiles of a 256 x 256 image: here that is one 8-bit pass instead of two.)
+static inline int ts_tile_bits(int ntiles) { return ts_higher_msb((uint32_t)(ntiles > 1 ? ntiles - 1 : 1)); }
+
 static inline size_t ts_carve_binning(char *base, int64_t N, int32_t W, int32_t H, BinningStateView &v)
 {
     char *p = base;
@@ -177,7 +181,7 @@ static inline size_t ts_carve_binning(char *base, int64_t N, int32_t W, int32_t 
     ts_carve(p, v.k[1], n);
     ts_carve(p, v.v[0], n);
     ts_carve(p, v.v[1], n);
-    v.passes = (ts_higher_msb((uint32_t)(gx * gy)) + 7) / 8; // tile bits only (see binning.hip)
+    v.passes = (ts_tile_bits(gx * gy) + 7) / 8; // tile bits only (see binning.hip)
     v.tile = v.k[v.passes & 1];
     v.vals = v.v[v.passes & 1];
     ts_carve_radix(p, n, v.rs, ts_instance_chunk(n), TS_RS_CHUNK_SMALL);
