@@ -197,12 +197,13 @@ def main():
     overlap = world > 1 and args.delayed_exchange
     two_buckets = world > 1 and (overlap or args.exchange_compare)
     if world > 1:
-        shapes = [vertex.shape, opacity.shape, torch.Size((P, 2))] + ([] if factored else [shs.shape])
+        # (no slot for dL_dcenter2D: it is a per-view statistic, not a parameter gradient -- each view keeps its own, nothing to sum)
+        shapes = [vertex.shape, opacity.shape] + ([] if factored else [shs.shape])
         # two process groups = two RCCL communicators / streams: the bucket's reduce-scatter + all-gather and the SH-gradient all-gather
         # are in flight together; two buckets: the exchange of step i has the whole of step i + 1 to finish
         bucket_group, sh_group = parallel.exchange_groups()
         for _ in range(2 if two_buckets else 1):
-            buckets.append(GradBucket(shapes, dev, group=bucket_group, names=["vertex", "opacity", "center2D"] + ([] if factored else ["color"])))
+            buckets.append(GradBucket(shapes, dev, group=bucket_group, names=["vertex", "opacity"] + ([] if factored else ["color"])))
             if args.range_exchange > 1:
                 if args.sparse_exchange:
                     raise SystemExit("--range-exchange and --sparse-exchange are alternatives")
@@ -234,7 +235,7 @@ def main():
     def step():
         center2D = torch.zeros((P, 2), device=dev, requires_grad=True)  # like triangle_renderer.py:67
         if bucket is not None:
-            # N > 1: the backward kernels write dL_dvertex / dL_dopacity / dL_dcenter2D (and, with --dense-exchange, dL_dshs)
+            # N > 1: the backward kernels write dL_dvertex / dL_dopacity (and, with --dense-exchange, dL_dshs)
             # straight into the exchange bucket; its reduce-scatter + all-gather starts on a side stream as soon as the backward
             # is queued, the factored SH-gradient all-gather + expansion on another (parallel.py)
             i = state["step"]
@@ -421,7 +422,7 @@ def main():
                                "sync-free (ts2d_forward, device-side instance count)" if args.sync_free else
                                "speculative (ts2d_forward_speculative: queued for 1.25 x the recent instance count, exact num_rendered read back "
                                "behind the queue; the package default)"),
-                   "parallelism": f"image-parallel x{world}" + ((", RCCL reduce-scatter + all-gather of one 12-float/triangle bucket the backward writes into (GradBucket.capture) + all-gather of factored SH grads (3 floats/triangle/view)" if factored
+                   "parallelism": f"image-parallel x{world}" + ((", RCCL reduce-scatter + all-gather of one 10-float/triangle bucket the backward writes into (GradBucket.capture) + all-gather of factored SH grads (3 floats/triangle/view)" if factored
                                        else ", RCCL all-reduce of dense per-triangle grads (60 floats/triangle)") if world > 1 else ""),
                    "exchange": ({"mode": "delayed: double-buffered buckets, step i's exchange is waited for behind step i+1's kernels (one-step-delayed application)"
                                          if overlap else "synchronous: step i's reduced gradients are waited for inside step i (north_star's all-reduce semantics)",
