@@ -398,8 +398,10 @@ __device__ __forceinline__ void rs_scatter_body(const uint32_t *__restrict__ kin
     if (!resolve_count<CH>(n_dev, n, r)) return;
     if (pass_skipped(skip_flag)) return;
     if (acc_clear && (int)blockIdx.x < r.slabs) acc_clear[(size_t)blockIdx.x * NB + threadIdx.x] = 0u;
-    __shared__ __attribute__((aligned(16))) uint32_t stage_k[CH], stage_v[TWO_PHASE ? 4 : CH];
-    static_assert(CH >= (TWO_PHASE ? 12 : 8) * NB, "the DIRECT prefix exchange borrows 8 (TWO_PHASE: 12) x 256 words of stage_k");
+    constexpr int SK = (!TWO_PHASE && CH < 8 * NB) ? 8 * NB : CH; // the DIRECT prefix exchange borrows 8 (TWO_PHASE: 12) x 256 words of stage_k
+    constexpr int SV = TWO_PHASE ? 4 : (CH < 4 * NB ? 4 * NB : CH); // ... and 4 x 256 words of stage_v (TWO_PHASE: all 12 x 256 of stage_k)
+    __shared__ __attribute__((aligned(16))) uint32_t stage_k[SK], stage_v[SV];
+    static_assert(!TWO_PHASE || CH >= 12 * NB, "TWO_PHASE borrows 12 x 256 words of stage_k");
     static_assert(!TWO_PHASE || (!IDENTITY_VALUES && !CENSUS), "TWO_PHASE is the instance sort's flavour");
     uint32_t *const xtotal = TWO_PHASE ? stage_k + 8 * NB : stage_v; // where the four waves' partial digit totals meet
     __shared__ uint32_t wcnt[4][NB]; // per-wave digit counts, then the chunk-local start of the (wave, digit) run
@@ -543,7 +545,7 @@ __device__ __forceinline__ void rs_scatter_body(const uint32_t *__restrict__ kin
             if (i < mine) val[b] = vin_w[i];
         }
         __syncthreads();
-        uint32_t dpack[KB / 4]; // the digits of the KB positions this thread writes out, for the values' turn
+        uint32_t dpack[KB / 4 > 0 ? KB / 4 : 1]; // the digits of the KB positions this thread writes out, for the values' turn
 #pragma unroll
         for (int j = 0; j < KB; j++)
         {
@@ -605,41 +607,46 @@ __global__ void __launch_bounds__(256, 5) rs_scatter_two_phase_kernel(const uint
     rs_scatter_body<false, CH, true, false, true>(kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc, acc_clear, DepthCensus{});
 }
 
+// The chunk length is a run-time property of the sort's scratch (ts2d_common.h: 1024 / 2048 / 4096 pairs); every launcher instantiates its kernel
+// for the three of them.  Inside the braces CH is the compile-time length.
+#define TS_WITH_CHUNK(chunk, ...)                                    \
+    switch (chunk)                                                   \
+    {                                                                \
+    case TS_RS_CHUNK_SMALL: { constexpr int CH = TS_RS_CHUNK_SMALL; __VA_ARGS__; } break; \
+    case TS_RS_CHUNK_MID: { constexpr int CH = TS_RS_CHUNK_MID; __VA_ARGS__; } break;     \
+    default: { constexpr int CH = TS_RS_CHUNK; __VA_ARGS__; } break; \
+    }
 void radix_hist(const uint32_t *kin, int64_t n, const unsigned long long *n_dev, int shift, int nbits, const RadixScratchView &r, hipStream_t s,
                 const DepthCensus *census = nullptr, const uint32_t *skip_flag = nullptr)
 {
     const dim3 grid((unsigned)r.chunks);
     const uint32_t mask = (1u << nbits) - 1u;
-    const bool small = r.chunk == TS_RS_CHUNK_SMALL;
-    if (census && small) hipLaunchKernelGGL((rs_hist_kernel<true, TS_RS_CHUNK_SMALL>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, *census, skip_flag);
-    else if (census) hipLaunchKernelGGL((rs_hist_kernel<true, TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, *census, skip_flag);
-    else if (small) hipLaunchKernelGGL((rs_hist_kernel<false, TS_RS_CHUNK_SMALL>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, DepthCensus{}, skip_flag);
-    else hipLaunchKernelGGL((rs_hist_kernel<false, TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, DepthCensus{}, skip_flag);
+    TS_WITH_CHUNK(r.chunk,
+                  if (census) hipLaunchKernelGGL((rs_hist_kernel<true, CH>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, *census, skip_flag);
+                  else hipLaunchKernelGGL((rs_hist_kernel<false, CH>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, DepthCensus{}, skip_flag))
+}
+template <int CH>
+void radix_scatter_ch(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
+                      int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag, const uint32_t *acc, uint32_t *acc_clear)
+{
+    const dim3 grid((unsigned)r.chunks);
+#define TS_SCATTER(ID, D) hipLaunchKernelGGL((rs_scatter_kernel<ID, CH, D>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc, acc_clear)
+    if (acc && vin)
+    {
+        if constexpr (CH == TS_RS_CHUNK) // the instance sort of large scenes: keys and values through one staging array (rs_scatter_body)
+            hipLaunchKernelGGL((rs_scatter_two_phase_kernel<CH>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc, acc_clear);
+        else TS_SCATTER(false, true);
+    }
+    else if (acc) TS_SCATTER(true, true);
+    else if (vin) TS_SCATTER(false, false);
+    else TS_SCATTER(true, false);
+#undef TS_SCATTER
 }
 void radix_scatter(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
                    int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag = nullptr, const uint32_t *acc = nullptr,
                    uint32_t *acc_clear = nullptr)
 {
-    const dim3 grid((unsigned)r.chunks);
-    const bool small = r.chunk == TS_RS_CHUNK_SMALL;
-#define TS_SCATTER(ID, C, D) hipLaunchKernelGGL((rs_scatter_kernel<ID, C, D>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc, acc_clear)
-    if (acc && vin)
-    {
-        if (small) TS_SCATTER(false, TS_RS_CHUNK_SMALL, true);
-        else
-            hipLaunchKernelGGL((rs_scatter_two_phase_kernel<TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, vin, kout, vout, n, n_dev, shift, nbits, r, skip_flag, acc,
-                               acc_clear);
-    }
-    else if (acc)
-    {
-        if (small) TS_SCATTER(true, TS_RS_CHUNK_SMALL, true);
-        else TS_SCATTER(true, TS_RS_CHUNK, true);
-    }
-    else if (vin && small) TS_SCATTER(false, TS_RS_CHUNK_SMALL, false);
-    else if (vin) TS_SCATTER(false, TS_RS_CHUNK, false);
-    else if (small) TS_SCATTER(true, TS_RS_CHUNK_SMALL, false);
-    else TS_SCATTER(true, TS_RS_CHUNK, false);
-#undef TS_SCATTER
+    TS_WITH_CHUNK(r.chunk, radix_scatter_ch<CH>(kin, vin, kout, vout, n, n_dev, shift, nbits, r, s, skip_flag, acc, acc_clear))
 }
 void radix_pass(const uint32_t *kin, const uint32_t *vin, uint32_t *kout, uint32_t *vout, int64_t n, const unsigned long long *n_dev, int shift,
                 int nbits, const RadixScratchView &r, hipStream_t s, const uint32_t *skip_flag = nullptr)
@@ -661,9 +668,7 @@ void radix_pass_direct(const uint32_t *kin, const uint32_t *vin, uint32_t *kout,
 {
     const dim3 grid((unsigned)r.chunks);
     const uint32_t mask = (1u << nbits) - 1u;
-    if (r.chunk == TS_RS_CHUNK_SMALL)
-        hipLaunchKernelGGL((rs_hist_direct_kernel<TS_RS_CHUNK_SMALL>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, r.slabacc[which], skip_flag);
-    else hipLaunchKernelGGL((rs_hist_direct_kernel<TS_RS_CHUNK>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, r.slabacc[which], skip_flag);
+    TS_WITH_CHUNK(r.chunk, hipLaunchKernelGGL((rs_hist_direct_kernel<CH>), grid, dim3(256), 0, s, kin, n, n_dev, shift, mask, r, r.slabacc[which], skip_flag))
     radix_scatter(kin, vin, kout, vout, n, n_dev, shift, nbits, r, s, skip_flag, r.slabacc[which], r.slabacc[which ^ 1]);
 }
 
@@ -1149,18 +1154,10 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
     const uint32_t *keys = (const uint32_t *)g.depth;
     const unsigned long long *no_count = nullptr;
     const uint32_t *no_vals = nullptr, *no_skip = nullptr;
-    if (g.rs.chunk == TS_RS_CHUNK_SMALL)
-    {
-        hipLaunchKernelGGL((rs_hist_census_direct_kernel<TS_RS_CHUNK_SMALL>), grid, dim3(256), 0, s, keys, (int64_t)P, 0xFFu, g.rs, g.rs.slabacc[0], c);
-        hipLaunchKernelGGL((rs_scatter_kernel<true, TS_RS_CHUNK_SMALL, true, true>), grid, dim3(256), 0, s, keys, no_vals, g.sk[0], g.sv[0], (int64_t)P, no_count,
-                           0, 8, g.rs, no_skip, (const uint32_t *)g.rs.slabacc[0], g.rs.slabacc[1], c);
-    }
-    else
-    {
-        hipLaunchKernelGGL((rs_hist_census_direct_kernel<TS_RS_CHUNK>), grid, dim3(256), 0, s, keys, (int64_t)P, 0xFFu, g.rs, g.rs.slabacc[0], c);
-        hipLaunchKernelGGL((rs_scatter_kernel<true, TS_RS_CHUNK, true, true>), grid, dim3(256), 0, s, keys, no_vals, g.sk[0], g.sv[0], (int64_t)P, no_count, 0, 8,
-                           g.rs, no_skip, (const uint32_t *)g.rs.slabacc[0], g.rs.slabacc[1], c);
-    }
+    TS_WITH_CHUNK(g.rs.chunk,
+                  hipLaunchKernelGGL((rs_hist_census_direct_kernel<CH>), grid, dim3(256), 0, s, keys, (int64_t)P, 0xFFu, g.rs, g.rs.slabacc[0], c);
+                  hipLaunchKernelGGL((rs_scatter_kernel<true, CH, true, true>), grid, dim3(256), 0, s, keys, no_vals, g.sk[0], g.sv[0], (int64_t)P, no_count, 0, 8,
+                                     g.rs, no_skip, (const uint32_t *)g.rs.slabacc[0], g.rs.slabacc[1], c))
 }
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
@@ -1222,7 +1219,7 @@ void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const Bin
 }
 
 // ---- the same sort for other callers (knn.hip: 30-bit Morton codes) --------------------------------------------------------
-static int generic_chunk(size_t n) { return n <= (size_t)2500000 ? TS_RS_CHUNK_SMALL : TS_RS_CHUNK; } // few keys: more, shorter workgroups
+static int generic_chunk(size_t n) { return ts_instance_chunk(n); } // few keys: more, shorter workgroups
 size_t ts_radix_scratch_bytes(size_t n)
 {
     RadixScratchView r{};

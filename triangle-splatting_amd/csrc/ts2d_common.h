@@ -37,12 +37,21 @@
 
 // Scratch of one stable LSD radix pass over n (key, value) pairs (binning.hip): per-chunk digit counts, their per-slab
 // and per-digit prefixes.  One chunk = consecutive pairs handled by one workgroup; one slab = 64 chunks.  The chunk length is a property
-// of the sort: 4096 pairs for the instance sort (millions of pairs: longer digit runs = better coalesced scatter stores), 2048 for the
-// per-triangle depth sort (1 M keys are only 245 workgroups of 4096 -- one per CU; measured 0.103 vs 0.113 ms, profiles/r03_notes.md).
+// of the sort, picked from its size: 4096 pairs for instance lists of millions (longer digit runs = better coalesced scatter stores; keys and
+// values through one staging array), 1024 for everything up to 2.5 M pairs -- such a sort is a few hundred to a few thousand workgroups that
+// are all resident at once, and each launch lasts as long as ONE workgroup's chain of ranking steps (16 / 8 / 4 per lane at 4096 / 2048 /
+// 1024): depth sort of 1 M keys 45 -> 40 us against 2048 (round 3: 2048 against 4096 0.103 vs 0.113 ms), of 93 k keys 36 -> 33, tile sort of
+// 1 M instances 35 -> 31 (profiles/r05_small_chunks_ab.txt) -- and 2048 for depth sorts beyond that (5 M triangles: 39 slabs, still ticket-free).
 #ifndef TS_RS_CHUNK
 #define TS_RS_CHUNK 4096
 #endif
-#define TS_RS_CHUNK_SMALL 2048
+#define TS_RS_CHUNK_MID 2048
+#define TS_RS_CHUNK_SMALL 1024
+#define TS_RS_SMALL_BELOW 2500000 /* pairs */
+// Chunk length of the instance sort, from the CAPACITY of the binning state (so that the forward and the backward, which both carve from the
+// buffer's size, agree); the tables are sized for the shortest chunks at every capacity, so that bytes(capacity) grows with the capacity.
+static inline int ts_instance_chunk(size_t n) { return n <= (size_t)TS_RS_SMALL_BELOW ? TS_RS_CHUNK_SMALL : TS_RS_CHUNK; }
+static inline int ts_depth_chunk(size_t n) { return n <= (size_t)TS_RS_SMALL_BELOW ? TS_RS_CHUNK_SMALL : TS_RS_CHUNK_MID; }
 #define TS_RS_BINS 256
 #define TS_RS_TICKET_EXTRA 8 /* words behind the per-slab tickets; [slabs + 4] = the depth sort's top_const flag.  (The census of the depth sort's
                                 first histogram needs no words here: its per-chunk sums / key-bit ORs / ANDs borrow g.blocksum, g.tiles_sorted and
@@ -56,7 +65,7 @@ struct RadixScratchView
     uint32_t *slabacc[2]; // slabs x 256 each: per-slab digit totals of the ticket-free passes (binning.hip, rs_hist_direct_kernel), accumulated
                           // with atomics; pass p uses [p & 1], and whoever runs before it has cleared that buffer
     int chunks, slabs;
-    int chunk; // pairs per chunk: TS_RS_CHUNK or TS_RS_CHUNK_SMALL
+    int chunk; // pairs per chunk: TS_RS_CHUNK, TS_RS_CHUNK_MID or TS_RS_CHUNK_SMALL
 };
 
 struct GeometryStateView
@@ -141,7 +150,7 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.offsets, n);
     ts_carve(p, v.blocksum, (n + 1023) / 1024 + 2);
     ts_carve(p, v.supersum, ((n + 1023) / 1024 + 63) / 64 + 1);
-    ts_carve_radix(p, n, v.rs, TS_RS_CHUNK_SMALL);
+    ts_carve_radix(p, n, v.rs, ts_depth_chunk(n));
     v.top_const = v.rs.tickets + v.rs.slabs + 4;
     return (size_t)(p - base) + TS_ALIGN;
 }
@@ -158,15 +167,6 @@ static inline int ts_higher_msb(uint32_t n) // R2D/src/rasterizer.cu:20-35 (same
     if (n >> msb) msb++;
     return (int)msb;
 }
-
-// Chunk length of the instance sort, from the CAPACITY of the binning state (so that the forward and the backward, which both carve from the
-// buffer's size, agree): lists of up to TS_INSTANCE_SMALL_BELOW instances are a few hundred workgroups of 4096 -- all resident at once, the launch
-// lasts as long as ONE workgroup's chain of 16 ranking steps per lane; 2048-pair chunks halve that chain (tile sort 40 -> 28 us at 44 k instances, 50 -> 35 at 1 M, 54 -> 43 at 1.4 M;
-// equal at the headline's 4.6 M: profiles/r05_instance_chunk_ab.txt).
-#ifndef TS_INSTANCE_SMALL_BELOW
-#define TS_INSTANCE_SMALL_BELOW 2500000
-#endif
-static inline int ts_instance_chunk(size_t n) { return n <= (size_t)TS_INSTANCE_SMALL_BELOW ? TS_RS_CHUNK_SMALL : TS_RS_CHUNK; }
 
 // Key bits of the instance sort: the tile ids are 0 .. ntiles - 1.  (The reference sorts 32 + getHigherMsb(ntiles) bits, rasterizer.cu:211-222 -- one
 // more than needed when ntiles is a power of two, e.g. 9 for the 256 tiles of a 256 x 256 image: here that is one 8-bit pass instead of two.)
