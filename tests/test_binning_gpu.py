@@ -81,10 +81,10 @@ def test_instance_offsets_match_rocprim_scan(P, W, H):
     assert np.array_equal(ranges[:, 1] - ranges[:, 0], np.bincount(keys >> 32, minlength=ranges.shape[0]))
 
 
-@pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 1024, 1025, 4097, 10_000, 16_383, 16_384, 16_385, 20_000])
+@pytest.mark.parametrize("P", [1, 63, 64, 65, 1000, 1024, 1025, 4097, 10_000, 12_287, 12_288, 12_289, 20_000])
 @pytest.mark.parametrize("spread", [False, True])
 def test_depth_order_of_small_scenes_is_the_stable_sort(P, spread):
-    """Up to 16 384 triangles ONE launch orders the triangles (binning.hip: depth_order_small_kernel -- one workgroup, the pairs in registers, LDS
+    """Up to 12 288 triangles ONE launch orders the triangles (binning.hip: depth_order_small_kernel -- one workgroup, the pairs in registers, LDS
     between the passes) and leaves what the census and the block-sum launch leave at larger sizes; above, the multi-launch sort.  Either way:
     ids in (depth bits, id) order = numpy's stable argsort of the keys (culled triangles carry key 0), offsets = the running sum of the tile
     counts in that order, N = its last value.  `spread`: depths over a factor > 4, so the top key byte varies and the fourth pass runs."""

@@ -973,7 +973,7 @@ __global__ void zero_words_kernel(uint32_t *p, int n)
 // them through LDS after every pass, and then does what the census, publish_census and gather_blocksum_kernel do: N to the device word and
 // the pinned host word, tiles_sorted, the raw block sums.  Same passes (the fourth skipped under the same condition), same stable order,
 // so sv[1] holds exactly the ids the multi-launch path leaves in sorted_ids(); top_const stays 0 (the order is always in sk[1] / sv[1]).
-constexpr int TS_DEPTH_SMALL_MAX = 16384;
+constexpr int TS_DEPTH_SMALL_MAX = 12288; // level with the multi-launch path (1024-pair chunks) at ~12 k triangles: 34 us either way
 constexpr int DS_WAVES = 16, DS_KB = TS_DEPTH_SMALL_MAX / (64 * DS_WAVES);
 __global__ void __launch_bounds__(64 * DS_WAVES) depth_order_small_kernel(int P, GeometryStateView g, unsigned long long *host_out)
 {
