@@ -936,28 +936,42 @@ int P, int grid_x, int ntiles, GeometryStateView g, BinningStateView b, uint2 *r
     }
 }
 
+// Four consecutive instances per thread (one dwordx4 + the word in front): a quarter of the workgroups and of the loads of the one-key-per-thread
+// form (10.4 -> 7.6 us at the headline, 38.9 -> 19.1 us at 5 M triangles: profiles/r05_notes.md section 12).  `tile` is 16-byte aligned (ts_carve); words past N are never looked at.
 __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t N, const unsigned long long *n_dev, const uint32_t *__restrict__ tile,
                                                            uint2 *__restrict__ ranges)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (n_dev)
     {
         const unsigned long long live = *n_dev;
         N = (live <= (unsigned long long)N) ? (int64_t)live : 0;
     }
-    if (i >= N) return;
-    const uint32_t cur = tile[i];
-    if (i == 0) ranges[cur].x = 0;
-    else
+    if (i0 >= N) return;
+    uint32_t k[4];
+    if (i0 + 3 < N)
     {
-        const uint32_t prev = tile[i - 1];
-        if (cur != prev)
+        const uint4 q = *(const uint4 *)(tile + i0);
+        k[0] = q.x; k[1] = q.y; k[2] = q.z; k[3] = q.w;
+    }
+    else
+        for (int j = 0; j < 4; j++) k[j] = i0 + j < N ? tile[i0 + j] : 0u;
+    uint32_t prev = i0 > 0 ? tile[i0 - 1] : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+        const int64_t i = i0 + j;
+        if (i >= N) break;
+        const uint32_t cur = k[j];
+        if (i == 0) ranges[cur].x = 0;
+        else if (cur != prev)
         {
             ranges[prev].y = (uint32_t)i;
             ranges[cur].x = (uint32_t)i;
         }
+        if (i == N - 1) ranges[cur].y = (uint32_t)N;
+        prev = cur;
     }
-    if (i == N - 1) ranges[cur].y = (uint32_t)N;
 }
 
 __global__ void zero_words_kernel(uint32_t *p, int n)
@@ -1215,7 +1229,7 @@ void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long lon
 void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s)
 {
     if (N <= 0) return;
-    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, N, n_dev, b.tile, im.ranges);
+    hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((N + 1023) / 1024)), dim3(256), 0, s, N, n_dev, b.tile, im.ranges);
 }
 
 // ---- the same sort for other callers (knn.hip: 30-bit Morton codes) --------------------------------------------------------
