@@ -282,10 +282,20 @@ __global__ void __launch_bounds__(256) rs_hist_direct_kernel(const uint32_t *__r
     __syncthreads();
     const int64_t base = (int64_t)chunk * CH;
 #pragma unroll
-    for (int b = 0; b < CH / 256; b++)
+    for (int b = 0; b < CH / 1024; b++) // one dwordx4 per thread and round (the counts do not care about the order inside the chunk)
     {
-        const int64_t i = base + 256 * b + t;
-        if (i < n) atomicAdd(&bins[(keys[i] >> shift) & mask], 1u);
+        const int64_t i = base + 1024 * b + 4 * t;
+        if (i + 3 < n)
+        {
+            const uint4 q = *(const uint4 *)(keys + i);
+            atomicAdd(&bins[(q.x >> shift) & mask], 1u);
+            atomicAdd(&bins[(q.y >> shift) & mask], 1u);
+            atomicAdd(&bins[(q.z >> shift) & mask], 1u);
+            atomicAdd(&bins[(q.w >> shift) & mask], 1u);
+        }
+        else
+            for (int k = 0; k < 4; k++)
+                if (i + k < n) atomicAdd(&bins[(keys[i + k] >> shift) & mask], 1u);
     }
     __syncthreads();
     const uint32_t c = bins[t];
@@ -468,15 +478,21 @@ __device__ __forceinline__ void rs_scatter_body(const uint32_t *__restrict__ kin
     {
         const bool valid = 64 * b + lane < mine;
         const uint32_t d = (key[b] >> shift) & mask;
-        unsigned long long m = ballot64(valid);
+        // lanes whose digit differs from mine in some bit: (ballot of bit i) xor (my bit i, sign-extended), or-ed over the bits, in two 32-bit
+        // halves -- three instructions per bit and half (round 5; the select form `m &= one ? bb : ~bb` compiled to ~100 instructions per step,
+        // and a launch of a few resident workgroups per SIMD spends a good part of its time issuing exactly these)
+        const unsigned long long vm = ballot64(valid);
+        uint32_t mis_lo = ~(uint32_t)vm, mis_hi = ~(uint32_t)(vm >> 32);
         for (int bit = 0; bit < nbits; bit++)
         {
-            const bool one = (d >> bit) & 1u;
-            const unsigned long long bb = ballot64(one);
-            m &= one ? bb : ~bb;
+            const unsigned long long bb = ballot64((d >> bit) & 1u);
+            const uint32_t e = 0u - ((d >> bit) & 1u); // all ones when my bit is set
+            mis_lo |= (uint32_t)bb ^ e;
+            mis_hi |= (uint32_t)(bb >> 32) ^ e;
         }
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        const uint32_t c = (uint32_t)__popcll(m);
+        const uint32_t m_lo = ~mis_lo, m_hi = ~mis_hi; // the valid lanes that hold my digit
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        const uint32_t c = (uint32_t)(__popc(m_lo) + __popc(m_hi));
         uint32_t seen = 0;
         if (valid) seen = cnt[d];
         wave_lds_order(); // every lane has read its digit's count before the group leaders advance it
