@@ -244,3 +244,25 @@ def test_ctypes_structures_match_the_c_headers(tmp_path, hip_lib_built):
         body = re.search(r"typedef struct " + cname + r"\s*\{(.*?)\}\s*" + cname + r"\s*;", text, flags=re.S).group(1)
         declared = [n for stmt in body.split(";") for n in re.findall(r"\**\s*([A-Za-z_]\w*)\s*(?:,|$)", stmt.strip().split(None, 1)[-1] if stmt.strip() else "")]
         assert len(declared) == len(mirror._fields_), (cname, declared, [f for f, _ in mirror._fields_])
+
+
+def test_binning_state_bytes_grow_with_the_capacity_and_invert(lib):
+    """The forward and the backward both carve the binning state from the BUFFER'S SIZE (ts2d_binning_capacity inverts ts2d_binning_state_bytes by
+    bisection), so the bytes must never shrink when the capacity grows -- also across the capacities at which the instance sort changes its chunk
+    length (csrc/ts2d_common.h: ts_instance_chunk; the tables are sized for the shortest chunks at every capacity for exactly this reason)."""
+    lib.ts2d_binning_state_bytes.restype = ctypes.c_size_t
+    lib.ts2d_binning_state_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32, ctypes.c_int32]
+    lib.ts2d_binning_capacity.restype = ctypes.c_int64
+    lib.ts2d_binning_capacity.argtypes = [ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32]
+    for W, H in ((1920, 1080), (256, 256), (37, 5)):
+        caps = sorted(set(list(range(0, 70000, 997)) + list(range(2_499_000, 2_501_001, 125)) + [1 << k for k in range(4, 27)] +
+                          [(1 << k) + 1 for k in range(4, 27)] + [4_610_000, 12_600_000, 23_000_000]))
+        prev = -1
+        for n in caps:
+            b = lib.ts2d_binning_state_bytes(n, W, H)
+            assert b >= 16 * n and b >= prev, (n, b, prev)
+            prev = b
+        for n in (0, 1, 1023, 1024, 1025, 65_537, 2_499_999, 2_500_000, 2_500_001, 4_610_000):
+            b = lib.ts2d_binning_state_bytes(n, W, H)
+            cap = lib.ts2d_binning_capacity(b, W, H)
+            assert cap >= n and lib.ts2d_binning_state_bytes(cap, W, H) <= b, (n, b, cap)  # the largest capacity whose carving fits the buffer
