@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- fwd+bwd throughput of the MI355X triangle rasterizer on BASELINE.json's headline workload.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]            # N > 1: spawns the N ranks itself (ensure_world below)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                 # the driver's form; WORLD_SIZE != --gpus is refused (exit code 2)
 
 One "step" = one forward + one backward of the rasterizer over one view of the synthetic scene
 S(P=1M, 1920x1080, SH degree 3, rich_info=True) (SURVEY.md 8d / BASELINE.md 4), through the drop-in Python
@@ -106,9 +106,11 @@ def main():
                          "application of the gradients -- NOT north_star's semantics); default: synchronous, step i's reduced gradients are waited "
                          "for before step i+1's forward is queued")
     ap.add_argument("--sync-exchange", action="store_true", help="(default since round 4; kept for old command lines)")
-    ap.add_argument("--exchange-compare", action="store_true",
-                    help="N > 1: after the timed region, time K more steps in the OTHER exchange mode and report its exposed_ms_per_step and "
-                         "ms_per_step beside the headline mode's (config.exchange.other_mode)")
+    ap.add_argument("--exchange-compare", action="store_true", help="(default for N > 1 since round 6; kept for old command lines)")
+    ap.add_argument("--no-exchange-compare", action="store_true",
+                    help="N > 1: by default K more steps are timed in the OTHER exchange mode behind the timed region and reported beside the headline "
+                         "mode's figures (config.exchange.other_mode: ms_per_step, exposed_ms_per_step) -- one multi-GPU lease yields both exposure "
+                         "figures; this switches that leg off.  The headline `value` is never affected: the leg runs after the timed region")
     ap.add_argument("--with-optimizer", action="store_true",
                     help="NOT the headline metric: every step also runs the fused Adam step (diff_recon_hip.FusedAdam: vertex, opacity and the SH tensor "
                          "with the reference's f_dc / f_rest learning-rate split, one launch) on the step's gradients, with all learning rates 0 so that "
@@ -139,13 +141,18 @@ def main():
                          "(torch.cuda.CUDAGraph on the rasterizer's launches; the sync-free forward has no host read to break the capture) and the "
                          "timed steps are graph replays -- what a training loop with a fixed triangle count between densifications can do.  Host "
                          "cost per step = one graph launch; implies --sync-free, N = 1")
+    ap.add_argument("--rendezvous-check", action="store_true",
+                    help="NOT a measurement: after the ranks have been created (see ensure_world) every rank joins the process group, the ranks "
+                         "all-gather their (rank, pid) and rank 0 prints them as one JSON line -- what tests/test_bench_launch_cpu.py runs over gloo "
+                         "to pin that `--gpus N` alone produces N ranks; needs no HIP device")
     args = ap.parse_args()
     if args.hip_graph:
         args.sync_free = True
+    args.exchange_compare = args.gpus > 1 and not args.no_exchange_compare
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = ensure_world(args)
+    if args.rendezvous_check:
+        return rendezvous_check(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the rasterizer has no CPU fallback)")
     # TS2D_BENCH_BACKEND=gloo is a functional check of the N > 1 code path on a box with fewer GPUs than ranks (ranks
@@ -431,7 +438,11 @@ def main():
                                           f"all rows, in {args.range_exchange} triangle ranges behind the ranged backward" if args.range_exchange > 1 else "all rows (dense)"),
                                  "visible_fraction": (round(state.get("visible_rows", 0) / max(P, 1), 4) if vis_rows is not None else None),
                                  "bucket_bytes_per_rank_and_step": (buckets[0].last_exchanged_bytes if buckets and hasattr(buckets[0], "last_exchanged_bytes") else None),
+                                 "wire_bytes_per_rank_and_step": wire_bytes(world, buckets[0].last_exchanged_bytes if buckets and hasattr(buckets[0], "last_exchanged_bytes") else 0,
+                                                                            P * 12 * (state.get("visible_rows", P) / max(P, 1) if vis_rows is not None else 1.0) if factored else 0,
+                                                                            exposed_ms if not overlap else None),
                                  "other_mode": other, "process_groups": 2} if world > 1 else None),
+                   "distributed": backend_info(backend, world),
                    # spread of the host-side time per queued step: a stalled host (allocator growth, garbage collection, a descheduled thread)
                    # shows up here as a maximum far above the median, and in `value` (the contract times all K steps, stalls included)
                    "settle_steps_untimed": settle_steps,
@@ -486,6 +497,82 @@ def main():
                 result["reference_gpu"] = ref
                 result["reference_gpu"]["speedup"] = round(result["value"] / ref["value"], 2)
         print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def ensure_world(args):
+    """`--gpus N` IS the number of ranks.  Three cases:
+      * WORLD_SIZE set (the driver's `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`): it must equal --gpus, anything else
+        is a launch error -- exit code 2, nothing is measured (a line that said "n_gpus": 1 for a command that asked for 8 would be worse than none);
+      * WORLD_SIZE unset and --gpus 1: this process is the one rank;
+      * WORLD_SIZE unset and --gpus N > 1 (the N = 1 command with the number changed): this process becomes the LAUNCHER -- it re-executes the
+        same command line under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1, a free port), forwards the children's
+        output and exit code, and never touches a device itself.
+    Returns (rank, local_rank, world) in a process that is a rank."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={env_world}: launch one rank per GPU "
+                             f"(python bench.py --gpus N spawns them itself; under torch.distributed.run use --nproc-per-node == --gpus)\n")
+            raise SystemExit(2)
+        return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(env_world)
+    if args.gpus <= 1:
+        if args.gpus < 1:
+            raise SystemExit("--gpus must be >= 1")
+        return 0, 0, 1
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free port for the rendezvous (the driver passes its own through torchrun)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def wire_bytes(world, bucket_bytes, sh_factor_bytes, exposed_ms):
+    """What one rank must SEND per step for the exchange it was handed (the figure a link-level counter would be compared with): reduce-scatter +
+    all-gather of the bucket = 2 (N - 1) / N of its bytes, the all-gather of the colour factors = (N - 1) x this rank's factors; and, in the
+    synchronous mode (the whole exchange is exposed), the bus rate that the exposed time implies.  xGMI: 7 links x ~153 GB/s per GPU."""
+    if world <= 1:
+        return None
+    bucket = 2.0 * (world - 1) / world * bucket_bytes
+    sh = (world - 1) * sh_factor_bytes
+    out = {"bucket_rs_ag": int(bucket), "sh_factors_all_gather": int(sh), "total": int(bucket + sh),
+           "expected_ms_at_7x153_GBs_all_links": round((bucket + sh) / (7 * 153e9) * 1e3, 4),
+           "expected_ms_ring_one_link_153_GBs": round((bucket + sh) / 153e9 * 1e3, 4)}
+    if exposed_ms:
+        out["implied_bus_GBs_from_exposed_ms"] = round((bucket + sh) / (exposed_ms * 1e-3) / 1e9, 2)
+    return out
+
+
+def backend_info(backend, world):
+    """What the exchange ran on, for the JSON line: torch.distributed's backend name and, over RCCL, the library's version."""
+    info = {"world": world, "backend": (dist.get_backend() if world > 1 else None), "requested": backend if world > 1 else None}
+    if world > 1 and backend == "nccl":
+        try:
+            info["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            info["rccl_version"] = None
+    return info
+
+
+def rendezvous_check(rank, world):
+    """--rendezvous-check: every rank reports (rank, pid); rank 0 prints what it gathered.  gloo unless TS2D_BENCH_BACKEND says otherwise, no device."""
+    backend = os.environ.get("TS2D_BENCH_BACKEND", "gloo")
+    seen = [(rank, os.getpid())]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        seen = [None] * world
+        dist.all_gather_object(seen, (rank, os.getpid()))
+    if rank == 0:
+        print(json.dumps({"rendezvous_check": True, "n_gpus": world, "ranks": sorted(r for r, _ in seen), "distinct_processes": len({p for _, p in seen}),
+                          "distributed": backend_info(backend, world)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -21,6 +21,36 @@ if FORCE_TICKETS:
     _C._lib.ts2d_lab_force_ticket_passes(1)
 
 out = []
+if os.environ.get("LAB_DEPTH_ORDER") == "1":
+    # the one-launch depth order of small scenes (binning.hip: depth_order_small_kernel) has its own census, its own fourth-pass rule and
+    # its own block sums.  Same scene through the three forms -- one launch (the product's path up to 12 288 triangles), the multi-launch ticket-free
+    # passes (reached through ts2d_lab_force_depth_pass4) and the hierarchical ticket passes (ts2d_lab_force_ticket_passes): the depth permutation,
+    # the instance offsets (= block sums + scan), the instance count and the sorted instance list must be IDENTICAL.
+    from diff_triangle_rasterization_2D import _C
+    _C._lib.ts2d_lab_force_depth_pass4.argtypes = [__import__("ctypes").c_int]
+    for P, culled in [(1, False), (63, False), (64, False), (65, False), (1023, False), (12287, False), (12288, False), (12289, False), (700, True), (12288, True)]:
+        s = synthetic.scene(P, 160, 96, 1, seed=500 + P)
+        if culled:
+            s["vertex"][:, :, 2] += 5000.0  # every triangle behind the camera: all culled, zero instances
+        got = {}
+        for form, (tick, p4) in {"one_launch": (0, 0), "multi_launch": (0, 1), "tickets": (1, 0)}.items():
+            _C._lib.ts2d_lab_force_ticket_passes(tick)
+            _C._lib.ts2d_lab_force_depth_pass4(p4)
+            hf = helpers.hip_forward_backward(s, True, backward=False)
+            got[form] = (int(hf["num_rendered"]), helpers.hip_state(hf, s, "depth_perm").copy(), helpers.hip_state(hf, s, "point_offsets").copy(),
+                         helpers.hip_state(hf, s, "vals").copy() if hf["num_rendered"] > 0 else np.zeros(0, np.int32), hf["out_feature"].copy())
+        _C._lib.ts2d_lab_force_ticket_passes(0)
+        _C._lib.ts2d_lab_force_depth_pass4(0)
+        a = got["one_launch"]
+        e = {"P": P, "culled": culled, "num_rendered": a[0]}
+        for form in ("multi_launch", "tickets"):
+            b = got[form]
+            # the permutation of CULLED triangles (depth key 0, no instances) is stable in every form too: plain equality
+            e[form] = float(a[0] != b[0] or not np.array_equal(a[1], b[1]) or not np.array_equal(a[2], b[2]) or not np.array_equal(a[3], b[3])
+                            or not np.array_equal(a[4], b[4]))
+        out.append(e)
+    print("LAB_RESULT " + json.dumps(out))
+    sys.exit(0)
 if FORCE_TICKETS:
     for near in (False, True):  # False: every depth shares its top key byte (4th depth pass skipped); True: it varies
         s = synthetic.scene(20000, 200, 120, 2, seed=91)

@@ -252,3 +252,28 @@ def test_rccl_reduce_scatter_all_gather_branch_runs_on_one_gpu():
     assert p.exitcode == 0
     ok, errs = q.get(timeout=10)
     assert ok, errs
+
+
+def test_bench_gpus_2_spawns_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` -- the N = 1 command with the number changed, NO torchrun in front -- must run two ranks and say
+    so.  Two processes share this box's one GPU over gloo (TS2D_BENCH_BACKEND: a functional run, its timings mean nothing); the line must carry
+    n_gpus == 2, the backend, both exchange modes (the comparison leg is the default for N > 1 since round 6) and the bytes a rank puts on the wire."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(TS2D_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--triangles", "20000", "--width", "320", "--height", "240",
+                        "--steps", "3", "--warmup", "1", "--settle-steps", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["distributed"] == {"world": 2, "backend": "gloo", "requested": "gloo"}
+    ex = line["config"]["exchange"]
+    assert ex["mode"].startswith("synchronous") and ex["other_mode"]["mode"] == "delayed" and ex["other_mode"]["ms_per_step"] > 0
+    wire = ex["wire_bytes_per_rank_and_step"]
+    assert wire["bucket_rs_ag"] == ex["bucket_bytes_per_rank_and_step"] and wire["sh_factors_all_gather"] == 20000 * 12  # 2 (N-1)/N = 1, (N-1) = 1
+    # and the mismatch: a world that contradicts --gpus is refused before anything is measured
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "WORLD_SIZE" in r.stderr

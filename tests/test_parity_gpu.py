@@ -264,6 +264,27 @@ def test_forced_ticket_passes_match_oracle():
             assert v < (1.0 if k.startswith("int_") else GRAD_TOL if k.startswith("dL_") else IMG_TOL), (k, v)
 
 
+def test_one_launch_depth_order_equals_the_multi_launch_forms():
+    """up to 12 288 triangles ONE launch (binning.hip: depth_order_small_kernel) replaces the depth sort's eight launches and the block-sum
+    launch, with its own census and its own rule for the skipped fourth pass.  P = 1, 63, 64, 65, 1023, 12 287, 12 288 (the limit), 12 289 (first scene
+    past it) and two all-culled scenes through the one-launch form, the ticket-free multi-launch passes and the hierarchical ticket passes (lab
+    switches, tests/lab_worker.py): depth permutation, instance offsets, num_rendered, the sorted instance list and the image are identical."""
+    import json
+    import subprocess
+    import sys
+    if not os.path.exists(LAB_LIB):
+        pytest.skip("tools/bin/libts2d_lab.so not built")
+    e = dict(os.environ, TS2D_LIBRARY_PATH=LAB_LIB, LAB_DEPTH_ORDER="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab_worker.py")], env=e, capture_output=True,
+                       text=True, timeout=400)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("LAB_RESULT ")][-1][len("LAB_RESULT "):])
+    assert len(res) == 10
+    for case in res:
+        assert case["multi_launch"] == 0.0 and case["tickets"] == 0.0, case
+        assert (case["num_rendered"] == 0) == case["culled"], case
+
+
 @pytest.mark.parametrize("P,W,H,D,variant,gamma", [
     (1_000_000, 1920, 1080, 3, 2, 1.0),   # bench.py headline
     (300_000, 800, 800, 3, 2, 1.0),       # BASELINE.json configs[1]

@@ -990,9 +990,9 @@ __global__ void __launch_bounds__(256) tile_ranges_kernel(int64_t N, const unsig
     }
 }
 
-__global__ void zero_words_kernel(uint32_t *p, int n)
+__global__ void zero_words_kernel(uint32_t *p, size_t n) // 64-bit count and index: 16 P words at P near 2^28 pass 2^31
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) p[i] = 0u;
 }
 // ---- small scenes: the whole depth order in ONE launch ------------------------------------------------------------------------------
@@ -1005,6 +1005,13 @@ __global__ void zero_words_kernel(uint32_t *p, int n)
 // so sv[1] holds exactly the ids the multi-launch path leaves in sorted_ids(); top_const stays 0 (the order is always in sk[1] / sv[1]).
 constexpr int TS_DEPTH_SMALL_MAX = 12288; // level with the multi-launch path (1024-pair chunks) at ~12 k triangles: 34 us either way
 constexpr int DS_WAVES = 16, DS_KB = TS_DEPTH_SMALL_MAX / (64 * DS_WAVES);
+// The one-launch form lives on gfx950's 160 KB of LDS per workgroup (two stages of TS_DEPTH_SMALL_MAX words + the per-wave digit table): 64 KB
+// parts cannot hold it, and nothing else in the library may quietly push it over
+#if !defined(__gfx950__) && defined(__HIP_DEVICE_COMPILE__)
+#error "depth_order_small_kernel is sized for gfx950 (160 KB LDS per workgroup)"
+#endif
+static_assert(2 * TS_DEPTH_SMALL_MAX * 4 + DS_WAVES * NB * 4 + DS_WAVES * 8 + (TS_DEPTH_SMALL_MAX / SB) * 8 + 2 * DS_WAVES * 4 + 16 <= 160 * 1024 - 8 * 1024,
+              "depth_order_small_kernel: static LDS must leave 8 KB of the 160 KB for the runtime / alignment");
 __global__ void __launch_bounds__(64 * DS_WAVES) depth_order_small_kernel(int P, GeometryStateView g, unsigned long long *host_out)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stage_k[TS_DEPTH_SMALL_MAX], stage_v[TS_DEPTH_SMALL_MAX];
@@ -1265,9 +1272,9 @@ int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, in
     RadixScratchView r{};
     char *p = (char *)ts_align_up((size_t)scratch);
     ts_carve_radix(p, n, r, generic_chunk(n));
-    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((r.slabs + TS_RS_TICKET_EXTRA + 255) / 256)), dim3(256), 0, s, r.tickets, r.slabs + TS_RS_TICKET_EXTRA);
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((r.slabs + TS_RS_TICKET_EXTRA + 255) / 256)), dim3(256), 0, s, r.tickets, (size_t)(r.slabs + TS_RS_TICKET_EXTRA));
     const bool direct = !force_tickets && radix_direct_ok(r);
-    if (direct) hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)r.slabs), dim3(256), 0, s, r.slabacc[0], r.slabs * NB);
+    if (direct) hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)r.slabs), dim3(256), 0, s, r.slabacc[0], (size_t)(r.slabs * NB));
     const int passes = (end_bit + 7) / 8;
     int src = 0;
     for (int ps = 0; ps < passes; ps++)
@@ -1292,6 +1299,6 @@ void ts_launch_zero_words(uint32_t *p, size_t n, hipStream_t s) // n 32-bit word
 {
     if (n == 0) return;
     if (n % 4 == 0 && ((size_t)p & 15) == 0) hipLaunchKernelGGL(zero_words4_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, (uint4 *)p, n / 4);
-    else hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, (int)n);
+    else hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
 }
 void ts_force_depth_pass4(bool on) { g_force_pass4 = on; }

@@ -216,6 +216,10 @@ class _RasterizeTriangles(torch.autograd.Function):
                     for name, g in captured:
                         if name in nv and g is not None:
                             nv[name].add_(g.view(nv[name].shape))
+                    # the range events of the FIRST backward no longer say "rows final": these add_ kernels follow them on the compute stream.
+                    # reduce_ranges_async() then orders the whole exchange behind the compute stream instead of range by range
+                    if getattr(bucket, "range_events", None):
+                        bucket._ranges_recorded = False
                 # What autograd gets back under a capture: NOTHING for the captured parameter slots -- their gradient lives in the bucket
                 # until bucket.wait() (handing out the bucket's own views would let AccumulateGrad alias `param.grad` to the bucket, and a
                 # second view would then be added twice: once above, once by autograd) -- and a PRIVATE tensor for dL_dcenter2D, which

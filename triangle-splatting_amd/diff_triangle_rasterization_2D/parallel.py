@@ -86,13 +86,19 @@ class VisibleRows:
             raise RuntimeError("VisibleRows.index() before begin()")
         consumer = torch.cuda.current_stream(self._mask.device) if self._stream is not None else None
         if self._idx is None:
-            if self._work is not None:
-                self._work.wait()
-                self._work = None
             if self._stream is not None:
                 with torch.cuda.stream(self._stream):
+                    # Work.wait() on RCCL makes the CURRENT stream wait for the collective and nothing else: it must be called with the side
+                    # stream current, or nonzero() below -- queued on the side stream -- reads this rank's mask before the MAX has landed and
+                    # the ranks size their collectives differently (gloo blocks the host in wait(), which hid it)
+                    if self._work is not None:
+                        self._work.wait()
+                        self._work = None
                     self._idx = torch.nonzero(self._mask).reshape(-1)  # synchronises the SIDE stream only (nonzero reads its count back)
             else:
+                if self._work is not None:
+                    self._work.wait()
+                    self._work = None
                 self._idx = torch.nonzero(self._mask).reshape(-1)
         if consumer is not None:
             consumer.wait_stream(self._stream)  # nonzero's second kernel (the indices) may still be in flight on the side stream
