@@ -73,6 +73,8 @@ def algorithmic_bytes(P, N, W, H, D, ntiles):
     k["depth_sort"] = P * 16 * 4
     k["depth_census"] = P * 8          # first histogram: keys + tile counts (small scenes: the whole depth order in this one launch)
     k["zero_grad_records"] = P * 64
+    k["preprocess_records"] = P * (36 + sh + 4 + 65)  # the record half of the per-triangle kernel (side stream): vertex + SH + opacity in, record + clamp flags out
+    k["preprocess_geometry"] = P * (36 + 20)          # the half the ordering chain waits for: vertex in; radii, tile count, rectangle, depth key out
     k["tile_sort"] = N * 16 * -(-msb_bits(ntiles) // 8)
     return k
 
@@ -119,6 +121,10 @@ def main():
                     help="NOT the headline: the depth sort runs its fourth pass although every depth of the synthetic scene shares the top key byte "
                          "(what a scene spanning more than a factor of four in depth costs).  Needs the lab library: "
                          "TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so (the product library has no switch)")
+    ap.add_argument("--no-side-stream", action="store_true",
+                    help="NOT the headline: the forward as one chain on the caller's stream (the per-triangle kernel as ONE launch, the gradient records "
+                         "cleared behind the scan) instead of forking the library's side stream -- the A/B partner of the product's sequence.  Needs the "
+                         "lab library: TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--timed-kernel-events", default="dominant", choices=["dominant", "all"],
                     help="which kernels are bracketed by HIP events INSIDE the timed region: the dominant one (2 events per step; default) or "
@@ -166,7 +172,7 @@ def main():
         dist.init_process_group(backend, rank=rank, world_size=world, device_id=dev if backend == "nccl" else None)
 
     import synthetic
-    from diff_triangle_rasterization_2D import TriangleRasterizationSettings, TriangleRasterizer, _C
+    from diff_triangle_rasterization_2D import TriangleRasterizationSettings, TriangleRasterizer, _C, center2D_sink
     if args.rasterizer == "3D":
         from diff_triangle_rasterization_3D import TriangleRasterizer
     from diff_triangle_rasterization_2D import parallel
@@ -176,6 +182,10 @@ def main():
         if not hasattr(_C._lib, "ts2d_lab_force_depth_pass4"):
             raise SystemExit("--force-depth-pass4 needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
         _C._lib.ts2d_lab_force_depth_pass4(1)
+    if args.no_side_stream:
+        if not hasattr(_C._lib, "ts2d_lab_no_side_stream"):
+            raise SystemExit("--no-side-stream needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
+        _C._lib.ts2d_lab_no_side_stream(1)
     P, W, H, D = args.triangles, args.width, args.height, args.sh_degree
     s = synthetic.scene(P, W, H, D, seed=42, mode=args.scene_mode, edge_px=args.edge_px)
     # one view per rank: same triangles, camera shifted sideways by a few world units per rank
@@ -240,7 +250,7 @@ def main():
         wait_events.append((e0, e1))
 
     def step():
-        center2D = torch.zeros((P, 2), device=dev, requires_grad=True)  # like triangle_renderer.py:67
+        center2D = center2D_sink(P, dev)  # the caller's gradient sink (triangle_renderer.py:67), as diff_recon_hip.TriangleRenderer makes it: a fresh leaf per step, no fill kernel
         if bucket is not None:
             # N > 1: the backward kernels write dL_dvertex / dL_dopacity (and, with --dense-exchange, dL_dshs)
             # straight into the exchange bucket; its reduce-scatter + all-gather starts on a side stream as soon as the backward
@@ -475,8 +485,13 @@ def main():
             result["kernels_avg_ms"] = {k: round(v, 4) for k, v in kernels.items()}  # ten steps right behind the timed region
             if world == 1:
                 busy = sum(kernels.values())
+                # what runs on the library's side stream BESIDE the depth sort (csrc/api.hip: SideLane; scenes of 131 072 triangles and more): the
+                # record half of the per-triangle kernel and the clear of the gradient records.  Their durations are in `busy` but not on the
+                # critical path, so the idle figure is taken against the main chain alone.
+                side = 0.0 if (args.no_side_stream or P < 131072) else sum(kernels.get(k, 0.0) for k in ("preprocess_records", "zero_grad_records"))
                 result["config"]["gpu_busy_ms_per_step"] = round(busy, 4)  # sum of the kernels' own durations
-                result["config"]["gpu_idle_ms_per_step"] = round(sum(device_steps) / len(device_steps) - busy, 4)
+                result["config"]["side_stream_ms_per_step"] = round(side, 4)
+                result["config"]["gpu_idle_ms_per_step"] = round(sum(device_steps) / len(device_steps) - (busy - side), 4)
             dom, dom_ms, dom_n = rows[0]
             dom_avg = dom_ms / max(dom_n, 1)
             ach = alg.get(dom, 0) / (dom_avg * 1e-3) / 1e9

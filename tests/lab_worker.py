@@ -51,6 +51,34 @@ if os.environ.get("LAB_DEPTH_ORDER") == "1":
         out.append(e)
     print("LAB_RESULT " + json.dumps(out))
     sys.exit(0)
+if os.environ.get("LAB_SIDE_STREAM") == "1":
+    # Round 6: scenes of TS2D_SIDE_STREAM_MIN_TRIANGLES triangles and more run the record half of the per-triangle kernel and the clear of the
+    # gradient records on the library's side stream (api.hip: SideLane).  Same scene with the side stream (the product's sequence) and without
+    # (ts2d_lab_no_side_stream: one per-triangle launch, everything on the caller's stream): every state array and every forward output must be
+    # IDENTICAL (the two halves repeat the same contraction-free arithmetic), the gradients equal up to the order of the atomics.
+    import ctypes
+    import torch
+    from diff_triangle_rasterization_2D import _C
+    _C._lib.ts2d_lab_no_side_stream.argtypes = [ctypes.c_int]
+    for P, W, H, D, variant, feat in [(140000, 640, 360, 3, 2, False), (131072, 400, 300, 0, 3, False), (150001, 320, 200, 1, 2, True)]:
+        s = synthetic.scene(P, W, H, D, seed=600 + D)
+        got = {}
+        for form, off in (("side", 0), ("single", 1)):
+            _C._lib.ts2d_lab_no_side_stream(off)
+            hf = helpers.hip_forward_backward(s, True, use_feature=feat, variant=variant)
+            got[form] = hf, {k: helpers.hip_state(hf, s, k).copy() for k in ("records", "clamped", "tiles_touched", "rect", "depth", "depth_perm", "point_offsets", "vals", "ranges", "n_contrib")}
+        _C._lib.ts2d_lab_no_side_stream(0)
+        (a, sa), (b, sb) = got["side"], got["single"]
+        e = {"P": P, "variant": variant, "int_num_rendered": float(a["num_rendered"] != b["num_rendered"])}
+        for k in sa:
+            e["int_state_" + k] = float(not np.array_equal(sa[k], sb[k]))
+        for k in ("out_feature", "depth", "normal", "radii"):
+            e["int_" + k] = float(not np.array_equal(a[k], b[k]))
+        for k in ("contrib_sum", "contrib_max", "dL_dvertex", "dL_dcenter2D", "dL_dopacity", "dL_dfeature" if feat else "dL_dshs"):
+            e[k] = helpers.rel_l2(a[k], b[k])
+        out.append(e)
+    print("LAB_RESULT " + json.dumps(out))
+    sys.exit(0)
 if FORCE_TICKETS:
     for near in (False, True):  # False: every depth shares its top key byte (4th depth pass skipped); True: it varies
         s = synthetic.scene(20000, 200, 120, 2, seed=91)

@@ -1,0 +1,47 @@
+#!/bin/bash
+# tools/lease.sh -- ONE parameterised script for every GPU lease (round 6 on; rounds 4-5 kept one script per lease, tools/r05_call*.sh were folded
+# into this).  A lease is a list of steps, each a shell function below:
+#     gpurun --timeout 1500 -- 'bash tools/lease.sh r06_a "t tests/test_side_stream_gpu.py; bench head; ab r05 2; prof head"'
+# Output goes to gpurun_out/<tag>/ (merged back by gpurun); what is worth judging is copied from there into profiles/ by hand.
+R=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=$1; shift
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+export TMPDIR=/tmp
+
+# t <pytest args>: GPU tests, quiet, last lines only
+t() { timeout 1500 python -m pytest "$@" -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -6 | tee -a $O/tests.txt; }
+
+# summary of one bench line on stdin: ms/step + the kernels' averages
+_sum() { python -c "
+import json,sys
+L=[l for l in sys.stdin.read().splitlines() if l.startswith('{')]
+if not L: print('$1 NO LINE'); sys.exit()
+j=json.loads(L[-1]); k=j.get('kernels_avg_ms',{}); c=j['config']
+print('$1', j['ms_per_step'], 'dev_med=%s idle=%s host_med=%s' % (c['device_step_ms']['median'], c.get('gpu_idle_ms_per_step'), c['host_step_ms']['median']), ' '.join(f'{a}={b:.4f}' for a,b in k.items()))"; }
+
+# bench <name> [bench.py args]: one run of bench.py, the JSON line appended to <name>.jsonl
+bench() { local n=$1; shift; timeout 600 python bench.py "$@" 2>$O/$n.err | tee -a $O/$n.jsonl | _sum $n | tee -a $O/summary.txt; }
+
+# ab <libtag> <rounds> [bench.py args]: the product library and tools/bin/libts2d_<libtag>.so alternating on this box
+ab() { local L=$1 n=$2; shift 2; for i in $(seq $n); do
+    bench ab_product --no-cpu-baseline "$@"
+    TS2D_LIBRARY_PATH=$R/tools/bin/libts2d_$L.so bench ab_$L --no-cpu-baseline "$@"; done; }
+
+# abflag <rounds> <flag> [bench.py args]: the lab library with and without one bench.py switch (e.g. --no-side-stream), alternating
+abflag() { local n=$1 f=$2; shift 2; for i in $(seq $n); do
+    TS2D_LIBRARY_PATH=$R/tools/bin/libts2d_lab.so bench abflag_off --no-cpu-baseline "$@"
+    TS2D_LIBRARY_PATH=$R/tools/bin/libts2d_lab.so bench "abflag_${f#--}" --no-cpu-baseline $f "$@"; done; }
+
+# prof <name> [bench.py args]: rocprofv3 kernel trace + stats of bench.py (no counters in this pass)
+prof() { local n=$1; shift; rm -rf $O/prof_$n; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o $n --output-format csv -- python $R/bench.py --no-cpu-baseline "$@" > $O/prof_$n.log 2>&1)
+    f=$(find $O/prof_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${n}_kernel_stats.csv && head -25 $f
+    tr=$(find $O/prof_$n -name "*kernel_trace.csv" | head -1); [ -n "$tr" ] && python $R/tools/overlap_summary.py $tr | tee $O/${n}_overlap.txt
+    find $O/prof_$n -name "*kernel_trace.csv" -size +20M -delete; }
+
+# pmc <name> "<counters>" [bench.py args]: one counter pass (own run, kernel trace only -- gpurun refuses counters with other trace domains)
+pmc() { local n=$1 c=$2; shift 2; rm -rf $O/pmc_$n; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n -o $n --output-format csv -- python $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 --settle-steps 0 --no-kernel-events "$@" > $O/pmc_$n.log 2>&1)
+    f=$(find $O/pmc_$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $f | tee $O/${n}_pmc.txt; rm -rf $O/pmc_$n; }
+
+eval "$@"

@@ -112,6 +112,7 @@ void prof_drain()
 
 #ifdef TS2D_LAB
 bool g_lab_all_quadrants = false; // ts2d_lab_force_all_quadrants (csrc/ts2d_lab.h)
+bool g_lab_no_side_stream = false; // ts2d_lab_no_side_stream: the single per-triangle launch at every size (A/B of the side stream)
 #endif
 
 int validate(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags)
@@ -176,6 +177,43 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
 #endif
     return r;
 }
+// ---- the library's side stream ---------------------------------------------------------------------------------------------------------
+// One forward = a chain of latency-bound launches (depth sort, scan: 2-3 waves per SIMD, the HBM mostly idle) behind an HBM-bound per-triangle
+// kernel of which the chain needs 20 of the 99 bytes it writes.  The other 79 -- the render record, with the 192-byte SH row it reads -- and the
+// clear of the gradient records go to a LOW-PRIORITY stream owned by the library, forked from the caller's stream by an event and joined back
+// by an event before the emission kernel (the record's first reader).  Lanes are per device, handed out round-robin: two forwards in flight on
+// one device (two caller streams) take different lanes; events are re-recorded per call.
+struct SideLane { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+SideLane *acquire_side_lane()
+{
+    constexpr int LANES = 4, MAXDEV = 16;
+    static SideLane lanes[MAXDEV][LANES];
+    static std::atomic<unsigned> next[MAXDEV];
+    static std::mutex mu;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return nullptr;
+    SideLane &l = lanes[dev][next[dev].fetch_add(1) % LANES];
+    if (!l.s)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!l.s)
+        {
+            int lo = 0, hi = 0; // numerically larger = lower priority
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess)
+            {
+                (void)hipGetLastError();
+                (void)hipStreamDestroy(st);
+                return nullptr;
+            }
+            l.s = st;
+        }
+    }
+    return &l;
+}
+
 // Early read-back of the instance count (binning.hip, count_instances_kernel): a pinned host word + an event per call in flight
 struct EarlyCount
 {
@@ -288,6 +326,7 @@ extern "C" {
 
 const char *ts2d_version(void) { return "ts2d 0.1 (gfx950)"; }
 const char *ts2d_last_error(void) { return g_err.c_str(); }
+uint32_t ts2d_abi_features(void) { return TS2D_FEATURE_PREPARED_RECORDS; }
 
 size_t ts2d_geometry_state_bytes(int32_t P)
 {
@@ -472,10 +511,34 @@ int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
     GeometryStateView g;
     ts_carve_geometry((char *)state->geometry, P, g);
     const PreprocessArgs a = make_pre(cam, geom, flags);
+    // Large scenes: the record half of the per-triangle kernel (and the clear of the gradient records) beside the depth sort, see SideLane.
+    // With the debug flag every kernel is followed by a synchronisation of `s`: keep the single launch there.
+    SideLane *lane = (P >= TS2D_SIDE_STREAM_MIN_TRIANGLES && !(flags & TS2D_FLAG_DEBUG) && ts_preprocess_fwd_splittable(a)
+#ifdef TS2D_LAB
+                      && !g_lab_no_side_stream
+#endif
+                      ) ? acquire_side_lane() : nullptr;
+    const bool prepare = flags & TS2D_FLAG_PREPARE_BACKWARD;
+    if (lane)
+    {
+        TS_HIP(hipEventRecord(lane->fork, s));
+        TS_HIP(hipStreamWaitEvent(lane->s, lane->fork, 0));
+        {
+            ProfScope ps("preprocess_records", lane->s);
+            if (flags & TS2D_FLAG_3D) ts_launch_preprocess3d_fwd(a, radii, g, lane->s, 2);
+            else ts_launch_preprocess_fwd(a, radii, g, lane->s, 2);
+        }
+        if (prepare)
+        {
+            ProfScope ps("zero_grad_records", lane->s);
+            ts_launch_zero_words((uint32_t *)g.grad_rec, (size_t)TS_GRAD_FLOATS * (size_t)P, lane->s);
+        }
+        TS_HIP(hipEventRecord(lane->join, lane->s));
+    }
     {
         ProfScope ps("preprocess_fwd", s);
-        if (flags & TS2D_FLAG_3D) ts_launch_preprocess3d_fwd(a, radii, g, s);
-        else ts_launch_preprocess_fwd(a, radii, g, s);
+        if (flags & TS2D_FLAG_3D) ts_launch_preprocess3d_fwd(a, radii, g, s, lane ? 1 : 0);
+        else ts_launch_preprocess_fwd(a, radii, g, s, lane ? 1 : 0);
     }
     TS_CHECK(flags, s, "preprocess_fwd");
     {
@@ -495,6 +558,12 @@ int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
         ts_scan_offsets(g, P, s);
     }
     TS_CHECK(flags, s, "scan");
+    if (lane) TS_HIP(hipStreamWaitEvent(s, lane->join, 0)); // the emission kernel reads the records: the join sits in front of whatever `s` runs next
+    else if (prepare)
+    {
+        ProfScope ps("zero_grad_records", s);
+        ts_launch_zero_words((uint32_t *)g.grad_rec, (size_t)TS_GRAD_FLOATS * (size_t)P, s);
+    }
     return TS2D_OK;
 }
 } // namespace
@@ -619,7 +688,8 @@ int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint
     if (!out->dL_dvertex || !out->dL_dcenter2D || !out->dL_dfeature || !out->dL_dopacity || (use_shs && !factored && !out->dL_dshs))
         return fail(TS2D_ERR_INVALID, "gradient outputs are null");
     if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
-    if (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P)) return fail(TS2D_ERR_CAPACITY, "backward scratch too small");
+    const bool records_ready = flags & TS2D_FLAG_GRAD_RECORDS_READY; // the forward cleared the state's own gradient records (TS2D_FLAG_PREPARE_BACKWARD)
+    if (!records_ready && (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P))) return fail(TS2D_ERR_CAPACITY, "backward scratch too small");
     if (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P) || !state->image ||
         state->image_bytes < ts2d_image_state_bytes(W, H) ||
         (N > 0 && (!state->binning || ts_binning_capacity(state->binning_bytes, W, H) < N)))
@@ -631,8 +701,9 @@ int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint
     if (N > 0) ts_carve_binning((char *)state->binning, ts_binning_capacity(state->binning_bytes, W, H), W, H, b); // as the forward carved it
     ts_carve_image((char *)state->image, W, H, im);
     const RenderArgs r = make_render(cam, geom, flags);
-    float *grad_rec = (float *)ts_align_up((size_t)scratch);
+    float *grad_rec = records_ready ? g.grad_rec : (float *)ts_align_up((size_t)scratch);
 
+    if (!records_ready)
     {
         ProfScope ps("zero_grad_records", s);
         // rasterizer.cu:290-300.  A KERNEL, not hipMemsetAsync: captured into a HIP graph (GraphedStep, bench.py --hip-graph) the memset became a
@@ -1125,6 +1196,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
 // ts2d_test_sort_pairs / ts2d_test_inclusive_scan_rocprim: csrc/lab_hooks.hip (the rocPRIM comparators live there, outside the product's objects)
 void ts2d_lab_force_ticket_passes(int on) { ts_force_ticket_passes(on != 0); }
 void ts2d_lab_force_all_quadrants(int on) { g_lab_all_quadrants = on != 0; }
+void ts2d_lab_no_side_stream(int on) { g_lab_no_side_stream = on != 0; }
 void ts2d_lab_force_depth_pass4(int on) { ts_force_depth_pass4(on != 0); }
 #endif // TS2D_LAB
 

@@ -19,6 +19,10 @@ using namespace ts;
 namespace
 {
 // One triangle.  `vp` = its 9 vertex floats, `shp` = its SH row (3 M floats); either global memory or an LDS row.
+// MODE (ts2d_preprocess_launch.h): PRE_ALL = everything; PRE_GEOMETRY = what the ordering chain needs (radii, tile count, rectangle, depth key);
+// PRE_RECORD = the render record + clamp flags (the same arithmetic up to the cull decisions -- contraction-free, so both instantiations decide
+// alike -- then the SH colour): the half that runs on the library's side stream beside the depth sort.
+template <int MODE>
 __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int32_t *__restrict__ radii, const GeometryStateView &g,
                                                    int idx, const float *vp, const float *shp, float4 *rec_row)
 {
@@ -82,6 +86,8 @@ __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int3
         const int rmaxy = min(a.grid_y, max(0, f2i((v_max.y + TS_TILE - 1) / TS_TILE)));
         if (rmaxx <= rminx || rmaxy <= rminy) break;
 
+        if (MODE != PRE_GEOMETRY)
+        {
         f3 rgb = {0, 0, 0};
         if (a.use_shs)
         {
@@ -107,22 +113,29 @@ __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int3
             rec[10] = n_view.x; rec[11] = n_view.y; rec[12] = n_view.z;
             rec[13] = r1_view.z + center_view.z; rec[14] = r2_view.z + center_view.z; rec[15] = r3_view.z + center_view.z;
         }
+        }
         out_depth = center_view.z;
         out_tiles = (uint32_t)(rmaxx - rminx) * (uint32_t)(rmaxy - rminy);
         out_rect = {(uint32_t)rminx | ((uint32_t)rminy << 16), (uint32_t)rmaxx | ((uint32_t)rmaxy << 16)};
         out_radius = f2i(fmaxf(ceilf((v_max.x - v_min.x) * 0.5f), ceilf((v_max.y - v_min.y) * 0.5f))); // forward.cu:192
     } while (false);
 
-    radii[idx] = out_radius;
-    g.tiles_touched[idx] = out_tiles;
-    g.rect[idx] = out_rect;
-    g.clamped[idx] = out_clamped;
-    g.depth[idx] = out_depth;
-    float4 *r = rec_row; // the triangle's 64-byte render record: g.rec + 4 idx, or an LDS row the workgroup writes out in one block
-    r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
-    r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
-    r[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
-    r[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
+    if (MODE != PRE_RECORD)
+    {
+        radii[idx] = out_radius;
+        g.tiles_touched[idx] = out_tiles;
+        g.rect[idx] = out_rect;
+        g.depth[idx] = out_depth;
+    }
+    if (MODE != PRE_GEOMETRY)
+    {
+        g.clamped[idx] = out_clamped;
+        float4 *r = rec_row; // the triangle's 64-byte render record: g.rec + 4 idx, or an LDS row the workgroup writes out in one block
+        r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+        r[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
+        r[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
+    }
 }
 
 // backward.cu:131-142
@@ -262,15 +275,17 @@ __device__ __forceinline__ f3 preprocess_bwd_one(const PreprocessArgs &a, const 
 
 struct Raster2D
 {
-    template <class... T> static __device__ __forceinline__ void fwd(T... t) { preprocess_fwd_one(t...); }
+    template <int MODE, class... T> static __device__ __forceinline__ void fwd(T... t) { preprocess_fwd_one<MODE>(t...); }
     template <class... T> static __device__ __forceinline__ f3 bwd(T... t) { return preprocess_bwd_one(t...); }
 };
 } // namespace
 
-void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s)
+void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s, int mode)
 {
-    launch_preprocess_fwd<Raster2D>(a, radii, g, s);
+    launch_preprocess_fwd<Raster2D>(a, radii, g, s, mode);
 }
+
+bool ts_preprocess_fwd_splittable(const PreprocessArgs &a) { return preprocess_fwd_splittable(a); }
 
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,

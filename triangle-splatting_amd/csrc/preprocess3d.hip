@@ -21,6 +21,7 @@ namespace
 __device__ __forceinline__ float proj_to_pix(float v, int S) { return (v + 1.0f) * S * 0.5f - 0.5f; } // R3D auxiliary.h:35-38
 
 // One triangle; `vp` / `shp` = its vertex / SH rows (global memory or LDS, ts2d_preprocess_launch.h).
+template <int MODE> // PRE_ALL / PRE_GEOMETRY / PRE_RECORD, see preprocess.hip
 __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, int32_t *__restrict__ radii, const GeometryStateView &g,
                                                      int idx, const float *vp, const float *shp, float4 *rec_row)
 {
@@ -63,7 +64,8 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
         if (rmaxx <= rminx || rmaxy <= rminy) break;
 
         f3 rgb = {0, 0, 0};
-        if (a.use_shs)
+        if (MODE == PRE_GEOMETRY) {}
+        else if (a.use_shs)
         {
             const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
             rgb = sh_to_rgb(a.D, shp, center, cp);
@@ -81,7 +83,7 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
         rec[3] = v2_view.x; rec[4] = v2_view.y; rec[5] = v2_view.z;
         rec[6] = v3_view.x; rec[7] = v3_view.y; rec[8] = v3_view.z;
         rec[9] = normal_view.x; rec[10] = normal_view.y; rec[11] = normal_view.z;
-        rec[12] = a.opacity[idx];
+        rec[12] = MODE == PRE_GEOMETRY ? 0.0f : a.opacity[idx];
         rec[13] = rgb.x; rec[14] = rgb.y; rec[15] = rgb.z;
         out_depth = center_view.z;
         out_tiles = (uint32_t)(rmaxx - rminx) * (uint32_t)(rmaxy - rminy);
@@ -89,16 +91,22 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
         out_radius = f2i(fmaxf(ceilf((v_max.x - v_min.x) * 0.5f), ceilf((v_max.y - v_min.y) * 0.5f)));
     } while (false);
 
-    radii[idx] = out_radius;
-    g.tiles_touched[idx] = out_tiles;
-    g.rect[idx] = out_rect;
-    g.clamped[idx] = out_clamped;
-    g.depth[idx] = out_depth;
-    float4 *r = rec_row; // the triangle's 64-byte render record: g.rec + 4 idx, or an LDS row the workgroup writes out in one block
-    r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
-    r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
-    r[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
-    r[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
+    if (MODE != PRE_RECORD)
+    {
+        radii[idx] = out_radius;
+        g.tiles_touched[idx] = out_tiles;
+        g.rect[idx] = out_rect;
+        g.depth[idx] = out_depth;
+    }
+    if (MODE != PRE_GEOMETRY)
+    {
+        g.clamped[idx] = out_clamped;
+        float4 *r = rec_row; // the triangle's 64-byte render record: g.rec + 4 idx, or an LDS row the workgroup writes out in one block
+        r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
+        r[1] = make_float4(rec[4], rec[5], rec[6], rec[7]);
+        r[2] = make_float4(rec[8], rec[9], rec[10], rec[11]);
+        r[3] = make_float4(rec[12], rec[13], rec[14], rec[15]);
+    }
 }
 
 // One triangle; `ov` (9 floats) / `osh` (3 M floats, may be null) receive dL_dvertex / dL_dshs (global memory or LDS rows).
@@ -173,14 +181,14 @@ __device__ __forceinline__ f3 preprocess3d_bwd_one(const PreprocessArgs &a, cons
 }
 struct Raster3D
 {
-    template <class... T> static __device__ __forceinline__ void fwd(T... t) { preprocess3d_fwd_one(t...); }
+    template <int MODE, class... T> static __device__ __forceinline__ void fwd(T... t) { preprocess3d_fwd_one<MODE>(t...); }
     template <class... T> static __device__ __forceinline__ f3 bwd(T... t) { return preprocess3d_bwd_one(t...); }
 };
 } // namespace
 
-void ts_launch_preprocess3d_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s)
+void ts_launch_preprocess3d_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s, int mode)
 {
-    launch_preprocess_fwd<Raster3D>(a, radii, g, s);
+    launch_preprocess_fwd<Raster3D>(a, radii, g, s, mode);
 }
 
 void ts_launch_preprocess3d_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,

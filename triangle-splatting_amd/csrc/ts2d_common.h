@@ -85,6 +85,8 @@ struct GeometryStateView
     uint64_t *blocksum;      // ceil(P / 1024) + 2   raw per-block sums of tiles_sorted; [nblocks] = N (scratch of the depth sort's census before that)
     uint64_t *supersum;      // ceil(nblocks / 64) + 1   sums of 64 consecutive block sums (atomics; zeroed by the step's first launch)
     RadixScratchView rs;
+    float *grad_rec;         // P * 16  gradient records (TS_GRAD_FLOATS), zeroed by a forward that was asked to (TS2D_FLAG_PREPARE_BACKWARD) on the
+                             //         side stream; a backward told so (TS2D_FLAG_GRAD_RECORDS_READY) accumulates here and clears nothing
 };
 
 struct BinningStateView
@@ -152,6 +154,7 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.supersum, ((n + 1023) / 1024 + 63) / 64 + 1);
     ts_carve_radix(p, n, v.rs, ts_depth_chunk(n));
     v.top_const = v.rs.tickets + v.rs.slabs + 4;
+    ts_carve(p, v.grad_rec, n * TS_GRAD_FLOATS);
     return (size_t)(p - base) + TS_ALIGN;
 }
 
@@ -237,7 +240,8 @@ struct PreprocessArgs
     const float *vertex, *shs, *feature, *opacity;
 };
 
-void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s);
+void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s, int mode = 0); // mode: ts2d_preprocess_launch.h (PRE_ALL / PRE_GEOMETRY / PRE_RECORD)
+bool ts_preprocess_fwd_splittable(const PreprocessArgs &a);
 // binning.hip -- every step hand-written for gfx950 (the round-1 rocPRIM calls survive only as test comparators)
 void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s); // first histogram + N + key-bit census
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s);          // the rest: (depth bits, id) -> sorted ids
@@ -301,7 +305,7 @@ void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, con
 // ---- 3D variant (TS2D_FLAG_3D): same states and binning, its own record contents and blend maths -----------------
 // Render record: [0..8] v1_view v2_view v3_view   [9..11] normal_view (unnormalised)   [12] opacity   [13..15] r g b
 // Gradient record: [0..8] dL/dv{1,2,3}_view   [9..11] dL/dnormal_view   [12] dL/dopacity   [13..15] dL/drgb
-void ts_launch_preprocess3d_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s);
+void ts_launch_preprocess3d_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s, int mode = 0);
 void ts_launch_preprocess3d_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                                 const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,
                                 float *dL_dfeature, float *dL_dopacity, hipStream_t s);

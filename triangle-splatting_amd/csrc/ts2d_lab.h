@@ -45,6 +45,11 @@ void ts2d_lab_force_depth_pass4(int on);
  * tests/test_qmask_gpu.py compares the two, bit for bit where the arithmetic is ordered. */
 void ts2d_lab_force_all_quadrants(int on);
 
+/* on != 0: later forwards in this library never fork the side stream -- one per-triangle launch on the caller's stream, the gradient records
+ * (TS2D_FLAG_PREPARE_BACKWARD) cleared on it behind the scan: the A/B partner of the product's sequence (tools/ab_side_stream.sh) and the
+ * reference for tests/test_side_stream_gpu.py (both sequences must leave the same state and outputs, bit for bit). */
+void ts2d_lab_no_side_stream(int on);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,13 @@
 #endif
 namespace ts
 {
+// Which half of the per-triangle forward a launch computes (api.hip: forward_bin_impl).  The ordering chain -- depth sort, scan -- needs four words
+// per triangle (radii, tile count, rectangle, depth key: 36 bytes in, 20 out); the render record with its SH colour (228 of the 327 bytes per
+// triangle at SH degree 3) is first read by the emission kernel behind the scan.  PRE_GEOMETRY runs on the caller's stream in front of the depth
+// sort, PRE_RECORD on the library's side stream BESIDE it (the sort is a latency chain that leaves the HBM idle); PRE_ALL = both in one launch
+// (small scenes, unaligned inputs).
+enum { PRE_ALL = 0, PRE_GEOMETRY = 1, PRE_RECORD = 2 };
+
 // The binning kernels' "last block finishes" tickets (binning.hip) are zeroed by the first launch of the step.  Every grid has at
 // least 64 threads and slabs + TS_RS_TICKET_EXTRA <= max(P, 64), so the threads beyond P of a tiny scene take part.  The slab totals of the
 // depth sort's first (ticket-free) histogram and the group sums of the scan are cleared here as well.
@@ -35,16 +42,26 @@ __global__ void __launch_bounds__(256) preprocess_fwd_direct_kernel(PreprocessAr
     const int idx = blockIdx.x * 256 + threadIdx.x;
     clear_tickets(g, idx, a.P);
     if (idx >= a.P) return;
-    Body::fwd(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr, g.rec + 4 * (size_t)idx);
+    Body::template fwd<PRE_ALL>(a, radii, g, idx, a.vertex + 9 * (size_t)idx, a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr, g.rec + 4 * (size_t)idx);
 }
 
 // vertex rows always staged; SH rows (SHROW = 3 M > 0 floats) travel either through LDS as well (SH_REGS = false) or straight into
 // the lane's registers with SHROW / 4 dwordx4 loads (SH_REGS = true).  Both read the rows at the same rate in isolation
 // (tools/sh_stage_bench.hip: 5.5-5.7 TB/s), but 12.5 KB of LDS per single-wave workgroup held the kernel at 2 waves per SIMD with
 // 73 % of the wave cycles spent waiting (profiles/r02_notes.md); without it the registers are the only limit.
-template <class Body, int SHROW, bool SH_REGS>
+template <class Body, int SHROW, bool SH_REGS, int MODE>
 __global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
 {
+    if (MODE == PRE_GEOMETRY) // no colour, no record: vertex rows in, four words per triangle out
+    {
+        __shared__ float s_vg[64 * 9];
+        const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
+        stage_rows_in<9, 9>(s_vg, a.vertex, row0, a.P, lane);
+        __syncthreads();
+        clear_tickets(g, idx, a.P);
+        if (idx < a.P) Body::template fwd<PRE_GEOMETRY>(a, radii, g, idx, s_vg + lane * 9, (const float *)nullptr, (float4 *)nullptr);
+        return;
+    }
     __shared__ float s_v[64 * 9];
     __shared__ float s_sh[(SHROW > 0 && !SH_REGS) ? 64 * (SHROW + 1) : 1];
     const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
@@ -58,14 +75,14 @@ __global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArg
     stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
     if (SHROW > 0 && !SH_REGS) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
     __syncthreads();
-    clear_tickets(g, idx, a.P);
+    if (MODE == PRE_ALL) clear_tickets(g, idx, a.P); // (PRE_RECORD runs beside the sort that the tickets belong to)
     // the 64 render records of the workgroup are one contiguous 4 KB block: each lane parks its record in LDS (row stride 80 bytes:
     // conflict-free 128-bit accesses) and the block leaves with coalesced dwordx4 stores instead of four stores at a 64-byte lane stride
     __shared__ float4 s_rec[64 * 5];
     if (idx < a.P)
     {
         const float *shp = SHROW > 0 ? (SH_REGS ? shr : s_sh + lane * (SHROW + 1)) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
-        Body::fwd(a, radii, g, idx, s_v + lane * 9, shp, s_rec + lane * 5);
+        Body::template fwd<(MODE == PRE_RECORD ? PRE_RECORD : PRE_ALL)>(a, radii, g, idx, s_v + lane * 9, shp, s_rec + lane * 5);
     }
     __syncthreads();
     float4 *out = g.rec + 4 * (size_t)row0;
@@ -150,26 +167,37 @@ __global__ void __launch_bounds__(64) preprocess_bwd_staged_kernel(PreprocessArg
 // element is written).  M outside {1, 4, 9, 16} never stages SH rows.
 static inline int staged_shrow(const PreprocessArgs &a) { return (a.use_shs && (a.M == 1 || a.M == 4 || a.M == 9 || a.M == 16)) ? 3 * a.M : 0; }
 
+// Can the per-triangle forward of these arguments run as two launches (PRE_GEOMETRY + PRE_RECORD)?  Only the staged kernels have the two halves.
+static inline bool preprocess_fwd_splittable(const PreprocessArgs &a) { return a.P > 0 && aligned16(a.vertex); }
+
+template <class Body, int MODE>
+void launch_preprocess_fwd_mode(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s)
+{
+    const int shrow = staged_shrow(a);
+    const bool sh_in = MODE != PRE_GEOMETRY && shrow > 0 && 2 * (a.D + 1) * (a.D + 1) >= a.M && aligned16(a.shs);
+    const dim3 grid((a.P + 63) / 64), block(64);
+    switch (sh_in ? shrow : 0)
+    {
+    case 48: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 48, true, MODE>), grid, block, 0, s, a, radii, g); break; // rows are 16-byte multiples
+    case 27: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 27, false, MODE>), grid, block, 0, s, a, radii, g); break;
+    case 12: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 12, true, MODE>), grid, block, 0, s, a, radii, g); break;
+    case 3: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 3, false, MODE>), grid, block, 0, s, a, radii, g); break;
+    default: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 0, false, MODE>), grid, block, 0, s, a, radii, g); break;
+    }
+}
+
 template <class Body>
-void launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s)
+void launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s, int mode)
 {
     if (a.P <= 0) return;
-    const int shrow = staged_shrow(a);
-    const bool sh_in = shrow > 0 && 2 * (a.D + 1) * (a.D + 1) >= a.M && aligned16(a.shs);
-    if (!aligned16(a.vertex))
+    if (!aligned16(a.vertex)) // callers ask preprocess_fwd_splittable() first: an unaligned scene only ever comes here with PRE_ALL
     {
         hipLaunchKernelGGL((preprocess_fwd_direct_kernel<Body>), dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g);
         return;
     }
-    const dim3 grid((a.P + 63) / 64), block(64);
-    switch (sh_in ? shrow : 0)
-    {
-    case 48: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 48, true>), grid, block, 0, s, a, radii, g); break; // rows are 16-byte multiples
-    case 27: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 27, false>), grid, block, 0, s, a, radii, g); break;
-    case 12: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 12, true>), grid, block, 0, s, a, radii, g); break;
-    case 3: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 3, false>), grid, block, 0, s, a, radii, g); break;
-    default: hipLaunchKernelGGL((preprocess_fwd_staged_kernel<Body, 0, false>), grid, block, 0, s, a, radii, g); break;
-    }
+    if (mode == PRE_GEOMETRY) launch_preprocess_fwd_mode<Body, PRE_GEOMETRY>(a, radii, g, s);
+    else if (mode == PRE_RECORD) launch_preprocess_fwd_mode<Body, PRE_RECORD>(a, radii, g, s);
+    else launch_preprocess_fwd_mode<Body, PRE_ALL>(a, radii, g, s);
 }
 
 #define TS_BWD_STAGED(SHROW, SH_IN, WRITE_SH)                                                                                \

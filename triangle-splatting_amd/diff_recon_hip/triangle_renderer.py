@@ -30,8 +30,10 @@ class TriangleRenderer:
 
     def render(self, vertex: torch.Tensor, shs: Optional[torch.Tensor], color: Optional[torch.Tensor],
                opacity: torch.Tensor) -> Dict[str, torch.Tensor]:
-        # gradient sink for the screen-space (2D) / view-space (3D) triangle centres, reference :67
-        center2D = torch.zeros((vertex.shape[0], 2), device=vertex.device, dtype=vertex.dtype, requires_grad=True)
+        # gradient sink for the screen-space (2D) / view-space (3D) triangle centres, reference :67 -- a fresh leaf per call like the
+        # reference's, over one cached block of zeros instead of a fill kernel per step (diff_triangle_rasterization_2D.center2D_sink)
+        from diff_triangle_rasterization_2D import center2D_sink
+        center2D = center2D_sink(vertex.shape[0], vertex.device, vertex.dtype)
         out = self.rasterizer.forward(vertex=vertex, center2D=center2D, opacity=opacity, shs=shs, feature=color)
         pkg = {"render": out[0], "radii": out[1], "center2D": center2D}
         if self.rasterizer.raster_settings.rich_info:

@@ -110,6 +110,25 @@ def forward_overflowed(out_feature: torch.Tensor = None):
         raise RuntimeError("no sync-free forward has run (set_instance_capacity)")
     return _C.forward_status(*_last_sync_free_forward)
 
+_center2D_zeros = {}
+
+
+def center2D_sink(num_points: int, device, dtype=torch.float32) -> torch.Tensor:
+    """The `center2D` argument of TriangleRasterizer.forward: a (P, 2) leaf that exists only so that autograd has somewhere to put
+    dL_dcenter2D (`center2D.grad`, read by the model's densification statistics, VanillaTS_model.py:347-363); it is never sent to the native
+    side (reference __init__.py:52-60).  The reference's caller makes a fresh `torch.zeros((P, 2), requires_grad=True)` per render call
+    (src/diff_recon/renderer/triangle_renderer.py:67): one fill kernel on the critical path of every step for values nobody reads.  This hands
+    out a NEW leaf per call -- its own `.grad`, its own place in the graph -- over ONE cached block of zeros per (device, dtype, P): no kernel.
+    Do not write into it in place (nothing in the reference does)."""
+    key = (torch.device(device), dtype, int(num_points))
+    z = _center2D_zeros.get(key)
+    if z is None:
+        if len(_center2D_zeros) >= 8:  # a model that densifies walks through sizes: keep the cache from growing without bound
+            _center2D_zeros.clear()
+        z = _center2D_zeros[key] = torch.zeros((int(num_points), 2), device=key[0], dtype=dtype)
+    return z.detach().requires_grad_(True)
+
+
 # Set by parallel.GradBucket.capture(): while a bucket is installed, backward passes write dL_dvertex / dL_dopacity /
 # dL_dcenter2D (and the dense colour gradient when the bucket has a slot for it) straight into the bucket's views.
 _grad_bucket = None
@@ -138,10 +157,14 @@ class _RasterizeTriangles(torch.autograd.Function):
             bg_depth = float(bg_depth)
         native_args = (rs.image_width, rs.image_height) + _camera_and_geometry_args(rs, bg_depth) + (
             vertex, shs, feature, opacity, rs.back_culling, rs.rich_info, rs.debug)
+        # a backward will follow: the forward clears the gradient records it accumulates into (they live in the geometry state) on the
+        # library's side stream, beside the depth sort, instead of the backward clearing a scratch buffer in front of its blend kernel
+        prepare = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
+        ctx.records_ready = prepare and vertex.shape[0] > 0 and _C.HAS_PREPARED_RECORDS
         with _snapshot_on_error("rasterize_triangles", native_args, rs.debug):
             (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max,
              geometryBuffer, binningBuffer, imageBuffer) = _C.rasterize_triangles(
-                *native_args, variant=ctx._forward_cls._variant,
+                *native_args, variant=ctx._forward_cls._variant, prepare_backward=prepare,
                 instance_capacity=(_instance_capacity(vertex.shape[0], rs.image_width, rs.image_height) if callable(_instance_capacity)
                                    else _instance_capacity) if vertex.shape[0] > 0 else None)
 
@@ -201,8 +224,10 @@ class _RasterizeTriangles(torch.autograd.Function):
             # a bucket prepared for a ranged exchange (GradBucket.prepare_ranges): the per-triangle kernel runs range by range with an event behind
             # each, so that the exchange of range k overlaps range k + 1 -- only for the backward that WRITES the bucket (the first under a capture)
             ranged = place is not None and getattr(bucket, "range_events", None)
+            ready, ctx.records_ready = getattr(ctx, "records_ready", False), False  # a second backward through this forward clears a scratch itself
             g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(
-                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place, range_events=ranged or None)
+                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place, range_events=ranged or None,
+                records_ready=ready)
             if ranged:
                 bucket._ranges_recorded = True
             if sink is not None:
@@ -271,4 +296,4 @@ set_capacity_hint_key = _C.set_capacity_hint_key      # separate binning-size hi
 speculative_overflows = _C.speculative_overflows      # forwards that guessed too small and rendered twice, since the process started
 
 __all__ = ["TriangleRasterizationSettings", "TriangleRasterizer", "set_instance_capacity", "forward_overflowed", "set_capacity_hint_key",
-           "speculative_overflows"]
+           "speculative_overflows", "center2D_sink"]
