@@ -73,8 +73,7 @@ def algorithmic_bytes(P, N, W, H, D, ntiles):
     k["depth_sort"] = P * 16 * 4
     k["depth_census"] = P * 8          # first histogram: keys + tile counts (small scenes: the whole depth order in this one launch)
     k["zero_grad_records"] = P * 64
-    k["preprocess_records"] = P * (36 + sh + 4 + 65)  # the record half of the per-triangle kernel (side stream): vertex + SH + opacity in, record + clamp flags out
-    k["preprocess_geometry"] = P * (36 + 20)          # the half the ordering chain waits for: vertex in; radii, tile count, rectangle, depth key out
+    k["preprocess_colour"] = P * (4 + 36 + sh + 13)   # the SH colours on the side stream: tile count + vertex + SH row in, r g b + clamp flags out
     k["tile_sort"] = N * 16 * -(-msb_bits(ntiles) // 8)
     return k
 
@@ -121,10 +120,11 @@ def main():
                     help="NOT the headline: the depth sort runs its fourth pass although every depth of the synthetic scene shares the top key byte "
                          "(what a scene spanning more than a factor of four in depth costs).  Needs the lab library: "
                          "TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so (the product library has no switch)")
-    ap.add_argument("--no-side-stream", action="store_true",
-                    help="NOT the headline: the forward as one chain on the caller's stream (the per-triangle kernel as ONE launch, the gradient records "
-                         "cleared behind the scan) instead of forking the library's side stream -- the A/B partner of the product's sequence.  Needs the "
-                         "lab library: TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
+    ap.add_argument("--side-stream", action="store_true",
+                    help="NOT the headline, lab library only (TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so): the SH colours evaluated by a throttled kernel on a "
+                         "library-owned stream beside the ordering chain (csrc/api.hip: SideLane) -- round 6's measured negative result, kept reproducible "
+                         "(profiles/r06_side_stream.txt)")
+    ap.add_argument("--colour-blocks", type=int, default=0, help="with --side-stream: the colour kernel's grid = its throttle (default 512)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--timed-kernel-events", default="dominant", choices=["dominant", "all"],
                     help="which kernels are bracketed by HIP events INSIDE the timed region: the dominant one (2 events per step; default) or "
@@ -182,10 +182,12 @@ def main():
         if not hasattr(_C._lib, "ts2d_lab_force_depth_pass4"):
             raise SystemExit("--force-depth-pass4 needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
         _C._lib.ts2d_lab_force_depth_pass4(1)
-    if args.no_side_stream:
-        if not hasattr(_C._lib, "ts2d_lab_no_side_stream"):
-            raise SystemExit("--no-side-stream needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
-        _C._lib.ts2d_lab_no_side_stream(1)
+    if args.side_stream:
+        if not hasattr(_C._lib, "ts2d_lab_side_stream"):
+            raise SystemExit("--side-stream needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
+        _C._lib.ts2d_lab_side_stream(1)
+        if args.colour_blocks:
+            _C._lib.ts2d_lab_colour_blocks(args.colour_blocks)
     P, W, H, D = args.triangles, args.width, args.height, args.sh_degree
     s = synthetic.scene(P, W, H, D, seed=42, mode=args.scene_mode, edge_px=args.edge_px)
     # one view per rank: same triangles, camera shifted sideways by a few world units per rank
@@ -485,12 +487,8 @@ def main():
             result["kernels_avg_ms"] = {k: round(v, 4) for k, v in kernels.items()}  # ten steps right behind the timed region
             if world == 1:
                 busy = sum(kernels.values())
-                # what runs on the library's side stream BESIDE the depth sort (csrc/api.hip: SideLane; scenes of 131 072 triangles and more): the
-                # record half of the per-triangle kernel and the clear of the gradient records.  Their durations are in `busy` but not on the
-                # critical path, so the idle figure is taken against the main chain alone.
-                side = 0.0 if (args.no_side_stream or P < 131072) else sum(kernels.get(k, 0.0) for k in ("preprocess_records", "zero_grad_records"))
+                side = kernels.get("preprocess_colour", 0.0) if args.side_stream else 0.0  # (lab experiment: a kernel BESIDE the main chain)
                 result["config"]["gpu_busy_ms_per_step"] = round(busy, 4)  # sum of the kernels' own durations
-                result["config"]["side_stream_ms_per_step"] = round(side, 4)
                 result["config"]["gpu_idle_ms_per_step"] = round(sum(device_steps) / len(device_steps) - (busy - side), 4)
             dom, dom_ms, dom_n = rows[0]
             dom_avg = dom_ms / max(dom_n, 1)

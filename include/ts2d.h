@@ -7,12 +7,7 @@
  * the caller owns all memory, including the three opaque state buffers that the reference keeps in
  * torch uint8 tensors (geometryBuffer / binningBuffer / imageBuffer,
  * R2D/src/extension_interface.cu:126-128).  All kernels are enqueued on the HIP stream passed in
- * (`stream` is a hipStream_t; NULL = the null stream).  Scenes of TS2D_SIDE_STREAM_MIN_TRIANGLES triangles and more additionally use one
- * library-owned low-priority stream per call: it is forked from `stream` by an event at the top of the forward, carries the half of the
- * per-triangle kernel that nothing in the depth sort needs (the render records with their SH colours) and the clear of the gradient records,
- * and is joined back into `stream` by an event BEFORE the call returns its last launch -- so the caller sees plain stream semantics on
- * `stream` (everything queued behind the call is ordered behind all of the call's work; a capture of `stream` into a HIP graph captures the
- * side stream's nodes with it).
+ * (`stream` is a hipStream_t; NULL = the null stream).
  *
  * What each entry point replaces in the reference:
  *
@@ -67,19 +62,8 @@ extern "C" {
                                        the clamp-masked colour gradient dL_dRGB (P*3) from which ts2d_sh_grad_expand
                                        rebuilds dL_dshs -- the multi-GPU exchange format (new; no reference counterpart) */
 
-#define TS2D_FLAG_PREPARE_BACKWARD 0x40u /* forward entry points that queue the whole forward (ts2d_forward, ts2d_forward_speculative,
-                                       ts2d_forward_bin): also clear the per-triangle gradient records the backward accumulates into
-                                       (Rasterizer::backward's zeroed scratch tensors, R2D/src/rasterizer.cu:290-300) -- they live in the
-                                       geometry state, and the clear runs on the library's side stream beside the depth sort instead of in
-                                       front of the backward's blend kernel */
-#define TS2D_FLAG_GRAD_RECORDS_READY 0x80u /* ts2d_backward / ts2d_backward_ranged: the caller's promise that the forward that filled `state`
-                                       ran with TS2D_FLAG_PREPARE_BACKWARD and that no backward has consumed its records since.  The backward
-                                       then clears nothing and `scratch` may be NULL.  Without the flag: the reference's sequence (the
-                                       caller's scratch, cleared by the library) -- e.g. a second backward through one forward */
-
 #define TS2D_MAX_CHANNELS 3 /* R2D/src/config.h:3 */
 #define TS2D_TILE 16        /* R2D/src/config.h:4-5 (BLOCK_X = BLOCK_Y = 16) */
-#define TS2D_SIDE_STREAM_MIN_TRIANGLES 131072 /* below: one per-triangle launch on `stream`, no side stream (a fork / join costs more than it hides) */
 
 /* CameraInfo, R2D/src/param_struct.h:127-136.  All pointers are device pointers. */
 typedef struct ts2d_camera
@@ -152,10 +136,6 @@ typedef struct ts2d_state
 
 const char *ts2d_version(void);
 const char *ts2d_last_error(void);
-/* Bit mask of optional behaviour this build of the library has, for callers that may be handed an older libts2d.so:
- * bit 0 = TS2D_FLAG_PREPARE_BACKWARD / TS2D_FLAG_GRAD_RECORDS_READY (gradient records inside the geometry state). */
-#define TS2D_FEATURE_PREPARED_RECORDS 0x1u
-uint32_t ts2d_abi_features(void);
 
 size_t ts2d_geometry_state_bytes(int32_t P);
 size_t ts2d_binning_state_bytes(int64_t num_rendered, int32_t width, int32_t height);
@@ -178,7 +158,7 @@ int ts2d_forward_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
                         const ts2d_state *state, const ts2d_forward_out *out, void *stream);
 
 /* Backward.  `scratch` is >= ts2d_backward_scratch_bytes(P) bytes of device memory (zeroed by the
- * library); with TS2D_FLAG_GRAD_RECORDS_READY it is not used and may be NULL.  Fully asynchronous. */
+ * library).  Fully asynchronous. */
 int ts2d_backward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t num_rendered,
                   const int32_t *radii, const ts2d_state *state, const ts2d_loss_grads *loss, void *scratch,
                   size_t scratch_bytes, const ts2d_backward_out *out, void *stream);

@@ -52,22 +52,24 @@ if os.environ.get("LAB_DEPTH_ORDER") == "1":
     print("LAB_RESULT " + json.dumps(out))
     sys.exit(0)
 if os.environ.get("LAB_SIDE_STREAM") == "1":
-    # Round 6: scenes of TS2D_SIDE_STREAM_MIN_TRIANGLES triangles and more run the record half of the per-triangle kernel and the clear of the
-    # gradient records on the library's side stream (api.hip: SideLane).  Same scene with the side stream (the product's sequence) and without
-    # (ts2d_lab_no_side_stream: one per-triangle launch, everything on the caller's stream): every state array and every forward output must be
-    # IDENTICAL (the two halves repeat the same contraction-free arithmetic), the gradients equal up to the order of the atomics.
+    # Round 6's side-stream experiment (lab library only; csrc/api.hip: SideLane): the per-triangle kernel without the SH colours + a colour kernel
+    # on a library-owned stream beside the ordering chain.  Same scene with it (ts2d_lab_side_stream) and without (the product's one launch):
+    # every state array and every forward output must be IDENTICAL (the colour kernel repeats the single launch's contraction-free expressions),
+    # the gradients equal up to the order of the atomics.
     import ctypes
     import torch
     from diff_triangle_rasterization_2D import _C
-    _C._lib.ts2d_lab_no_side_stream.argtypes = [ctypes.c_int]
-    for P, W, H, D, variant, feat in [(140000, 640, 360, 3, 2, False), (131072, 400, 300, 0, 3, False), (150001, 320, 200, 1, 2, True)]:
+    _C._lib.ts2d_lab_side_stream.argtypes = [ctypes.c_int]
+    for P, W, H, D, variant, feat in [(140000, 640, 360, 3, 2, False), (131072, 400, 300, 1, 3, False), (150001, 320, 200, 1, 2, False), (135000, 320, 200, 3, 3, False)]:
         s = synthetic.scene(P, W, H, D, seed=600 + D)
+        if P == 150001:
+            s["vertex"][::3, :, 2] += 5000.0  # a third of the triangles behind the camera: culled, the colour kernel skips their SH rows
         got = {}
-        for form, off in (("side", 0), ("single", 1)):
-            _C._lib.ts2d_lab_no_side_stream(off)
+        for form, on in (("side", 1), ("single", 0)):
+            _C._lib.ts2d_lab_side_stream(on)
             hf = helpers.hip_forward_backward(s, True, use_feature=feat, variant=variant)
             got[form] = hf, {k: helpers.hip_state(hf, s, k).copy() for k in ("records", "clamped", "tiles_touched", "rect", "depth", "depth_perm", "point_offsets", "vals", "ranges", "n_contrib")}
-        _C._lib.ts2d_lab_no_side_stream(0)
+        _C._lib.ts2d_lab_side_stream(0)
         (a, sa), (b, sb) = got["side"], got["single"]
         e = {"P": P, "variant": variant, "int_num_rendered": float(a["num_rendered"] != b["num_rendered"])}
         for k in sa:

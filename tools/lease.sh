@@ -11,7 +11,9 @@ cd $R
 export TMPDIR=/tmp
 
 # t <pytest args>: GPU tests, quiet, last lines only
-t() { timeout 1500 python -m pytest "$@" -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -6 | tee -a $O/tests.txt; }
+t() { timeout 1500 python -m pytest "$@" -m gpu -q -x 2>&1 | grep -v amdgpu.ids | tail -40 | tee -a $O/tests.txt; }
+# lab <name> [bench.py args]: bench.py on the lab library
+lab() { local n=$1; shift; TS2D_LIBRARY_PATH=$R/tools/bin/libts2d_lab.so bench $n --no-cpu-baseline "$@"; }
 
 # summary of one bench line on stdin: ms/step + the kernels' averages
 _sum() { python -c "

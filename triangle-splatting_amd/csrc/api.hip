@@ -112,7 +112,8 @@ void prof_drain()
 
 #ifdef TS2D_LAB
 bool g_lab_all_quadrants = false; // ts2d_lab_force_all_quadrants (csrc/ts2d_lab.h)
-bool g_lab_no_side_stream = false; // ts2d_lab_no_side_stream: the single per-triangle launch at every size (A/B of the side stream)
+bool g_lab_side_stream = false; // ts2d_lab_side_stream: the SH colours on a side stream (measured, not adopted: see SideLane)
+int g_lab_colour_blocks = 0;    // ts2d_lab_colour_blocks: resident single-wave workgroups of the colour kernel (0 = TS_COLOUR_BLOCKS)
 #endif
 
 int validate(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags)
@@ -177,13 +178,20 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
 #endif
     return r;
 }
-// ---- the library's side stream ---------------------------------------------------------------------------------------------------------
-// One forward = a chain of latency-bound launches (depth sort, scan: 2-3 waves per SIMD, the HBM mostly idle) behind an HBM-bound per-triangle
-// kernel of which the chain needs 20 of the 99 bytes it writes.  The other 79 -- the render record, with the 192-byte SH row it reads -- and the
-// clear of the gradient records go to a LOW-PRIORITY stream owned by the library, forked from the caller's stream by an event and joined back
-// by an event before the emission kernel (the record's first reader).  Lanes are per device, handed out round-robin: two forwards in flight on
-// one device (two caller streams) take different lanes; events are re-recorded per call.
+#ifdef TS2D_LAB
+// ---- a side stream for the SH colours: LAB LIBRARY ONLY, a measured negative result (round 6, profiles/r06_side_stream.txt) --------------------
+// one forward = an HBM-bound per-triangle kernel in front of a chain of latency-bound launches (depth sort, scan, emission,
+// tile sort: 2-3 waves per SIMD, the HBM mostly idle), and 228 of the 327 bytes per triangle that kernel moves (the SH row -> r g b) are first
+// read by the blend kernel.  Built: the per-triangle kernel without the colours (PRE_NOCOLOUR, 72 -> 34 us) and a colour kernel on a library-owned
+// stream, forked behind it and joined in front of the blend kernel, throttled by its grid.  Measured at the headline, product and variant
+// alternating on one box: NO grid wins -- the chain's kernels are chains of dependent memory round trips, and any background stream of bytes
+// stretches every one of them (grid 512 = 2.3 TB/s beside them: depth sort 40 -> 67 us, census 21 -> 31, emission 53 -> 60: step 1.581 against
+// 1.563; grid 128: the colours arrive 0.17 ms late).  A lowest-priority stream made EVERY later kernel of the process slower (preprocess_bwd +13 %)
+// and a capture of the forked stream into a HIP graph crashed in hipStreamEndCapture on this stack.  The product keeps ONE launch on ONE stream.
 struct SideLane { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; };
+#ifndef TS_COLOUR_BLOCKS
+#define TS_COLOUR_BLOCKS 512 /* resident single-wave workgroups of the colour kernel: the throttle (2 per compute unit) */
+#endif
 SideLane *acquire_side_lane()
 {
     constexpr int LANES = 4, MAXDEV = 16;
@@ -198,10 +206,8 @@ SideLane *acquire_side_lane()
         std::lock_guard<std::mutex> lk(mu);
         if (!l.s)
         {
-            int lo = 0, hi = 0; // numerically larger = lower priority
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-            hipStream_t st = nullptr;
-            if (hipStreamCreateWithPriority(&st, hipStreamNonBlocking, lo) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            hipStream_t st = nullptr; // default priority: see above
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
             if (hipEventCreateWithFlags(&l.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&l.join, hipEventDisableTiming) != hipSuccess)
             {
                 (void)hipGetLastError();
@@ -213,6 +219,9 @@ SideLane *acquire_side_lane()
     }
     return &l;
 }
+#else
+struct SideLane; // (lab library only)
+#endif
 
 // Early read-back of the instance count (binning.hip, count_instances_kernel): a pinned host word + an event per call in flight
 struct EarlyCount
@@ -221,7 +230,7 @@ struct EarlyCount
     hipEvent_t ev = nullptr;
 };
 int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state, hipStream_t s,
-                     EarlyCount *early);
+                     EarlyCount *early, SideLane **pending = nullptr);
 bool acquire_early_count(EarlyCount &e)
 {
     constexpr int SLOTS = 64, MAXDEV = 16; // calls that may be between their launch and their wait at the same time, per device
@@ -326,7 +335,6 @@ extern "C" {
 
 const char *ts2d_version(void) { return "ts2d 0.1 (gfx950)"; }
 const char *ts2d_last_error(void) { return g_err.c_str(); }
-uint32_t ts2d_abi_features(void) { return TS2D_FEATURE_PREPARED_RECORDS; }
 
 size_t ts2d_geometry_state_bytes(int32_t P)
 {
@@ -414,7 +422,7 @@ namespace
 // Everything after the instance count is known -- on the host (n_dev == nullptr, N exact: the reference's sequence) or only on
 // the device (n_dev != nullptr, N = the capacity the binning state was carved for).
 int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int64_t N, const unsigned long long *n_dev,
-                        const ts2d_state *state, const ts2d_forward_out *out, hipStream_t s)
+                        const ts2d_state *state, const ts2d_forward_out *out, hipStream_t s, SideLane *pending = nullptr)
 {
     const bool rich = flags & TS2D_FLAG_RICH_INFO;
     const int P = geom->P, W = cam->width, H = cam->height;
@@ -462,6 +470,9 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
         }
         TS_CHECK(flags, s, "tile_ranges");
     }
+#ifdef TS2D_LAB
+    if (pending) TS_HIP(hipStreamWaitEvent(s, pending->join, 0)); // the SH colours: the blend kernel is their first reader
+#endif
     {
         ProfScope ps("render_fwd", s);
 #ifdef TS2D_LAB
@@ -505,42 +516,36 @@ int check_forward_args(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
 
 // preprocess + depth order + instance count on the device (no host read)
 int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state, hipStream_t s,
-                     EarlyCount *early)
+                     EarlyCount *early, SideLane **pending)
 {
+    if (pending) *pending = nullptr;
     const int P = geom->P;
     GeometryStateView g;
     ts_carve_geometry((char *)state->geometry, P, g);
     const PreprocessArgs a = make_pre(cam, geom, flags);
-    // Large scenes: the record half of the per-triangle kernel (and the clear of the gradient records) beside the depth sort, see SideLane.
-    // With the debug flag every kernel is followed by a synchronisation of `s`: keep the single launch there.
-    SideLane *lane = (P >= TS2D_SIDE_STREAM_MIN_TRIANGLES && !(flags & TS2D_FLAG_DEBUG) && ts_preprocess_fwd_splittable(a)
+    SideLane *lane = nullptr;
 #ifdef TS2D_LAB
-                      && !g_lab_no_side_stream
+    // lab library only: the SH colours on a side stream beside the ordering chain (see SideLane: measured, not adopted)
+    if (g_lab_side_stream && P >= 131072 && !(flags & TS2D_FLAG_DEBUG) && ts_preprocess_fwd_splittable(a)) lane = acquire_side_lane();
 #endif
-                      ) ? acquire_side_lane() : nullptr;
-    const bool prepare = flags & TS2D_FLAG_PREPARE_BACKWARD;
-    if (lane)
-    {
-        TS_HIP(hipEventRecord(lane->fork, s));
-        TS_HIP(hipStreamWaitEvent(lane->s, lane->fork, 0));
-        {
-            ProfScope ps("preprocess_records", lane->s);
-            if (flags & TS2D_FLAG_3D) ts_launch_preprocess3d_fwd(a, radii, g, lane->s, 2);
-            else ts_launch_preprocess_fwd(a, radii, g, lane->s, 2);
-        }
-        if (prepare)
-        {
-            ProfScope ps("zero_grad_records", lane->s);
-            ts_launch_zero_words((uint32_t *)g.grad_rec, (size_t)TS_GRAD_FLOATS * (size_t)P, lane->s);
-        }
-        TS_HIP(hipEventRecord(lane->join, lane->s));
-    }
     {
         ProfScope ps("preprocess_fwd", s);
         if (flags & TS2D_FLAG_3D) ts_launch_preprocess3d_fwd(a, radii, g, s, lane ? 1 : 0);
         else ts_launch_preprocess_fwd(a, radii, g, s, lane ? 1 : 0);
     }
     TS_CHECK(flags, s, "preprocess_fwd");
+#ifdef TS2D_LAB
+    if (lane)
+    {
+        TS_HIP(hipEventRecord(lane->fork, s)); // behind the per-triangle kernel: the colour kernel reads its tile counts and writes into its records
+        TS_HIP(hipStreamWaitEvent(lane->s, lane->fork, 0));
+        {
+            ProfScope ps("preprocess_colour", lane->s);
+            ts_launch_preprocess_colour(a, g, (flags & TS2D_FLAG_3D) ? 3 : 2, g_lab_colour_blocks > 0 ? g_lab_colour_blocks : TS_COLOUR_BLOCKS, lane->s);
+        }
+        TS_HIP(hipEventRecord(lane->join, lane->s));
+    }
+#endif
     {
         // the first histogram of the depth sort also sums the instance count and writes it to the pinned host word itself: the host
         // waits for the event behind THIS launch only and allocates the binning buffer while the rest of the sort runs
@@ -558,12 +563,13 @@ int forward_bin_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t
         ts_scan_offsets(g, P, s);
     }
     TS_CHECK(flags, s, "scan");
-    if (lane) TS_HIP(hipStreamWaitEvent(s, lane->join, 0)); // the emission kernel reads the records: the join sits in front of whatever `s` runs next
-    else if (prepare)
+#ifdef TS2D_LAB
+    if (lane)
     {
-        ProfScope ps("zero_grad_records", s);
-        ts_launch_zero_words((uint32_t *)g.grad_rec, (size_t)TS_GRAD_FLOATS * (size_t)P, s);
+        if (pending) *pending = lane; // the caller queues the rest of the forward on `s` and joins in front of the blend kernel
+        else TS_HIP(hipStreamWaitEvent(s, lane->join, 0)); // two-call form: the join sits in front of whatever `s` runs next
     }
+#endif
     return TS2D_OK;
 }
 } // namespace
@@ -585,9 +591,10 @@ int ts2d_forward(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t fla
     if (geom->P == 0) return forward_render_impl(cam, geom, flags, 0, nullptr, state, out, s);
     if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
     if (instance_capacity <= 0) return fail(TS2D_ERR_INVALID, "instance_capacity must be positive");
-    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, nullptr)) return rc;
+    SideLane *pending = nullptr;
+    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, nullptr, &pending)) return rc;
     static const unsigned long long on_device = 0; // any non-null marker: forward_render_impl resolves the real address
-    return forward_render_impl(cam, geom, flags, instance_capacity, &on_device, state, out, s);
+    return forward_render_impl(cam, geom, flags, instance_capacity, &on_device, state, out, s, pending);
 }
 
 int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, uint32_t flags, int32_t *radii, const ts2d_state *state,
@@ -607,12 +614,13 @@ int ts2d_forward_speculative(const ts2d_camera *cam, const ts2d_geometry *geom, 
     if (state->binning && cap <= 0) return fail(TS2D_ERR_CAPACITY, "binning state buffer too small for any instance (pass NULL to size it from num_rendered)");
     EarlyCount early;
     const bool have_early = acquire_early_count(early);
-    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, have_early ? &early : nullptr)) return rc;
+    SideLane *pending = nullptr;
+    if (int rc = forward_bin_impl(cam, geom, flags, radii, state, s, have_early ? &early : nullptr, cap > 0 ? &pending : nullptr)) return rc;
     if (cap > 0)
     {
         // everything behind the count is queued for the CAPACITY before the host has seen the count: the GPU never waits for the host
         static const unsigned long long on_device = 0; // any non-null marker: forward_render_impl resolves the real address
-        if (int rc = forward_render_impl(cam, geom, flags, cap, &on_device, state, out, s)) return rc;
+        if (int rc = forward_render_impl(cam, geom, flags, cap, &on_device, state, out, s, pending)) return rc;
     }
     unsigned long long n = 0;
     if (have_early)
@@ -688,8 +696,7 @@ int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint
     if (!out->dL_dvertex || !out->dL_dcenter2D || !out->dL_dfeature || !out->dL_dopacity || (use_shs && !factored && !out->dL_dshs))
         return fail(TS2D_ERR_INVALID, "gradient outputs are null");
     if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
-    const bool records_ready = flags & TS2D_FLAG_GRAD_RECORDS_READY; // the forward cleared the state's own gradient records (TS2D_FLAG_PREPARE_BACKWARD)
-    if (!records_ready && (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P))) return fail(TS2D_ERR_CAPACITY, "backward scratch too small");
+    if (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P)) return fail(TS2D_ERR_CAPACITY, "backward scratch too small");
     if (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P) || !state->image ||
         state->image_bytes < ts2d_image_state_bytes(W, H) ||
         (N > 0 && (!state->binning || ts_binning_capacity(state->binning_bytes, W, H) < N)))
@@ -701,9 +708,8 @@ int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint
     if (N > 0) ts_carve_binning((char *)state->binning, ts_binning_capacity(state->binning_bytes, W, H), W, H, b); // as the forward carved it
     ts_carve_image((char *)state->image, W, H, im);
     const RenderArgs r = make_render(cam, geom, flags);
-    float *grad_rec = records_ready ? g.grad_rec : (float *)ts_align_up((size_t)scratch);
+    float *grad_rec = (float *)ts_align_up((size_t)scratch);
 
-    if (!records_ready)
     {
         ProfScope ps("zero_grad_records", s);
         // rasterizer.cu:290-300.  A KERNEL, not hipMemsetAsync: captured into a HIP graph (GraphedStep, bench.py --hip-graph) the memset became a
@@ -1196,7 +1202,8 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
 // ts2d_test_sort_pairs / ts2d_test_inclusive_scan_rocprim: csrc/lab_hooks.hip (the rocPRIM comparators live there, outside the product's objects)
 void ts2d_lab_force_ticket_passes(int on) { ts_force_ticket_passes(on != 0); }
 void ts2d_lab_force_all_quadrants(int on) { g_lab_all_quadrants = on != 0; }
-void ts2d_lab_no_side_stream(int on) { g_lab_no_side_stream = on != 0; }
+void ts2d_lab_side_stream(int on) { g_lab_side_stream = on != 0; }
+void ts2d_lab_colour_blocks(int blocks) { g_lab_colour_blocks = blocks; }
 void ts2d_lab_force_depth_pass4(int on) { ts_force_depth_pass4(on != 0); }
 #endif // TS2D_LAB
 

@@ -19,9 +19,8 @@ using namespace ts;
 namespace
 {
 // One triangle.  `vp` = its 9 vertex floats, `shp` = its SH row (3 M floats); either global memory or an LDS row.
-// MODE (ts2d_preprocess_launch.h): PRE_ALL = everything; PRE_GEOMETRY = what the ordering chain needs (radii, tile count, rectangle, depth key);
-// PRE_RECORD = the render record + clamp flags (the same arithmetic up to the cull decisions -- contraction-free, so both instantiations decide
-// alike -- then the SH colour): the half that runs on the library's side stream beside the depth sort.
+// MODE (ts2d_preprocess_launch.h): PRE_ALL = everything; PRE_NOCOLOUR = everything except the SH colour (SH mode only: the record's r g b and the
+// clamp flags are left 0, preprocess_colour_kernel fills them in on the library's side stream beside the ordering chain).
 template <int MODE>
 __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int32_t *__restrict__ radii, const GeometryStateView &g,
                                                    int idx, const float *vp, const float *shp, float4 *rec_row)
@@ -86,10 +85,10 @@ __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int3
         const int rmaxy = min(a.grid_y, max(0, f2i((v_max.y + TS_TILE - 1) / TS_TILE)));
         if (rmaxx <= rminx || rmaxy <= rminy) break;
 
-        if (MODE != PRE_GEOMETRY)
         {
         f3 rgb = {0, 0, 0};
-        if (a.use_shs)
+        if (MODE == PRE_NOCOLOUR) {}
+        else if (a.use_shs)
         {
             const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
             rgb = sh_to_rgb(a.D, shp, center, cp);
@@ -120,15 +119,11 @@ __device__ __forceinline__ void preprocess_fwd_one(const PreprocessArgs &a, int3
         out_radius = f2i(fmaxf(ceilf((v_max.x - v_min.x) * 0.5f), ceilf((v_max.y - v_min.y) * 0.5f))); // forward.cu:192
     } while (false);
 
-    if (MODE != PRE_RECORD)
     {
         radii[idx] = out_radius;
         g.tiles_touched[idx] = out_tiles;
         g.rect[idx] = out_rect;
         g.depth[idx] = out_depth;
-    }
-    if (MODE != PRE_GEOMETRY)
-    {
         g.clamped[idx] = out_clamped;
         float4 *r = rec_row; // the triangle's 64-byte render record: g.rec + 4 idx, or an LDS row the workgroup writes out in one block
         r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);
@@ -286,6 +281,11 @@ void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const Geo
 }
 
 bool ts_preprocess_fwd_splittable(const PreprocessArgs &a) { return preprocess_fwd_splittable(a); }
+void ts_launch_preprocess_colour(const PreprocessArgs &a, const GeometryStateView &g, int variant, int blocks, hipStream_t s)
+{
+    if (variant == 3) launch_preprocess_colour<13>(a, g, blocks, s); // record layouts: ts2d_common.h
+    else launch_preprocess_colour<7>(a, g, blocks, s);
+}
 
 void ts_launch_preprocess_bwd(const PreprocessArgs &a, const int32_t *radii, const GeometryStateView &g,
                               const float *grad_rec, float *dL_dvertex, float *dL_dcenter2D, float *dL_dshs,

@@ -21,7 +21,7 @@ namespace
 __device__ __forceinline__ float proj_to_pix(float v, int S) { return (v + 1.0f) * S * 0.5f - 0.5f; } // R3D auxiliary.h:35-38
 
 // One triangle; `vp` / `shp` = its vertex / SH rows (global memory or LDS, ts2d_preprocess_launch.h).
-template <int MODE> // PRE_ALL / PRE_GEOMETRY / PRE_RECORD, see preprocess.hip
+template <int MODE> // PRE_ALL / PRE_NOCOLOUR, see preprocess.hip
 __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, int32_t *__restrict__ radii, const GeometryStateView &g,
                                                      int idx, const float *vp, const float *shp, float4 *rec_row)
 {
@@ -64,7 +64,7 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
         if (rmaxx <= rminx || rmaxy <= rminy) break;
 
         f3 rgb = {0, 0, 0};
-        if (MODE == PRE_GEOMETRY) {}
+        if (MODE == PRE_NOCOLOUR) {}
         else if (a.use_shs)
         {
             const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
@@ -83,7 +83,7 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
         rec[3] = v2_view.x; rec[4] = v2_view.y; rec[5] = v2_view.z;
         rec[6] = v3_view.x; rec[7] = v3_view.y; rec[8] = v3_view.z;
         rec[9] = normal_view.x; rec[10] = normal_view.y; rec[11] = normal_view.z;
-        rec[12] = MODE == PRE_GEOMETRY ? 0.0f : a.opacity[idx];
+        rec[12] = a.opacity[idx];
         rec[13] = rgb.x; rec[14] = rgb.y; rec[15] = rgb.z;
         out_depth = center_view.z;
         out_tiles = (uint32_t)(rmaxx - rminx) * (uint32_t)(rmaxy - rminy);
@@ -91,15 +91,11 @@ __device__ __forceinline__ void preprocess3d_fwd_one(const PreprocessArgs &a, in
         out_radius = f2i(fmaxf(ceilf((v_max.x - v_min.x) * 0.5f), ceilf((v_max.y - v_min.y) * 0.5f)));
     } while (false);
 
-    if (MODE != PRE_RECORD)
     {
         radii[idx] = out_radius;
         g.tiles_touched[idx] = out_tiles;
         g.rect[idx] = out_rect;
         g.depth[idx] = out_depth;
-    }
-    if (MODE != PRE_GEOMETRY)
-    {
         g.clamped[idx] = out_clamped;
         float4 *r = rec_row; // the triangle's 64-byte render record: g.rec + 4 idx, or an LDS row the workgroup writes out in one block
         r[0] = make_float4(rec[0], rec[1], rec[2], rec[3]);

@@ -85,8 +85,6 @@ struct GeometryStateView
     uint64_t *blocksum;      // ceil(P / 1024) + 2   raw per-block sums of tiles_sorted; [nblocks] = N (scratch of the depth sort's census before that)
     uint64_t *supersum;      // ceil(nblocks / 64) + 1   sums of 64 consecutive block sums (atomics; zeroed by the step's first launch)
     RadixScratchView rs;
-    float *grad_rec;         // P * 16  gradient records (TS_GRAD_FLOATS), zeroed by a forward that was asked to (TS2D_FLAG_PREPARE_BACKWARD) on the
-                             //         side stream; a backward told so (TS2D_FLAG_GRAD_RECORDS_READY) accumulates here and clears nothing
 };
 
 struct BinningStateView
@@ -154,7 +152,6 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.supersum, ((n + 1023) / 1024 + 63) / 64 + 1);
     ts_carve_radix(p, n, v.rs, ts_depth_chunk(n));
     v.top_const = v.rs.tickets + v.rs.slabs + 4;
-    ts_carve(p, v.grad_rec, n * TS_GRAD_FLOATS);
     return (size_t)(p - base) + TS_ALIGN;
 }
 
@@ -240,8 +237,9 @@ struct PreprocessArgs
     const float *vertex, *shs, *feature, *opacity;
 };
 
-void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s, int mode = 0); // mode: ts2d_preprocess_launch.h (PRE_ALL / PRE_GEOMETRY / PRE_RECORD)
+void ts_launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s, int mode = 0); // mode: ts2d_preprocess_launch.h (PRE_ALL / PRE_NOCOLOUR)
 bool ts_preprocess_fwd_splittable(const PreprocessArgs &a);
+void ts_launch_preprocess_colour(const PreprocessArgs &a, const GeometryStateView &g, int variant, int blocks, hipStream_t s); // the SH colours behind a PRE_NOCOLOUR launch
 // binning.hip -- every step hand-written for gfx950 (the round-1 rocPRIM calls survive only as test comparators)
 void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s); // first histogram + N + key-bit census
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s);          // the rest: (depth bits, id) -> sorted ids

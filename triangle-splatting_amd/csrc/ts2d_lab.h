@@ -45,10 +45,12 @@ void ts2d_lab_force_depth_pass4(int on);
  * tests/test_qmask_gpu.py compares the two, bit for bit where the arithmetic is ordered. */
 void ts2d_lab_force_all_quadrants(int on);
 
-/* on != 0: later forwards in this library never fork the side stream -- one per-triangle launch on the caller's stream, the gradient records
- * (TS2D_FLAG_PREPARE_BACKWARD) cleared on it behind the scan: the A/B partner of the product's sequence (tools/ab_side_stream.sh) and the
- * reference for tests/test_side_stream_gpu.py (both sequences must leave the same state and outputs, bit for bit). */
-void ts2d_lab_no_side_stream(int on);
+/* Round 6, a measured negative result kept reproducible (csrc/api.hip: SideLane; profiles/r06_side_stream.txt): on != 0 -> SH scenes of 131 072
+ * triangles and more run the per-triangle kernel WITHOUT the SH colours and evaluate those with a throttled kernel on a library-owned stream,
+ * forked behind the per-triangle kernel and joined in front of the blend kernel (bench.py --side-stream [--colour-blocks n]; n = the colour
+ * kernel's grid = its throttle).  State and outputs are those of the single launch, bit for bit (tests/test_side_stream_gpu.py). */
+void ts2d_lab_side_stream(int on);
+void ts2d_lab_colour_blocks(int blocks);
 
 #ifdef __cplusplus
 }

@@ -17,12 +17,13 @@
 #endif
 namespace ts
 {
-// Which half of the per-triangle forward a launch computes (api.hip: forward_bin_impl).  The ordering chain -- depth sort, scan -- needs four words
-// per triangle (radii, tile count, rectangle, depth key: 36 bytes in, 20 out); the render record with its SH colour (228 of the 327 bytes per
-// triangle at SH degree 3) is first read by the emission kernel behind the scan.  PRE_GEOMETRY runs on the caller's stream in front of the depth
-// sort, PRE_RECORD on the library's side stream BESIDE it (the sort is a latency chain that leaves the HBM idle); PRE_ALL = both in one launch
-// (small scenes, unaligned inputs).
-enum { PRE_ALL = 0, PRE_GEOMETRY = 1, PRE_RECORD = 2 };
+// What a launch of the per-triangle forward computes (api.hip: forward_bin_impl).  The ordering chain -- depth sort, scan, emission, tile sort --
+// needs the integer state and the geometric part of the render record; the SH colour (192 of the 327 bytes per triangle the kernel moves at SH
+// degree 3) is first read by the blend kernel.  PRE_NOCOLOUR runs on the caller's stream and leaves r g b / the clamp flags 0;
+// preprocess_colour_kernel fills them in on the library's side stream BESIDE the ordering chain (a chain of latency-bound launches that leaves the
+// HBM mostly idle), throttled to a few hundred resident waves so that it does not stretch that chain's memory round trips.  PRE_ALL = one launch
+// (small scenes, feature mode, short SH rows, unaligned inputs).
+enum { PRE_ALL = 0, PRE_NOCOLOUR = 1 };
 
 // The binning kernels' "last block finishes" tickets (binning.hip) are zeroed by the first launch of the step.  Every grid has at
 // least 64 threads and slabs + TS_RS_TICKET_EXTRA <= max(P, 64), so the threads beyond P of a tiny scene take part.  The slab totals of the
@@ -52,16 +53,6 @@ __global__ void __launch_bounds__(256) preprocess_fwd_direct_kernel(PreprocessAr
 template <class Body, int SHROW, bool SH_REGS, int MODE>
 __global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
 {
-    if (MODE == PRE_GEOMETRY) // no colour, no record: vertex rows in, four words per triangle out
-    {
-        __shared__ float s_vg[64 * 9];
-        const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
-        stage_rows_in<9, 9>(s_vg, a.vertex, row0, a.P, lane);
-        __syncthreads();
-        clear_tickets(g, idx, a.P);
-        if (idx < a.P) Body::template fwd<PRE_GEOMETRY>(a, radii, g, idx, s_vg + lane * 9, (const float *)nullptr, (float4 *)nullptr);
-        return;
-    }
     __shared__ float s_v[64 * 9];
     __shared__ float s_sh[(SHROW > 0 && !SH_REGS) ? 64 * (SHROW + 1) : 1];
     const int lane = threadIdx.x, row0 = blockIdx.x * 64, idx = row0 + lane;
@@ -75,14 +66,14 @@ __global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArg
     stage_rows_in<9, 9>(s_v, a.vertex, row0, a.P, lane);
     if (SHROW > 0 && !SH_REGS) stage_rows_in<SHROW, SHROW + 1>(s_sh, a.shs, row0, a.P, lane);
     __syncthreads();
-    if (MODE == PRE_ALL) clear_tickets(g, idx, a.P); // (PRE_RECORD runs beside the sort that the tickets belong to)
+    clear_tickets(g, idx, a.P);
     // the 64 render records of the workgroup are one contiguous 4 KB block: each lane parks its record in LDS (row stride 80 bytes:
     // conflict-free 128-bit accesses) and the block leaves with coalesced dwordx4 stores instead of four stores at a 64-byte lane stride
     __shared__ float4 s_rec[64 * 5];
     if (idx < a.P)
     {
         const float *shp = SHROW > 0 ? (SH_REGS ? shr : s_sh + lane * (SHROW + 1)) : (a.use_shs ? a.shs + (size_t)idx * a.M * 3 : nullptr);
-        Body::template fwd<(MODE == PRE_RECORD ? PRE_RECORD : PRE_ALL)>(a, radii, g, idx, s_v + lane * 9, shp, s_rec + lane * 5);
+        Body::template fwd<MODE>(a, radii, g, idx, s_v + lane * 9, shp, s_rec + lane * 5);
     }
     __syncthreads();
     float4 *out = g.rec + 4 * (size_t)row0;
@@ -167,14 +158,55 @@ __global__ void __launch_bounds__(64) preprocess_bwd_staged_kernel(PreprocessArg
 // element is written).  M outside {1, 4, 9, 16} never stages SH rows.
 static inline int staged_shrow(const PreprocessArgs &a) { return (a.use_shs && (a.M == 1 || a.M == 4 || a.M == 9 || a.M == 16)) ? 3 * a.M : 0; }
 
-// Can the per-triangle forward of these arguments run as two launches (PRE_GEOMETRY + PRE_RECORD)?  Only the staged kernels have the two halves.
-static inline bool preprocess_fwd_splittable(const PreprocessArgs &a) { return a.P > 0 && aligned16(a.vertex); }
+// The SH colour of the triangles that survived the culls, written into their render records behind a PRE_NOCOLOUR launch: floats REC_OFF..+2 of
+// the record (2D: 7, 3D: 13) and the clamp flags.  A persistent grid of single-wave workgroups (grid = the throttle): wave w takes the 64-triangle
+// blocks w, w + grid, ...; a lane whose triangle was culled (no tiles) loads nothing -- a view that sees a fraction of the scene reads that fraction
+// of the SH rows.  Same expressions as the single launch (sh_to_rgb on the world-space centroid, forward.cu:165-171, 51-58): same bits.
+template <int SHROW, int REC_OFF>
+__global__ void __launch_bounds__(64) preprocess_colour_kernel(PreprocessArgs a, GeometryStateView g)
+{
+    static_assert(SHROW % 4 == 0, "rows of whole 16-byte pieces");
+    const int lane = threadIdx.x;
+    const f3 cp = {a.campos[0], a.campos[1], a.campos[2]};
+    for (int row0 = blockIdx.x * 64; row0 < a.P; row0 += gridDim.x * 64)
+    {
+        const int idx = row0 + lane;
+        if (idx >= a.P || g.tiles_touched[idx] == 0u) continue;
+        float shr[SHROW];
+        const float4 *rowp = (const float4 *)(a.shs + (size_t)idx * SHROW);
+#pragma unroll
+        for (int c = 0; c < SHROW / 4; c++) *(float4 *)(shr + 4 * c) = rowp[c];
+        const float *vp = a.vertex + 9 * (size_t)idx;
+        const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
+        const f3 center = divf(add(add(v1, v2), v3), 3.0f);
+        f3 rgb = sh_to_rgb(a.D, shr, center, cp);
+        g.clamped[idx] = (uint8_t)((rgb.x < 0 ? 1 : 0) | (rgb.y < 0 ? 2 : 0) | (rgb.z < 0 ? 4 : 0));
+        float *rec = (float *)(g.rec + 4 * (size_t)idx) + REC_OFF;
+        rec[0] = fmaxf(rgb.x, 0.0f); rec[1] = fmaxf(rgb.y, 0.0f); rec[2] = fmaxf(rgb.z, 0.0f);
+    }
+}
+
+// Can the SH colour of these arguments be split off (PRE_NOCOLOUR + preprocess_colour_kernel)?  SH rows of whole 16-byte pieces that are worth a
+// launch of their own (M = 4 or 16), aligned inputs (the staged kernels).
+static inline bool preprocess_fwd_splittable(const PreprocessArgs &a)
+{
+    return a.P > 0 && a.use_shs && (a.M == 4 || a.M == 16) && aligned16(a.vertex) && aligned16(a.shs);
+}
+
+template <int REC_OFF>
+void launch_preprocess_colour(const PreprocessArgs &a, const GeometryStateView &g, int blocks, hipStream_t s)
+{
+    const int nb = (a.P + 63) / 64;
+    const dim3 grid(blocks < nb ? blocks : nb), block(64);
+    if (a.M == 16) hipLaunchKernelGGL((preprocess_colour_kernel<48, REC_OFF>), grid, block, 0, s, a, g);
+    else hipLaunchKernelGGL((preprocess_colour_kernel<12, REC_OFF>), grid, block, 0, s, a, g);
+}
 
 template <class Body, int MODE>
 void launch_preprocess_fwd_mode(const PreprocessArgs &a, int32_t *radii, const GeometryStateView &g, hipStream_t s)
 {
     const int shrow = staged_shrow(a);
-    const bool sh_in = MODE != PRE_GEOMETRY && shrow > 0 && 2 * (a.D + 1) * (a.D + 1) >= a.M && aligned16(a.shs);
+    const bool sh_in = MODE != PRE_NOCOLOUR && shrow > 0 && 2 * (a.D + 1) * (a.D + 1) >= a.M && aligned16(a.shs);
     const dim3 grid((a.P + 63) / 64), block(64);
     switch (sh_in ? shrow : 0)
     {
@@ -195,8 +227,7 @@ void launch_preprocess_fwd(const PreprocessArgs &a, int32_t *radii, const Geomet
         hipLaunchKernelGGL((preprocess_fwd_direct_kernel<Body>), dim3((a.P + 255) / 256), dim3(256), 0, s, a, radii, g);
         return;
     }
-    if (mode == PRE_GEOMETRY) launch_preprocess_fwd_mode<Body, PRE_GEOMETRY>(a, radii, g, s);
-    else if (mode == PRE_RECORD) launch_preprocess_fwd_mode<Body, PRE_RECORD>(a, radii, g, s);
+    if (mode == PRE_NOCOLOUR) launch_preprocess_fwd_mode<Body, PRE_NOCOLOUR>(a, radii, g, s);
     else launch_preprocess_fwd_mode<Body, PRE_ALL>(a, radii, g, s);
 }
 

@@ -39,7 +39,6 @@ if not os.path.exists(_LIB_PATH):
 _lib = C.CDLL(_LIB_PATH)
 
 FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS, FLAG_3D, FLAG_SH_FACTORED = 1, 2, 4, 8, 16, 32
-FLAG_PREPARE_BACKWARD, FLAG_GRAD_RECORDS_READY = 64, 128
 MAX_CHANNELS = 3
 
 _fp = C.c_void_p
@@ -122,14 +121,6 @@ _lib.ts2d_profile_read.restype = C.c_int
 _lib.ts2d_profile_read.argtypes = [C.c_int32, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
 
 
-# A library from before round 6 (measurement only: TS2D_LIBRARY_PATH pointing at an older build for an A/B) has no gradient records in its
-# geometry state: the package then never asks for them.
-HAS_PREPARED_RECORDS = False
-if hasattr(_lib, "ts2d_abi_features"):
-    _lib.ts2d_abi_features.restype = C.c_uint32
-    HAS_PREPARED_RECORDS = bool(_lib.ts2d_abi_features() & 1)
-
-
 def set_capacity_hint_key(key: int) -> None:
     """Names the stream of views the calling thread's next forwards belong to (ts2d_set_capacity_hint_key): the speculative forward sizes its
     binning buffer from the history of (device, variant, image size, key).  Train and evaluation cameras of one size, or two models in one
@@ -209,14 +200,12 @@ def _state(geometryBuffer, binningBuffer, imageBuffer) -> _State:
 
 def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma,
                         scale_modifier, background_depth, background, vertex, shs, feature, opacity, back_culling,
-                        rich_info, debug, *, variant=2, instance_capacity=None, prepare_backward=False):
+                        rich_info, debug, *, variant=2, instance_capacity=None):
     """`variant=3` selects the 3D rasterizer (TS2D_FLAG_3D; used by the sibling package diff_triangle_rasterization_3D).
     `instance_capacity` (an int > 0) selects the SYNC-FREE forward (ts2d_forward): the binning state is sized for that many tile
     instances, nothing is read back, and the returned `num_rendered` is the capacity (it only sizes the state for the backward
     call); whether the true count fitted is reported by `forward_status`.  Default None = the reference's sequence with its one
-    blocking read of num_rendered.
-    `prepare_backward=True` (TS2D_FLAG_PREPARE_BACKWARD): the forward also clears the gradient records inside the geometry state, on the
-    library's side stream; the backward of THIS forward may then be called with `records_ready=True` (once)."""
+    blocking read of num_rendered."""
     P = vertex.size(0)
     H, W = int(image_height), int(image_width)
     use_shs = _use_shs(shs, feature)
@@ -269,8 +258,7 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
                     torch.empty((0,), **u8), torch.empty((0,), **u8))
 
         flags = ((FLAG_BACK_CULLING if back_culling else 0) | (FLAG_RICH_INFO if rich_info else 0) |
-                 (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) | (FLAG_3D if variant == 3 else 0) |
-                 (FLAG_PREPARE_BACKWARD if (prepare_backward and HAS_PREPARED_RECORDS) else 0))
+                 (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) | (FLAG_3D if variant == 3 else 0))
         cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
         geometryBuffer = torch.empty((_lib.ts2d_geometry_state_bytes(P),), **u8)
@@ -307,16 +295,13 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
 def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                                  background_depth, background, vertex, shs, feature, opacity, num_rendered, radii,
                                  geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
-                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False, out=None, range_events=None,
-                                 records_ready=False):
+                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False, out=None, range_events=None):
     """`sh_factored=True` (SH mode only; TS2D_FLAG_SH_FACTORED): dL_dshs is not formed (returned as None) and the fourth
     result holds the clamp-masked colour gradient dL_dRGB (P, 3) for `sh_grad_expand` -- see parallel.py.
     `out`: optional dict of preallocated contiguous float32 device tensors ("vertex" (P,3,3), "center2D" (P,2), "opacity" (P,1),
     "color" = dL_dshs (P,M,3) or dL_dfeature (P,C)) that the library writes instead of fresh allocations (parallel.GradBucket).
     `range_events`: a list of K torch.cuda.Event (each recorded at least once before): the per-triangle kernel runs as K launches over
-    consecutive triangle ranges of `backward_range_rows(P, K)` rows and event k is recorded behind range k (ts2d_backward_ranged).
-    `records_ready=True` (TS2D_FLAG_GRAD_RECORDS_READY): the forward that filled these buffers ran with `prepare_backward=True` and no backward
-    has used its gradient records since -- nothing is cleared and no scratch is allocated."""
+    consecutive triangle ranges of `backward_range_rows(P, K)` rows and event k is recorded behind range k (ts2d_backward_ranged)."""
     P = vertex.size(0)
     H, W = dL_dout_feature.size(1), dL_dout_feature.size(2)  # extension_interface.cu:182-183
     use_shs = _use_shs(shs, feature)
@@ -360,14 +345,14 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
         if P == 0:
             return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
         flags = ((FLAG_RICH_INFO if rich_info else 0) | (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) |
-                 (FLAG_3D if variant == 3 else 0) | (FLAG_SH_FACTORED if sh_factored else 0) | (FLAG_GRAD_RECORDS_READY if records_ready else 0))
+                 (FLAG_3D if variant == 3 else 0) | (FLAG_SH_FACTORED if sh_factored else 0))
         cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
         st = _state(geometryBuffer, binningBuffer, imageBuffer)
         loss = _LossGrads(_ptr(dL_dout_feature), _ptr(dL_dout_depth) if rich_info else None,
                           _ptr(dL_dout_normal) if rich_info else None)
-        scratch = None if records_ready else torch.empty((_lib.ts2d_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
-        scratch_bytes = 0 if scratch is None else scratch.numel()
+        scratch = torch.empty((_lib.ts2d_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+        scratch_bytes = scratch.numel()
         out = _BackwardOut(_ptr(dL_dvertex), _ptr(dL_dcenter2D), _ptr(dL_dshs), _ptr(dL_dfeature), _ptr(dL_dopacity))
         if range_events:
             handles = (_fp * len(range_events))(*[int(e.cuda_event) for e in range_events])

@@ -157,14 +157,10 @@ class _RasterizeTriangles(torch.autograd.Function):
             bg_depth = float(bg_depth)
         native_args = (rs.image_width, rs.image_height) + _camera_and_geometry_args(rs, bg_depth) + (
             vertex, shs, feature, opacity, rs.back_culling, rs.rich_info, rs.debug)
-        # a backward will follow: the forward clears the gradient records it accumulates into (they live in the geometry state) on the
-        # library's side stream, beside the depth sort, instead of the backward clearing a scratch buffer in front of its blend kernel
-        prepare = bool(ctx.needs_input_grad[0] or ctx.needs_input_grad[2] or ctx.needs_input_grad[3] or ctx.needs_input_grad[4])
-        ctx.records_ready = prepare and vertex.shape[0] > 0 and _C.HAS_PREPARED_RECORDS
         with _snapshot_on_error("rasterize_triangles", native_args, rs.debug):
             (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max,
              geometryBuffer, binningBuffer, imageBuffer) = _C.rasterize_triangles(
-                *native_args, variant=ctx._forward_cls._variant, prepare_backward=prepare,
+                *native_args, variant=ctx._forward_cls._variant,
                 instance_capacity=(_instance_capacity(vertex.shape[0], rs.image_width, rs.image_height) if callable(_instance_capacity)
                                    else _instance_capacity) if vertex.shape[0] > 0 else None)
 
@@ -224,10 +220,8 @@ class _RasterizeTriangles(torch.autograd.Function):
             # a bucket prepared for a ranged exchange (GradBucket.prepare_ranges): the per-triangle kernel runs range by range with an event behind
             # each, so that the exchange of range k overlaps range k + 1 -- only for the backward that WRITES the bucket (the first under a capture)
             ranged = place is not None and getattr(bucket, "range_events", None)
-            ready, ctx.records_ready = getattr(ctx, "records_ready", False), False  # a second backward through this forward clears a scratch itself
             g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(
-                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place, range_events=ranged or None,
-                records_ready=ready)
+                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place, range_events=ranged or None)
             if ranged:
                 bucket._ranges_recorded = True
             if sink is not None:
