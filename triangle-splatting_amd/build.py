@@ -41,7 +41,10 @@ SOURCES = {
     "model_update.hip": [],
     "optim.hip": ["-ffp-contract=off"],
     "binning.hip": [],
-    "render_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
+    # the 2D blend kernels: ONE source, two translation units (TSG_PART), so that each kernel gets the machine-scheduler strategy it measured best
+    # with (round 5, profiles/r05_sched_strategies.txt: max-ilp +1.3 % for the forward, -1 % for the backward; round 6: profiles/r06_blend_ab.txt)
+    "render_group.hip@fwd": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize", "-DTSG_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],
+    "render_group.hip@bwd": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize", "-DTSG_PART=2"],
     "render3d_group.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize"],
     "api.hip": [],
 }
@@ -96,8 +99,9 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
         os.makedirs(os.path.join(OBJ_DIR, "lab"), exist_ok=True)
         os.makedirs(os.path.dirname(LAB_LIB), exist_ok=True)
     for src, extra in sources.items():
+        src, _, part = src.partition("@")  # "file.hip@tag": the same source compiled into file_tag.o with its own flags
         s = os.path.join(CSRC, os.path.basename(src))
-        o = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        o = os.path.join(OBJ_DIR, src.replace(".hip", ("_" + part if part else "") + ".o"))
         objs.append(o)
         cmd = [cc, *COMMON, *extra, "-c", s, "-o", o]
         # the object is only reused when it was produced by this very command line with this very compiler: a profiling build

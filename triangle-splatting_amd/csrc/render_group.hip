@@ -48,6 +48,12 @@
 #ifndef TSG_TCAP
 #define TSG_TCAP 960
 #endif
+#ifndef TSG_PART // which kernels this translation unit holds: 1 = forward, 2 = backward, 3 = both.  build.py compiles the file twice, so that each
+#define TSG_PART 3 // kernel gets its own scheduler strategy (round 6: max-ilp is +1.3 % for the forward and -1 % for the backward, profiles/r05_notes.md)
+#endif
+#ifndef TSG_CARRY // 1: a batch with more than NR surviving entries hands the ones beyond the table to the NEXT batch instead of taking a second pass
+#define TSG_CARRY 1
+#endif
 #ifndef TSG_PROBE
 #define TSG_PROBE 0 // profiling builds: 1 = no contribution atomics, 2 = no contribution statistics at all, 3 = no serialised accumulate,
                     // 4 = backward without its step loop (what the per-batch work alone costs), 6 = backward without the row flush,
@@ -61,7 +67,7 @@ namespace
 // entry's 16 gradient sums to the row (BROW floats).  A list entry is the LDS BYTE OFFSET of its row (u16): the step loops spend no
 // instruction on unpacking or scaling an index (round 3: four half-rate instructions per step gone; gfx950 issues shifts, bit-field
 // extracts and 24-bit multiply-adds at half rate, tools/valu_bench3.hip).
-constexpr int BROW = ROW + 16;
+[[maybe_unused]] constexpr int BROW = ROW + 16;
 
 struct BlockCull
 {
@@ -179,6 +185,7 @@ __device__ unsigned long long g_stats_group[12];
 #define TSG_STAT(i, v)
 #endif
 
+#if TSG_PART & 1
 template <bool RICH, bool GAMMA1>
 __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                                 const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
@@ -234,12 +241,13 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
 #endif
     // dense batches: only the entries whose quadrant bit is set are gathered and culled (ts2d_group.h, stream_refill); `pos` = list position
     uint32_t id = 0;
-    int pos = 0, cursor = 0;
+    int pos = 0, cursor = 0, carried = 0; // carried: entries of the previous batch that did not fit its table (lanes [0, carried) of id / pos)
     for (;;)
     {
         const unsigned long long alive = ballot(!done);
         if (alive == 0) break;
-        int nq = 0;
+        int nq = TSG_CARRY ? carried : 0;
+        carried = 0;
         stream_refill<false, TSG_FWD_CAP>(id, pos, nq, point_list + range.x, cursor, len, TS_ID_BITS + wave, lane);
         if (nq == 0) break;
         const bool valid = lane < nq;
@@ -270,7 +278,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
         const int r = rank & (NR - 1);
         bool mine = anybit && rank < NR;
         if (mine) publish_row(cst + r * ROW, s, id, ent, r1, r2, r3);
-        for (int h = 0;;)
+        for ([[maybe_unused]] int h = 0;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
             list[lane] = dummy | (dummy << 16); // four lists x NR entries: the dummy row
@@ -365,9 +373,16 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
                 }
 #endif
             }
+#if TSG_CARRY
+            // more survivors than table rows: the ones beyond the table open the NEXT batch (one more gather + cull of a few lanes that the batch
+            // runs anyway) instead of a second pass of their own with its list build and its short lockstep loop -- group_sim: -26 % passes
+            if (nact > NR) carried = carry_over(id, pos, anybit && rank >= NR, lane);
+            break;
+#else
             if (++h * NR >= nact) break;
             mine = anybit && rank >= NR;
             if (mine) republish_row<RICH>(cst + r * ROW, point_list, rec, range.x + pos, ent, OX, OY);
+#endif
         }
     }
 
@@ -417,6 +432,8 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
     }
 }
 
+#endif // TSG_PART & 1
+
 // Backward.  Per (pixel, triangle) pair the reference adds 16 values into per-triangle arrays (backward.cu:412-490); here the
 // pair's 16 values are formed per lane exactly in the reference's per-pixel form (no moment / epilogue algebra):
 //   dL/dv_j (screen space) = perp(t_j) / area2 with  t_1 = e_3 p_v2 - e_2 p_v3,  t_2 = e_1 p_v3 - e_3 p_v1,  t_3 = e_2 p_v1 - e_1 p_v2,
@@ -430,6 +447,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
 // them as single-wave workgroups (WPB = 1): the dispatcher then fills a freed wave slot with the next quadrant instead of waiting for
 // four slots of one CU, which shortens the tail of the launch (8160 tiles are only 5.3 rounds of 256-thread workgroups).  The four
 // quadrants of a tile stay neighbours in dispatch order and on one XCD (shared L2 for the tile's list and records).
+#if TSG_PART & 2
 template <bool RICH, bool GAMMA1, int WPB>
 __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kernel(RenderArgs a, const uint2 *__restrict__ ranges,
                                                                    const uint32_t *__restrict__ point_list, const float4 *__restrict__ rec,
@@ -521,10 +539,11 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
 
     // dense batches, walked back to front: lane 0 holds the entry farthest back (ts2d_group.h, stream_refill<true>); `pos` = list position
     uint32_t id = 0;
-    int pos = 0, cursor = maxlast;
+    int pos = 0, cursor = maxlast, carried = 0;
     for (;;)
     {
-        int nq = 0;
+        int nq = TSG_CARRY ? carried : 0;
+        carried = 0;
         stream_refill<true, TSG_BWD_CAP>(id, pos, nq, point_list + range.x, cursor, maxlast, TS_ID_BITS + quad, lane);
         if (nq == 0) break;
         const bool valid = lane < nq;
@@ -548,7 +567,7 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
         const int r = rank & (NR - 1);
         bool mine = anybit && rank < NR;
         if (mine) publish_row(rows + r * BROW, s, id, ent, r1, r2, r3);
-        for (int h = (nact - 1) / NR;;)
+        for ([[maybe_unused]] int h = (nact - 1) / NR;;)
         {
             const unsigned long long mm = nact <= NR ? any : ballot(mine);
             if (mine)
@@ -685,14 +704,21 @@ __global__ void __launch_bounds__(64 * WPB, TSG_BWD_WAVES) render_bwd_group_kern
                     }
                 }
             }
+#if TSG_CARRY
+            if (nact > NR) carried = carry_over(id, pos, anybit && rank >= NR, lane); // see the forward
+            break;
+#else
             if (--h < 0) break;
             mine = anybit && rank >= NR;
             if (mine) republish_row<RICH>(rows + r * BROW, point_list, rec, range.x + pos, ent, OX, OY);
+#endif
         }
     }
 }
+#endif // TSG_PART & 2
 } // namespace
 
+#if TSG_PART & 1
 #define TS_DISPATCH_G(KERNEL, ...)                                                                                    \
     do                                                                                                                \
     {                                                                                                                 \
@@ -713,7 +739,9 @@ void ts_launch_render_fwd_group(const RenderArgs &a, const GeometryStateView &g,
                   contrib_sum, contrib_max);
 }
 
-#ifdef TS2D_STATS
+#endif // TSG_PART & 1
+
+#if defined(TS2D_STATS) && (TSG_PART & 1)
 extern "C" __attribute__((visibility("default"))) int ts2d_stats_read_group(unsigned long long *out, int reset)
 {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stats_group), sizeof(unsigned long long) * 12);
@@ -726,6 +754,7 @@ extern "C" __attribute__((visibility("default"))) int ts2d_stats_read_group(unsi
 }
 #endif
 
+#if TSG_PART & 2
 void ts_launch_render_bwd_group(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b, const ImageStateView &im,
                                 const float *dL_dout_feature, const float *dL_dout_depth, const float *dL_dout_normal, float *grad_rec,
                                 hipStream_t s)
@@ -743,3 +772,4 @@ void ts_launch_render_bwd_group(const RenderArgs &a, const GeometryStateView &g,
     else TS_BWD(false, false);
 #undef TS_BWD
 }
+#endif // TSG_PART & 2

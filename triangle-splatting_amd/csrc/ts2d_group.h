@@ -60,6 +60,18 @@ __device__ __forceinline__ void stream_refill(uint32_t &id, int &pos, int &n, co
     }
 }
 
+// The entries of a batch flagged `keep` move to lanes [0, n) of (id, pos), in lane order (= processing order); returns n.  One ballot, one
+// permutation of the 64 lanes -- the same move as stream_refill's.  The next stream_refill appends behind them.
+__device__ __forceinline__ int carry_over(uint32_t &id, int &pos, bool keep, int lane)
+{
+    const unsigned long long mk = ballot(keep);
+    const int cnt = __popcll(mk), rk = lane_rank(mk);
+    const int dest = keep ? rk : cnt + (lane - rk); // kept lanes to the front, the others behind them: a permutation
+    id = (uint32_t)__builtin_amdgcn_ds_permute(dest << 2, (int)id);
+    pos = __builtin_amdgcn_ds_permute(dest << 2, pos);
+    return cnt;
+}
+
 // ---- 16-lane (DPP row) transpose-reduce: N values per lane -> each lane keeps the row-wide reduction of ONE value ----
 // Level 1 pairs lanes l, l ^ 8 (row_ror:8), level 2 lanes inside a group of 8 (row_half_mirror), level 3 l, l ^ 2, then l, l ^ 1.
 struct RowSel
