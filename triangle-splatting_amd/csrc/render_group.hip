@@ -52,8 +52,9 @@
 #define TSG_PART 3 // kernel gets its own scheduler strategy (round 6: max-ilp is +1.3 % for the forward and -1 % for the backward, profiles/r05_notes.md)
 #endif
 #ifndef TSG_CARRY // 1: a batch with more than NR surviving entries hands the ones beyond the table to the NEXT batch instead of taking a second pass
-#define TSG_CARRY 1
-#endif
+#define TSG_CARRY 0 // ("carried-over table", DESIGN 14 / VERDICT r5 item 3 (i): group_sim -26 % passes.  Built and measured in round 6, parity-green:
+#endif              // render_fwd 0.382 -> 0.403 ms, render_bwd 0.792 -> 0.806 -- the carried entries take slots of the next batch, i.e. MORE batches, each
+                    // with its full cull and list build, where a second pass had neither; profiles/r06_blend_ab.txt)
 #ifndef TSG_PROBE
 #define TSG_PROBE 0 // profiling builds: 1 = no contribution atomics, 2 = no contribution statistics at all, 3 = no serialised accumulate,
                     // 4 = backward without its step loop (what the per-batch work alone costs), 6 = backward without the row flush,
