@@ -85,6 +85,15 @@ int tsl_scharr_smoothness_forward(const float *image, const float *mask, int32_t
 int tsl_scharr_smoothness_backward(const float *image, const float *mask, int32_t channels, int32_t height, int32_t width, void *workspace,
                                    size_t workspace_bytes, const float *grad_out, float *dL_dimage, void *stream);
 
+/* ---- the down-sampler of render_up_scale ----------------------------------------------------------------------------------------------
+ * F.interpolate(x, size=(h, w), mode="bilinear") of VanillaTS_model.py:649-656 for an INTEGER factor (H = f h, W = g w, f, g >= 2 -- render_up_scale
+ * = 2 in the NerfSynthetic *_mesh configuration): planar float32 (C, H, W) -> (C, h, w), PyTorch's source-index arithmetic in float32, and its
+ * backward in gather form (torch's upsample_bilinear2d_backward scatters with atomics): both fully written, run-to-run identical. */
+int tsl_downsample_forward(const float *in, int32_t channels, int32_t in_height, int32_t in_width, int32_t out_height, int32_t out_width, float *out,
+                           void *stream);
+int tsl_downsample_backward(const float *grad_out, int32_t channels, int32_t in_height, int32_t in_width, int32_t out_height, int32_t out_width,
+                            float *grad_in, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

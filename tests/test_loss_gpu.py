@@ -305,3 +305,27 @@ def test_aux_losses_full_size_against_oracle_and_surface():
         SmoothnessLoss()(torch.zeros(3, 8, 8, device="cuda"), torch.zeros(3, 8, 8, device="cuda", requires_grad=True))
     with pytest.raises(RuntimeError, match="at most 8 channels"):
         DoGLoss()(torch.zeros(3, 3, 8, 8, device="cuda"), torch.zeros(3, 3, 8, 8, device="cuda"))
+
+
+@pytest.mark.parametrize("shape,factor", [((3, 64, 96), 2), ((1, 30, 45), 3), ((2, 3, 40, 56), 4), ((3, 1600, 1600), 2), ((16, 24), 2)])
+def test_downsample_bilinear_equals_interpolate_and_its_autograd(shape, factor):
+    """Round 6: the resize behind a render at render_up_scale x the resolution (VanillaTS_model.py:649-656, F.interpolate(..., mode="bilinear")) as
+    one gather kernel each way (csrc/resample.hip) -- against torch's own kernels: forward to 1 ulp-ish, backward against autograd (whose
+    upsample_bilinear2d_backward scatters with atomics)."""
+    import torch.nn.functional as F
+    from diff_recon_hip import downsample_bilinear
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand(shape, device="cuda", generator=g).requires_grad_(True)
+    H, W = shape[-2:]
+    h, w = H // factor, W // factor
+    y = downsample_bilinear(x, (h, w))
+    x4 = x.reshape((1, -1, H, W)) if x.dim() != 4 else x
+    ref = F.interpolate(x4, size=(h, w), mode="bilinear").reshape(y.shape)
+    assert y.shape == tuple(shape[:-2]) + (h, w)
+    assert float((y - ref).abs().max()) < 2e-7
+    up = torch.rand(y.shape, device="cuda", generator=g)
+    (gx,) = torch.autograd.grad(y, x, up)
+    (gr,) = torch.autograd.grad(ref, x, up)
+    assert float((gx - gr).abs().max()) < 2e-7
+    with pytest.raises(RuntimeError):
+        downsample_bilinear(x, (h + 1, w))  # not an integer factor

@@ -46,4 +46,15 @@ prof() { local n=$1; shift; rm -rf $O/prof_$n; (cd /tmp && timeout 900 rocprofv3
 pmc() { local n=$1 c=$2; shift 2; rm -rf $O/pmc_$n; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n -o $n --output-format csv -- python $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 --settle-steps 0 --no-kernel-events "$@" > $O/pmc_$n.log 2>&1)
     f=$(find $O/pmc_$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $f | tee $O/${n}_pmc.txt; rm -rf $O/pmc_$n; }
 
+# train <config> [args]: one line of tools/bench_train_step.py appended to train_step.jsonl
+train() { timeout 900 python tools/bench_train_step.py --config "$@" 2>$O/train_$1.err | tee -a $O/train_step.jsonl | python -c "
+import json,sys
+for l in sys.stdin:
+    if not l.startswith('{'): continue
+    j=json.loads(l); k=j['kernels']
+    print(j['config'], 'eager', j['iteration_ms_eager'], 'graph', j['iteration_ms_graph'], j['graph_note'] or '', 'raster', j['raster_step_ms'], 'diff', j['iteration_minus_raster_ms'], 'glue', j['torch_glue_ms_per_iteration'])
+    print('   ', ' '.join('%s=%.4f(%s)' % (n, e['avg_ms'], e.get('hbm_frac','-')) for n,e in k.items() if n not in ('depth_census','depth_sort','scan','emit_keys','tile_sort','tile_ranges')))"; }
+# loss [H W]: tools/bench_loss.py (the fused L1 + SSIM against the eager-torch kernel sequence)
+loss() { timeout 600 python tools/bench_loss.py "$@" 2>/dev/null | tee -a $O/loss_bench.jsonl; }
+
 eval "$@"

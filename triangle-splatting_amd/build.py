@@ -37,6 +37,7 @@ SOURCES = {
     "photometric.hip": [],
     "depth_normal.hip": ["-ffp-contract=off"],
     "aux_losses.hip": ["-ffp-contract=off"],
+    "resample.hip": ["-ffp-contract=off"],
     "knn.hip": [],
     "model_update.hip": [],
     "optim.hip": ["-ffp-contract=off"],

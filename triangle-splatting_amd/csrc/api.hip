@@ -870,6 +870,31 @@ int tsl_depth_normal_backward(const float *depth, const float *normal, int32_t h
     return TS2D_OK;
 }
 
+// ---- the down-sampler of render_up_scale (resample.hip) ----------------------------------------------------------------------------
+static int downsample_args_ok(const void *a, const void *b, int32_t C, int32_t H, int32_t W, int32_t h, int32_t w)
+{
+    if (C <= 0 || H <= 0 || W <= 0 || h <= 0 || w <= 0) return fail(TS2D_ERR_INVALID, "dimensions must be positive");
+    if (H % h != 0 || W % w != 0 || H / h < 2 || W / w < 2) return fail(TS2D_ERR_INVALID, "the down-sampler takes integer factors >= 2 (H = f h, W = g w)");
+    if (!a || !b) return fail(TS2D_ERR_INVALID, "null pointer");
+    return TS2D_OK;
+}
+int tsl_downsample_forward(const float *in, int32_t C, int32_t H, int32_t W, int32_t h, int32_t w, float *out, void *stream)
+{
+    if (int rc = downsample_args_ok(in, out, C, H, W, h, w)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("downsample_fwd", s);
+    TS_HIP(ts_downsample_forward(in, C, H, W, h, w, out, s));
+    return TS2D_OK;
+}
+int tsl_downsample_backward(const float *grad_out, int32_t C, int32_t H, int32_t W, int32_t h, int32_t w, float *grad_in, void *stream)
+{
+    if (int rc = downsample_args_ok(grad_out, grad_in, C, H, W, h, w)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("downsample_bwd", s);
+    TS_HIP(ts_downsample_backward(grad_out, C, H, W, h, w, grad_in, s));
+    return TS2D_OK;
+}
+
 // ---- DoGLoss / SmoothnessLoss (aux_losses.hip) ------------------------------------------------------------------------------------
 size_t tsl_aux_loss_workspace_bytes(int32_t channels, int32_t height, int32_t width, double scale_factor)
 {

@@ -18,7 +18,6 @@ constexpr int R = 5, K = 11;           // window radius / size
 constexpr int TW = 32, TH = 16;        // output tile
 constexpr int IW = TW + 2 * R;         // 42 input columns
 constexpr int IH = TH + 2 * R;         // 26 input rows
-constexpr int IWP = IW + 2;            // padded LDS row stride
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 
 struct Gauss { float w[K]; };
@@ -41,77 +40,137 @@ __device__ __forceinline__ float wave_sum(float v)
     return v;
 }
 
-template <bool NEED_GRAD>
+// ---- round 6: the same separable passes with every LDS access a 128-bit one -------------------------------------------------------------
+// Round 1's kernels read one float per tap from LDS (22 + 55 ds_read_b32 per output pixel in the forward): 0.17 / 0.28 of the HBM roofline,
+// bound by the LDS pipe.  Now (i) the halo tile is loaded as aligned float4s (columns x0 - 8 .. x0 + 39: 12 float4 per row instead of 42 scalar
+// loads; needs W % 4 == 0 and 16-byte aligned planes, otherwise the scalar loader fills the same tile), (ii) a row-pass thread forms FOUR
+// adjacent outputs from five ds_read_b128 per image (a sliding window in registers), (iii) the row results are stored TRANSPOSED (column-major,
+// stride 28: rows of one column are contiguous), so that a column-pass thread forms four adjacent output rows of one column from four
+// ds_read_b128 per array.  Strides 52 / 28 floats make every 8-lane phase of those reads hit 8 x 4 distinct banks.  LDS bytes per output
+// pixel: ~400 -> ~165.  Summation order per output is unchanged (taps 0..10 in sequence): same bits as round 1's kernels.
+constexpr int LW = 48;            // LDS tile width: TW + 2 x 8 (the 5-pixel halo rounded to float4s)
+constexpr int LWP = 52;           // its row stride in floats
+constexpr int HS = 28;            // stride of a transposed column: IH = 26 rows, rounded to float4s
+
+template <int NARR, bool VEC>
+__device__ __forceinline__ void load_halo_tile(float (*dst)[IH][LWP], const float *const (&src)[NARR], int x0, int y0, int H, int W, int tid)
+{
+    if (VEC)
+    {
+        for (int i = tid; i < IH * (LW / 4); i += 256)
+        {
+            const int r = i / (LW / 4), q = i - r * (LW / 4);
+            const int gy = y0 + r - R, gx = x0 - 8 + 4 * q;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W; // W % 4 == 0 and gx % 4 == 0: the four columns are inside or outside together
+#pragma unroll
+            for (int a = 0; a < NARR; a++)
+                *(float4 *)&dst[a][r][4 * q] = in ? *(const float4 *)(src[a] + (size_t)gy * W + gx) : make_float4(0.0f, 0.0f, 0.0f, 0.0f); // zero padding, trainer_utils.py:42-43
+        }
+    }
+    else
+    {
+        for (int i = tid; i < IH * LW; i += 256)
+        {
+            const int r = i / LW, c = i - r * LW;
+            const int gy = y0 + r - R, gx = x0 - 8 + c;
+            const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
+#pragma unroll
+            for (int a = 0; a < NARR; a++) dst[a][r][c] = in ? src[a][(size_t)gy * W + gx] : 0.0f;
+        }
+    }
+}
+
+// Column pass of one thread: output rows r0 .. r0 + 3 of column c from the transposed row results (rows r0 .. r0 + 13 of that column).
+template <int NARR>
+__device__ __forceinline__ void column_pass4(const float (*hb)[TW][HS], const Gauss &g, int c, int r0, float (&out)[NARR][4])
+{
+#pragma unroll
+    for (int a = 0; a < NARR; a++)
+    {
+        float v[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) *(float4 *)(v + 4 * q) = *(const float4 *)&hb[a][c][r0 + 4 * q];
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < K; k++) acc = fmaf(g.w[k], v[o + k], acc);
+            out[a][o] = acc;
+        }
+    }
+}
+
+template <bool NEED_GRAD, bool VEC>
 __global__ void __launch_bounds__(256) ssim_l1_fwd_kernel(const float *__restrict__ img, const float *__restrict__ gt, int H, int W,
                                                            Gauss g, float *__restrict__ d_mu, float *__restrict__ d_s1,
                                                            float *__restrict__ d_s12, float2 *__restrict__ partial)
 {
-    __shared__ float sI[IH][IWP], sG[IH][IWP];
-    __shared__ float hb[5][IH][TW];
+    __shared__ __attribute__((aligned(16))) float sIG[2][IH][LWP];
+    __shared__ __attribute__((aligned(16))) float hb[5][TW][HS];
     __shared__ float red[2][4];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    const float *I = img + plane, *G = gt + plane;
-
-    for (int i = tid; i < IH * IW; i += 256)
-    {
-        const int r = i / IW, c = i - r * IW;
-        const int gy = y0 + r - R, gx = x0 + c - R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        sI[r][c] = in ? I[(size_t)gy * W + gx] : 0.0f; // zero padding, trainer_utils.py:42-43
-        sG[r][c] = in ? G[(size_t)gy * W + gx] : 0.0f;
-    }
+    const float *const src[2] = {img + plane, gt + plane};
+    load_halo_tile<2, VEC>(sIG, src, x0, y0, H, W, tid);
     __syncthreads();
-    for (int i = tid; i < IH * TW; i += 256) // rows
+    if (tid < IH * (TW / 4)) // rows: four adjacent outputs per thread
     {
-        const int r = i / TW, c = i - r * TW;
-        float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        const int r = tid % IH, c0 = 4 * (tid / IH);
+        float a[20], b[20]; // LDS columns c0 .. c0 + 19; output c0 + o reads taps at columns c0 + o + 3 + k
 #pragma unroll
-        for (int k = 0; k < K; k++)
+        for (int q = 0; q < 5; q++)
         {
-            const float a = sI[r][c + k], b = sG[r][c + k], w = g.w[k];
-            const float wa = w * a, wb = w * b;
-            a0 += wa; a1 += wb; a2 = fmaf(wa, a, a2); a3 = fmaf(wb, b, a3); a4 = fmaf(wa, b, a4);
+            *(float4 *)(a + 4 * q) = *(const float4 *)&sIG[0][r][c0 + 4 * q];
+            *(float4 *)(b + 4 * q) = *(const float4 *)&sIG[1][r][c0 + 4 * q];
         }
-        hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2; hb[3][r][c] = a3; hb[4][r][c] = a4;
+#pragma unroll
+        for (int o = 0; o < 4; o++)
+        {
+            float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+            for (int k = 0; k < K; k++)
+            {
+                const float x = a[o + 3 + k], y = b[o + 3 + k], w = g.w[k];
+                const float wa = w * x, wb = w * y;
+                a0 += wa; a1 += wb; a2 = fmaf(wa, x, a2); a3 = fmaf(wb, y, a3); a4 = fmaf(wa, y, a4);
+            }
+            hb[0][c0 + o][r] = a0; hb[1][c0 + o][r] = a1; hb[2][c0 + o][r] = a2; hb[3][c0 + o][r] = a3; hb[4][c0 + o][r] = a4;
+        }
     }
     __syncthreads();
     float ssim_sum = 0.0f, l1_sum = 0.0f;
-    const int c = tid & 31;
-#pragma unroll
-    for (int half = 0; half < 2; half++) // columns: two output pixels per thread
+    if (tid < TW * (TH / 4)) // columns: four adjacent output rows of one column per thread
     {
-        const int r = (tid >> 5) + half * 8;
-        const int gy = y0 + r, gx = x0 + c;
-        float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+        const int c = tid & (TW - 1), r0 = 4 * (tid / TW);
+        float cv[5][4];
+        column_pass4<5>(hb, g, c, r0, cv);
 #pragma unroll
-        for (int k = 0; k < K; k++)
+        for (int o = 0; o < 4; o++)
         {
-            const float w = g.w[k];
-            mu1 = fmaf(w, hb[0][r + k][c], mu1); mu2 = fmaf(w, hb[1][r + k][c], mu2);
-            e11 = fmaf(w, hb[2][r + k][c], e11); e22 = fmaf(w, hb[3][r + k][c], e22);
-            e12 = fmaf(w, hb[4][r + k][c], e12);
-        }
-        if (gy < H && gx < W)
-        {
-            // trainer_utils.py:62-75
-            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-            const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-            const float A1 = 2.0f * mu12 + C1, A2 = 2.0f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
-            const float iB1 = 1.0f / B1, iB2 = 1.0f / B2;
-            const float m = (A1 * A2) * (iB1 * iB2);
-            ssim_sum += m;
-            l1_sum += fabsf(sI[r + R][c + R] - sG[r + R][c + R]); // trainer_utils.py:323-324
-            if (NEED_GRAD)
+            const int r = r0 + o, gy = y0 + r, gx = x0 + c;
+            if (gy < H && gx < W)
             {
-                // independent variables mu1, e11 = E[I^2], e12 = E[IG] (s1 = e11 - mu1^2, s12 = e12 - mu1 mu2)
-                const float dm_ds1 = -m * iB2;                   // d map / d sigma1^2
-                const float dm_ds12 = 2.0f * A1 * (iB1 * iB2);   // d map / d sigma12
-                const float dm_dmu1 = (2.0f * mu2 * A2 * (iB1 * iB2) - 2.0f * mu1 * m * iB1) // through A1 / B1
-                                      - mu2 * dm_ds12 - 2.0f * mu1 * dm_ds1;
-                const size_t o = plane + (size_t)gy * W + gx;
-                d_mu[o] = dm_dmu1; d_s1[o] = dm_ds1; d_s12[o] = dm_ds12;
+                // trainer_utils.py:62-75
+                const float mu1 = cv[0][o], mu2 = cv[1][o], e11 = cv[2][o], e22 = cv[3][o], e12 = cv[4][o];
+                const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+                const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+                const float A1 = 2.0f * mu12 + C1, A2 = 2.0f * s12 + C2, B1 = mu1_sq + mu2_sq + C1, B2 = s1 + s2 + C2;
+                const float iB1 = 1.0f / B1, iB2 = 1.0f / B2;
+                const float m = (A1 * A2) * (iB1 * iB2);
+                ssim_sum += m;
+                l1_sum += fabsf(sIG[0][r + R][c + 8] - sIG[1][r + R][c + 8]); // trainer_utils.py:323-324
+                if (NEED_GRAD)
+                {
+                    // independent variables mu1, e11 = E[I^2], e12 = E[IG] (s1 = e11 - mu1^2, s12 = e12 - mu1 mu2)
+                    const float dm_ds1 = -m * iB2;                   // d map / d sigma1^2
+                    const float dm_ds12 = 2.0f * A1 * (iB1 * iB2);   // d map / d sigma12
+                    const float dm_dmu1 = (2.0f * mu2 * A2 * (iB1 * iB2) - 2.0f * mu1 * m * iB1) // through A1 / B1
+                                          - mu2 * dm_ds12 - 2.0f * mu1 * dm_ds1;
+                    const size_t ofs = plane + (size_t)gy * W + gx;
+                    d_mu[ofs] = dm_dmu1; d_s1[ofs] = dm_ds1; d_s12[ofs] = dm_ds12;
+                }
             }
         }
     }
@@ -148,62 +207,58 @@ __global__ void __launch_bounds__(256) loss_finish_kernel(const float2 *__restri
     }
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(256) ssim_l1_bwd_kernel(const float *__restrict__ img, const float *__restrict__ gt, int H, int W,
                                                            Gauss g, const float *__restrict__ d_mu, const float *__restrict__ d_s1,
                                                            const float *__restrict__ d_s12, float k_ssim, float k_l1,
                                                            const float *__restrict__ grad_out, float *__restrict__ dL_dimg)
 {
-    __shared__ float sM[3][IH][IWP];
-    __shared__ float hb[3][IH][TW];
+    __shared__ __attribute__((aligned(16))) float sM[3][IH][LWP];
+    __shared__ __attribute__((aligned(16))) float hb[3][TW][HS];
     const int tid = threadIdx.x;
     const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
     const size_t plane = (size_t)blockIdx.z * H * W;
-    const float *M0 = d_mu + plane, *M1 = d_s1 + plane, *M2 = d_s12 + plane;
-    for (int i = tid; i < IH * IW; i += 256)
+    const float *const src[3] = {d_mu + plane, d_s1 + plane, d_s12 + plane};
+    load_halo_tile<3, VEC>(sM, src, x0, y0, H, W, tid);
+    __syncthreads();
+    if (tid < IH * (TW / 4))
     {
-        const int r = i / IW, c = i - r * IW;
-        const int gy = y0 + r - R, gx = x0 + c - R;
-        const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-        const size_t o = (size_t)gy * W + gx;
-        sM[0][r][c] = in ? M0[o] : 0.0f;
-        sM[1][r][c] = in ? M1[o] : 0.0f;
-        sM[2][r][c] = in ? M2[o] : 0.0f;
+        const int r = tid % IH, c0 = 4 * (tid / IH);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+        {
+            float v[20];
+#pragma unroll
+            for (int q = 0; q < 5; q++) *(float4 *)(v + 4 * q) = *(const float4 *)&sM[a][r][c0 + 4 * q];
+#pragma unroll
+            for (int o = 0; o < 4; o++)
+            {
+                float acc = 0.0f;
+#pragma unroll
+                for (int k = 0; k < K; k++) acc = fmaf(g.w[k], v[o + 3 + k], acc);
+                hb[a][c0 + o][r] = acc;
+            }
+        }
     }
     __syncthreads();
-    for (int i = tid; i < IH * TW; i += 256)
+    if (tid < TW * (TH / 4))
     {
-        const int r = i / TW, c = i - r * TW;
-        float a0 = 0, a1 = 0, a2 = 0;
+        const float go = grad_out ? grad_out[0] : 1.0f;
+        const int c = tid & (TW - 1), r0 = 4 * (tid / TW);
+        float cv[3][4];
+        column_pass4<3>(hb, g, c, r0, cv);
 #pragma unroll
-        for (int k = 0; k < K; k++)
+        for (int o = 0; o < 4; o++)
         {
-            const float w = g.w[k];
-            a0 = fmaf(w, sM[0][r][c + k], a0); a1 = fmaf(w, sM[1][r][c + k], a1); a2 = fmaf(w, sM[2][r][c + k], a2);
-        }
-        hb[0][r][c] = a0; hb[1][r][c] = a1; hb[2][r][c] = a2;
-    }
-    __syncthreads();
-    const float go = grad_out ? grad_out[0] : 1.0f;
-    const int c = tid & 31;
-#pragma unroll
-    for (int half = 0; half < 2; half++)
-    {
-        const int r = (tid >> 5) + half * 8;
-        const int gy = y0 + r, gx = x0 + c;
-        float v0 = 0, v1 = 0, v2 = 0;
-#pragma unroll
-        for (int k = 0; k < K; k++)
-        {
-            const float w = g.w[k];
-            v0 = fmaf(w, hb[0][r + k][c], v0); v1 = fmaf(w, hb[1][r + k][c], v1); v2 = fmaf(w, hb[2][r + k][c], v2);
-        }
-        if (gy < H && gx < W)
-        {
-            const size_t o = plane + (size_t)gy * W + gx;
-            const float a = img[o], b = gt[o];
-            const float d = a - b;
-            const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); // torch.abs backward: sign, 0 at 0
-            dL_dimg[o] = go * (k_ssim * (v0 + 2.0f * a * v1 + b * v2) + k_l1 * sgn);
+            const int gy = y0 + r0 + o, gx = x0 + c;
+            if (gy < H && gx < W)
+            {
+                const size_t ofs = plane + (size_t)gy * W + gx;
+                const float a = img[ofs], b = gt[ofs];
+                const float d = a - b;
+                const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f); // torch.abs backward: sign, 0 at 0
+                dL_dimg[ofs] = go * (k_ssim * (cv[0][o] + 2.0f * a * cv[1][o] + b * cv[2][o]) + k_l1 * sgn);
+            }
         }
     }
 }
@@ -249,10 +304,11 @@ hipError_t ts_loss_forward(const float *image, const float *gt, int C, int H, in
 {
     const Carve c = carve(workspace, C, H, W);
     const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, C);
-    if (need_grad)
-        hipLaunchKernelGGL(ssim_l1_fwd_kernel<true>, grid, dim3(256), 0, s, image, gt, H, W, gauss(), c.d_mu, c.d_s1, c.d_s12, c.partial);
-    else
-        hipLaunchKernelGGL(ssim_l1_fwd_kernel<false>, grid, dim3(256), 0, s, image, gt, H, W, gauss(), c.d_mu, c.d_s1, c.d_s12, c.partial);
+    const bool vec = (W % 4 == 0) && (((size_t)image | (size_t)gt) & 15) == 0; // planes then start on 16-byte boundaries too (H * W * 4 bytes each)
+#define TS_SSIM_FWD(G, V) hipLaunchKernelGGL((ssim_l1_fwd_kernel<G, V>), grid, dim3(256), 0, s, image, gt, H, W, gauss(), c.d_mu, c.d_s1, c.d_s12, c.partial)
+    if (need_grad) { if (vec) TS_SSIM_FWD(true, true); else TS_SSIM_FWD(true, false); }
+    else { if (vec) TS_SSIM_FWD(false, true); else TS_SSIM_FWD(false, false); }
+#undef TS_SSIM_FWD
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, c.partial, c.nblocks, 1.0 / ((double)C * H * W), w_l1, w_ssim, out);
     return hipGetLastError();
 }
@@ -264,7 +320,12 @@ hipError_t ts_loss_backward(const float *image, const float *gt, int C, int H, i
     const dim3 grid((W + TW - 1) / TW, (H + TH - 1) / TH, C);
     const double inv_n = 1.0 / ((double)C * H * W);
     // d(1 - mean(map)) = -1/N per map element; d mean|I - G| = sign / N
-    hipLaunchKernelGGL(ssim_l1_bwd_kernel, grid, dim3(256), 0, s, image, gt, H, W, gauss(), c.d_mu, c.d_s1, c.d_s12,
-                       (float)(-(double)w_ssim * inv_n), (float)((double)w_l1 * inv_n), grad_out, dL_dimage);
+    const bool vec = (W % 4 == 0) && (((size_t)c.d_mu | (size_t)c.d_s1 | (size_t)c.d_s12) & 15) == 0;
+    if (vec)
+        hipLaunchKernelGGL(ssim_l1_bwd_kernel<true>, grid, dim3(256), 0, s, image, gt, H, W, gauss(), c.d_mu, c.d_s1, c.d_s12,
+                           (float)(-(double)w_ssim * inv_n), (float)((double)w_l1 * inv_n), grad_out, dL_dimage);
+    else
+        hipLaunchKernelGGL(ssim_l1_bwd_kernel<false>, grid, dim3(256), 0, s, image, gt, H, W, gauss(), c.d_mu, c.d_s1, c.d_s12,
+                           (float)(-(double)w_ssim * inv_n), (float)((double)w_l1 * inv_n), grad_out, dL_dimage);
     return hipGetLastError();
 }

@@ -344,6 +344,8 @@ hipError_t ts_masked_l1_backward(const float *img, const float *gt, const float 
 hipError_t ts_scharr_smoothness_forward(const float *img, const float *mask, int C, int H, int W, void *workspace, float *out, hipStream_t s);
 hipError_t ts_scharr_smoothness_backward(const float *img, const float *mask, int C, int H, int W, void *workspace, const float *grad_out, float *dimg,
                                          hipStream_t s);
+hipError_t ts_downsample_forward(const float *in, int C, int H, int W, int h, int w, float *out, hipStream_t s);   // resample.hip
+hipError_t ts_downsample_backward(const float *gout, int C, int H, int W, int h, int w, float *gin, hipStream_t s);
 size_t ts_depth_normal_workspace_bytes(int H, int W, double scale);
 hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, double scale, float quantile,
                                    void *workspace, float *out, hipStream_t s);

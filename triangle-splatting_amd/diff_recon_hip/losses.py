@@ -333,3 +333,44 @@ class SmoothnessLoss(nn.Module):
 
 dogLoss = DoGLoss()                  # the module-level instances of trainer_utils.py:350-351
 smoothnessLoss = SmoothnessLoss()
+
+
+# ---- the down-sampler of render_up_scale (include/ts_loss.h: tsl_downsample_*; csrc/resample.hip) ----------------------------------------
+_lib.tsl_downsample_forward.restype = C.c_int
+_lib.tsl_downsample_forward.argtypes = [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]
+_lib.tsl_downsample_backward.restype = C.c_int
+_lib.tsl_downsample_backward.argtypes = [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]
+
+
+class _Downsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, h, w):
+        xc = x.contiguous()
+        lead, (H, W) = xc.shape[:-2], xc.shape[-2:]
+        c = 1
+        for d in lead:
+            c *= int(d)
+        out = torch.empty(tuple(lead) + (h, w), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _native._check(_lib.tsl_downsample_forward(xc.data_ptr(), c, H, W, h, w, out.data_ptr(), torch.cuda.current_stream().cuda_stream), "downsample_bilinear")
+        ctx.dims = (c, H, W, h, w, tuple(xc.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        c, H, W, h, w, shape = ctx.dims
+        gc = g.contiguous()
+        gin = torch.empty(shape, device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            _native._check(_lib.tsl_downsample_backward(gc.data_ptr(), c, H, W, h, w, gin.data_ptr(), torch.cuda.current_stream().cuda_stream), "downsample_bilinear backward")
+        return gin, None, None
+
+
+def downsample_bilinear(x: torch.Tensor, size) -> torch.Tensor:
+    """`F.interpolate(x[None], size=size, mode="bilinear")[0]` for an INTEGER down-sampling factor in both directions -- the resize that follows a
+    render at render_up_scale x the camera's resolution (VanillaTS_model.py:649-656) -- as one HBM-bound HIP kernel each way; the backward gathers
+    (no atomics: run-to-run identical, unlike torch's upsample_bilinear2d_backward).  x: (..., H, W) float32 on the HIP device."""
+    h, w = int(size[0]), int(size[1])
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise RuntimeError("downsample_bilinear (MI355X build) needs a float32 tensor on a HIP device; there is no CPU fallback")
+    return _Downsample.apply(x, h, w)

@@ -19,6 +19,7 @@ from typing import Dict, Optional
 import torch
 import torch.nn.functional as F
 
+from .losses import downsample_bilinear
 from .triangle_renderer import TriangleRenderer
 
 
@@ -69,12 +70,14 @@ def render_view(camera, vertex: torch.Tensor, f_dc: torch.Tensor, f_rest: torch.
                                 gamma=gamma, back_culling=back_culling, rich_info=is_training, rasterizer_type=rasterizer_type)
     out = renderer.render(v_render, shs, None, o_render)
     if up > 1:
-        out["render"] = F.interpolate(out["render"].unsqueeze(0), size=(h, w), mode="bilinear").squeeze(0)
+        # F.interpolate(..., size=(h, w), mode="bilinear") of the reference (:649-656); for the integer factor this is, one gather kernel each way
+        # (diff_recon_hip.downsample_bilinear, csrc/resample.hip; pinned against F.interpolate + autograd in tests/test_loss_gpu.py)
+        out["render"] = downsample_bilinear(out["render"], (h, w))
         out["radii"] = out["radii"] // up
         if "depth" in out:
-            out["depth"] = F.interpolate(out["depth"].unsqueeze(0).unsqueeze(0), size=(h, w), mode="bilinear").squeeze(0).squeeze(0)
+            out["depth"] = downsample_bilinear(out["depth"], (h, w))
         if "normal" in out:
-            out["normal"] = F.interpolate(out["normal"].unsqueeze(0), size=(h, w), mode="bilinear").squeeze(0)
+            out["normal"] = downsample_bilinear(out["normal"], (h, w))
     pkg = {"render": out["render"]}
     if is_training:  # :664-679
         pkg.update(radii=out["radii"], center2D=out["center2D"], contrib_sum=out["contrib_sum"], contrib_max=out["contrib_max"],
