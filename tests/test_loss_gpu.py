@@ -312,6 +312,7 @@ def test_downsample_bilinear_equals_interpolate_and_its_autograd(shape, factor):
     """Round 6: the resize behind a render at render_up_scale x the resolution (VanillaTS_model.py:649-656, F.interpolate(..., mode="bilinear")) as
     one gather kernel each way (csrc/resample.hip) -- against torch's own kernels: forward to 1 ulp-ish, backward against autograd (whose
     upsample_bilinear2d_backward scatters with atomics)."""
+    import torch
     import torch.nn.functional as F
     from diff_recon_hip import downsample_bilinear
     g = torch.Generator(device="cuda").manual_seed(5)

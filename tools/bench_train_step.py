@@ -77,7 +77,7 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(1)
     gt = torch.rand((3, c.h, c.w), device=dev, generator=g)
     geo = D.DepthNormalLoss(scale_factor=0.5) if c.w_geo > 0 else None
-    bg = torch.zeros(3)
+    bg = torch.zeros(3, device=dev)  # on the device: TriangleRenderer's bg_color.to(device) is then no copy (a host-to-device copy cannot sit in a capture)
     out = {}
 
     def fwd_loss_bwd():

@@ -46,6 +46,9 @@ prof() { local n=$1; shift; rm -rf $O/prof_$n; (cd /tmp && timeout 900 rocprofv3
 pmc() { local n=$1 c=$2; shift 2; rm -rf $O/pmc_$n; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n -o $n --output-format csv -- python $R/bench.py --no-cpu-baseline --steps 5 --warmup 1 --settle-steps 0 --no-kernel-events "$@" > $O/pmc_$n.log 2>&1)
     f=$(find $O/pmc_$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $f | tee $O/${n}_pmc.txt; rm -rf $O/pmc_$n; }
 
+# pmcx <name> "<counters>" <command...>: one counter pass over ANY command (kernel trace only, no other trace domain)
+pmcx() { local n=$1 c=$2; shift 2; rm -rf $O/pmc_$n; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc $c -d $O/pmc_$n -o $n --output-format csv -- "$@" > $O/pmc_$n.log 2>&1)
+    f=$(find $O/pmc_$n -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python $R/tools/pmc_summary.py $f 3 | tee $O/${n}_pmc.txt; rm -rf $O/pmc_$n; }
 # train <config> [args]: one line of tools/bench_train_step.py appended to train_step.jsonl
 train() { timeout 900 python tools/bench_train_step.py --config "$@" 2>$O/train_$1.err | tee -a $O/train_step.jsonl | python -c "
 import json,sys

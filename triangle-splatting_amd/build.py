@@ -42,6 +42,7 @@ SOURCES = {
     "model_update.hip": [],
     "optim.hip": ["-ffp-contract=off"],
     "binning.hip": [],
+    "select.hip": [],
     # the 2D blend kernels: ONE source, two translation units (TSG_PART), so that each kernel gets the machine-scheduler strategy it measured best
     # with (round 5, profiles/r05_sched_strategies.txt: max-ilp +1.3 % for the forward, -1 % for the backward; round 6: profiles/r06_blend_ab.txt)
     "render_group.hip@fwd": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize", "-DTSG_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"],

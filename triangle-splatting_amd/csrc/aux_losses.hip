@@ -304,7 +304,7 @@ ACarve acarve(void *ws, const ADims &m)
     for (int i = 0; i < 2; i++) { ts_carve(p, c.k[i], HW); ts_carve(p, c.v[i], HW); }
     p = (char *)ts_align_up((size_t)p);
     c.scratch = p;
-    p += ts_radix_scratch_bytes(HW);
+    p += ts_radix_scratch_bytes(HW) > ts_quantile_scratch_bytes() ? ts_radix_scratch_bytes(HW) : ts_quantile_scratch_bytes(); // (the quantile is a radix select since round 6; the sort scratch is kept as an upper bound)
     c.bytes = (size_t)(p - (char *)ws) + TS_ALIGN;
     return c;
 }
@@ -353,8 +353,7 @@ hipError_t ts_smoothness_mask(const float *gt, int C, int H, int W, double scale
     hipLaunchKernelGGL(aux_scharr_norm_low_kernel, lo, dim3(256), 0, s, m, c.low, c.low1);
     const int nb = min(SUM_BLOCKS, (HW + 255) / 256);
     hipLaunchKernelGGL((aux_upsample_kernel<true, false>), dim3((unsigned)nb), dim3(256), 0, s, m, c.low1, c.U, c.k[0], (float *)nullptr, (float *)nullptr);
-    const int src = ts_radix_sort_pairs(c.k, c.v, (size_t)HW, 32, c.scratch, s); // the norms are >= 0: their bit patterns sort like the values
-    hipLaunchKernelGGL(quantile_threshold_kernel, dim3(1), dim3(1), 0, s, c.k[src], HW, quantile, c.thr);
+    ts_quantile_threshold(c.k[0], (size_t)HW, quantile, c.scratch, c.thr, s); // radix select (select.hip): the norms are >= 0, their bit patterns order like the values
     hipLaunchKernelGGL(aux_below_mask_kernel, hi, dim3(256), 0, s, HW, c.U, c.thr, mask);
     return hipGetLastError();
 }

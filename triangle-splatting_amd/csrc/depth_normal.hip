@@ -278,7 +278,7 @@ Carve carve(void *ws, const Dims &m)
     for (int i = 0; i < 2; i++) { ts_carve(p, c.k[i], HW); ts_carve(p, c.v[i], HW); }
     p = (char *)ts_align_up((size_t)p);
     c.scratch = p;
-    p += ts_radix_scratch_bytes(HW);
+    p += ts_radix_scratch_bytes(HW) > ts_quantile_scratch_bytes() ? ts_radix_scratch_bytes(HW) : ts_quantile_scratch_bytes(); // (the quantile is a radix select since round 6; the sort scratch is kept as an upper bound)
     c.bytes = (size_t)(p - (char *)ws) + TS_ALIGN;
     return c;
 }
@@ -300,8 +300,7 @@ hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int 
     hipLaunchKernelGGL(dn_downsample_kernel, lo, dim3(256), 0, s, m, depth, c.d);
     hipLaunchKernelGGL(dn_lowres_kernel, lo, dim3(256), 0, s, m, c.d, c.nraw, c.gnorm);
     hipLaunchKernelGGL(dn_fullres_kernel, hi, dim3(256), 0, s, m, c.nraw, c.gnorm, normal, c.G, c.k[0], c.t);
-    const int src = ts_radix_sort_pairs(c.k, c.v, (size_t)HW, 32, c.scratch, s);
-    hipLaunchKernelGGL(quantile_threshold_kernel, dim3(1), dim3(1), 0, s, c.k[src], HW, quantile, c.thr);
+    ts_quantile_threshold(c.k[0], (size_t)HW, quantile, c.scratch, c.thr, s); // radix select (select.hip): the norms are >= 0, their bit patterns order like the values
     const int nb = min(SUM_BLOCKS, (HW + 255) / 256);
     hipLaunchKernelGGL(dn_sum_kernel, dim3((unsigned)nb), dim3(256), 0, s, HW, c.t, c.G, c.thr, c.partial);
     hipLaunchKernelGGL(dn_finish_kernel, dim3(1), dim3(64), 0, s, nb, HW, c.partial, out);
