@@ -142,6 +142,9 @@ def main():
                     help="N > 1: the backward's per-triangle kernel runs as K launches over consecutive triangle ranges and the bucket is all-reduced "
                          "range by range as they finish (GradBucket.prepare_ranges / reduce_ranges_async, ts2d_backward_ranged): what it can hide is "
                          "bounded by that kernel (0.107 ms of the 1.59 ms step); compare config.exchange.exposed_ms_per_step with the default's")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="NOT the headline: the evaluation / viewer path -- forward with rich_info=False under no_grad, no backward "
+                         "(VanillaTS_trainer.py:167, viser_viewer.py:199-229); `metric` names itself, `value` = forward Mpix/s")
     ap.add_argument("--hip-graph", action="store_true",
                     help="NOT the driver's command: the step (sync-free forward, loss gradients, backward) is captured ONCE into a HIP graph "
                          "(torch.cuda.CUDAGraph on the rasterizer's launches; the sync-free forward has no host read to break the capture) and the "
@@ -203,7 +206,7 @@ def main():
     rs = TriangleRasterizationSettings(
         image_width=W, image_height=H, tanfovx=cam["tanfovx"], tanfovy=cam["tanfovy"], viewmatrix=t(cam["viewmatrix"]),
         projmatrix=t(cam["projmatrix"]), campos=t(cam["campos"]), sh_degree=D, gamma=args.gamma, scale_modifier=1.0,
-        background_depth=5000.0, background=t(s["background"]), back_culling=False, rich_info=True, debug=False)
+        background_depth=5000.0, background=t(s["background"]), back_culling=False, rich_info=not args.forward_only, debug=False)
     raster = TriangleRasterizer(rs)
     vertex = t(s["vertex"]).requires_grad_(True)
     shs = t(s["shs"]).requires_grad_(True)
@@ -279,6 +282,11 @@ def main():
             elif prev is not None:
                 collect(prev)    # one-step-delayed application: the previous step's gradients arrive while this step's exchange is in flight
             state["step"] = i + 1
+        elif args.forward_only:
+            with torch.no_grad():
+                out = raster(vertex, center2D, opacity, shs=shs)
+            state["image"] = out[0]
+            return
         else:
             out = raster(vertex, center2D, opacity, shs=shs)
             torch.autograd.backward([out[0], out[2], out[3]], [g_feat, g_depth, g_norm])
@@ -416,6 +424,9 @@ def main():
             other["ms_per_step"] = round(1e3 * float(tmax[1].item()) / args.steps, 4)
             other["exposed_ms_per_step"] = None if other["exposed_ms_per_step"] is None else round(other["exposed_ms_per_step"], 4)
 
+    if args.forward_only:  # no autograd node: count the instances with one more forward that keeps its graph
+        out = raster(vertex, center2D_sink(P, dev), opacity, shs=shs)
+        state["num_rendered"] = out[0].grad_fn.num_rendered
     true_n = int(state["num_rendered"])
     if args.sync_free:
         over, true_n = _pkg.forward_overflowed(state["image"])
@@ -427,15 +438,20 @@ def main():
     N = true_n
     ntiles = ((W + 15) // 16) * ((H + 15) // 16)
     alg = algorithmic_bytes(P, N, W, H, D, ntiles)
+    if args.forward_only:  # 48 B per instance and 20 B per pixel without rich_info; no backward rows
+        alg["render_fwd"] = N * 48 + W * H * 20
+        alg["total"] = alg["preprocess_fwd"] + alg["scan"] + alg["emit_keys"] + alg["sort_pairs"] + alg["tile_ranges"] + alg["render_fwd"]
 
     result = {
         # BASELINE.json's metric is quoted on the headline configuration; any other --triangles / --width / --height names itself
-        "metric": ("fwd+bwd Mpixels/sec @ 1M triangles, 1920x1080; achieved HBM GB/s" if (P, W, H) == (1_000_000, 1920, 1080)
+        "metric": (f"forward-only (rich_info=False, evaluation path) Mpixels/sec @ {P} triangles, {W}x{H}" if args.forward_only else
+                   "fwd+bwd Mpixels/sec @ 1M triangles, 1920x1080; achieved HBM GB/s" if (P, W, H) == (1_000_000, 1920, 1080)
                    else f"fwd+bwd Mpixels/sec @ {P} triangles, {W}x{H}; achieved HBM GB/s"),
         "value": round(mpix_s, 3), "unit": "Mpix/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"rasterizer": args.rasterizer, "workload": f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma={args.gamma:g}): fwd+bwd of one view per GPU",
+        "config": {"rasterizer": args.rasterizer, "workload": (f"S(P={P}, {W}x{H}, SH degree {D}, rich_info=False, gamma={args.gamma:g}): forward of one view (evaluation path)" if args.forward_only else
+                                                               f"S(P={P}, {W}x{H}, SH degree {D}, rich_info, gamma={args.gamma:g}): fwd+bwd of one view per GPU"),
                    "triangles": P, "width": W, "height": H, "sh_degree": D, "num_rendered": N, "scene_mode": args.scene_mode, "edge_px": args.edge_px,
                    "forward": ("sync-free, the whole step replayed from ONE captured HIP graph (torch.cuda.CUDAGraph): not the driver's command" if args.hip_graph else
                                "sync-free (ts2d_forward, device-side instance count)" if args.sync_free else
@@ -493,7 +509,7 @@ def main():
             dom, dom_ms, dom_n = rows[0]
             dom_avg = dom_ms / max(dom_n, 1)
             ach = alg.get(dom, 0) / (dom_avg * 1e-3) / 1e9
-            headline = (P, W, H, D, args.rasterizer) == (1_000_000, 1920, 1080, 3, "2D")
+            headline = (P, W, H, D, args.rasterizer) == (1_000_000, 1920, 1080, 3, "2D") and not args.forward_only
             result["roofline"] = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBS,
                                   "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5), "traffic": hbm_traffic(dom) if headline else None,
                                   "algorithmic_bytes_per_launch": alg.get(dom, 0), "avg_launch_ms": round(dom_avg, 4),
@@ -503,7 +519,7 @@ def main():
                                           "roofline they sit on; every duration is this run's timed-region HIP events"}
         else:
             result["roofline"] = None
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.forward_only:
             result["cpu_baseline"] = cpu_baseline(s, state["image"].detach().cpu().numpy(), 3 if args.rasterizer == "3D" else 2)
             ref = reference_gpu_baseline(s, dev, args.rasterizer, state["image"].detach())
             if ref is not None:

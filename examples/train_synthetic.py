@@ -100,7 +100,7 @@ class SyntheticModel(DensificationStats):
 
 
 def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, seed=0, views=2, views_per_step=2, log=print, updates=True,
-          w_geometry=0.0, single_sh=False):
+          w_geometry=0.0, single_sh=False, init_from_pcd=False):
     """w_geometry > 0 adds the depth / normal consistency term of the *_VanillaTS_mesh.yaml configurations (geometry_loss: w_geometry 0.05,
     scale_factor 0.5, from iteration start_iter on; VanillaTS_trainer.py:30-31,64-65,84,111) -- the producer of dL_dout_depth / dL_dout_normal."""
     dev = torch.device("cuda")
@@ -119,8 +119,15 @@ def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, se
     keep = torch.rand(triangles, device=dev, generator=g) < 0.7  # start sparser than the target: densification has work to do
     vertex = (t(s["vertex"]) + 1.5 * torch.randn(s["vertex"].shape, device=dev, generator=g))[keep].contiguous()
     n0 = vertex.shape[0]
-    m = SyntheticModel(vertex, torch.full((n0, 1, 3), 0.5, device=dev), torch.zeros((n0, (D_sh + 1) ** 2 - 1, 3), device=dev),
-                       torch.zeros((n0, 1), device=dev), iters, D_sh, single_sh=single_sh)
+    if init_from_pcd:
+        # the way the reference's trainer starts (VanillaTSModel.create_from_pcd, VanillaTS_model.py:830-917): a point cloud -- here the perturbed
+        # centroids with grey colours and no normals, like a COLMAP cloud without them -- becomes equilateral triangles sized by the distance to the
+        # three nearest neighbours (simple_knn.distCUDA2)
+        init = D.create_from_pcd(vertex.mean(dim=1), torch.full((n0, 3), 0.5, device=dev), None, max_sh_degree=D_sh, init_opacity=0.5)
+        m = SyntheticModel(init["_vertex"], init["_f_dc"], init["_f_rest"], init["_opacity"], iters, D_sh, single_sh=single_sh)
+    else:
+        m = SyntheticModel(vertex, torch.full((n0, 1, 3), 0.5, device=dev), torch.zeros((n0, (D_sh + 1) ** 2 - 1, 3), device=dev),
+                           torch.zeros((n0, 1), device=dev), iters, D_sh, single_sh=single_sh)
     losses, t0 = [], time.perf_counter()
     for it in range(1, iters + 1):
         m.optimizer.zero_grad(set_to_none=True)
@@ -157,9 +164,10 @@ if __name__ == "__main__":
     ap.add_argument("--triangles", type=int, default=20000)
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--single-sh-tensor", action="store_true", help="one (P, M, 3) colour parameter with two learning rates instead of f_dc + f_rest")
+    ap.add_argument("--init-from-pcd", action="store_true", help="start from diff_recon_hip.create_from_pcd (point cloud -> distCUDA2 -> equilateral triangles) like the reference's trainer")
     ap.add_argument("--w-geometry", type=float, default=0.0, help="weight of the depth / normal consistency loss (0.05 in the *_VanillaTS_mesh configs)")
     a = ap.parse_args()
-    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views, w_geometry=a.w_geometry, single_sh=a.single_sh_tensor)
+    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views, w_geometry=a.w_geometry, single_sh=a.single_sh_tensor, init_from_pcd=a.init_from_pcd)
     for row in m.log:
         print("  update", row)
     print(f"{a.rasterizer}: loss {losses[0]:.5f} -> {losses[-1]:.5f} in {a.iters} iterations, {sec * 1e3:.2f} ms/iteration (incl. Python)")

@@ -189,6 +189,54 @@ def load_reference_model_class():
             sys.modules[e.name] = types.ModuleType(e.name)
 
 
+def create_from_pcd(rng):
+    """create_from_pcd.npz: the reference's own VanillaTSModel.create_from_pcd on CPU tensors (VanillaTS_model.py:830-917).  Its one CUDA leaf,
+    distCUDA2 (exact mean squared distance to the three nearest neighbours, submodules/simple-knn), is replaced by the float64 k-d tree of
+    oracle/ts_knn_oracle.py -- the same exact search -- because this container has no GPU; everything else is the reference's code.  Random numbers
+    come from torch's global CPU generator, seeded per case (stored), so that the HIP-side test can replay the stream."""
+    from types import SimpleNamespace as NS
+    Model, Logger = load_reference_model_class()
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import ts_knn_oracle
+    import diff_recon.models.VanillaTS_model as VM
+
+    def ipd(pc):
+        d2 = ts_knn_oracle.mean_dist3(pc.detach().cpu().numpy().astype(np.float64))
+        return torch.from_numpy(np.asarray(d2, np.float32)).clamp_(min=1e-10).sqrt()
+    VM.inter_point_distance = ipd
+    PC = VM.PointCloud
+    out, cases = {}, {
+        "plain": dict(n=400, zero_normals=False, bbox=None, sampling=NS(sample_method="direct", n_sample_inside=None, n_sample_outside=None, grid_size_inside=None,
+                                                                       grid_size_outside=None, init_opacity=0.5, duplicate_count=1), back_culling=False, max_sh=3, seed=11),
+        "twins_dup": dict(n=300, zero_normals=True, bbox=(2.0, 2.0, 2.0, 8.0, 8.0, 8.0), sampling=NS(sample_method="direct", n_sample_inside=None, n_sample_outside=None,
+                                                                                                   grid_size_inside=None, grid_size_outside=None, init_opacity=0.1, duplicate_count=3),
+                          back_culling=True, max_sh=0, seed=12),
+        "grid": dict(n=2000, zero_normals=False, bbox=(0.0, 0.0, 10.0, 6.0), sampling=NS(sample_method="grid", n_sample_inside=300, n_sample_outside=None, grid_size_inside=None,
+                                                                                       grid_size_outside=1.5, init_opacity=0.3, duplicate_count=1), back_culling=False, max_sh=2, seed=13),
+    }
+    for name, c in cases.items():
+        pts = rng.random((c["n"], 3)) * 10
+        cols = rng.random((c["n"], 3))
+        nrm = np.zeros_like(pts) if c["zero_normals"] else rng.normal(size=(c["n"], 3))
+        nrm[: c["n"] // 10, :2] = 0.0  # some normals along +-z: the `up x normal` fallback (:897)
+        m = Model.__new__(Model)
+        torch.nn.Module.__init__(m) if isinstance(m, torch.nn.Module) else None
+        m.device, m.logger, m.scene_bbox, m.back_culling, m.max_sh_degree = torch.device("cpu"), Logger(), c["bbox"], c["back_culling"], c["max_sh"]
+        m.config = NS(sampling=c["sampling"])
+        m._training_setup = lambda: None
+        torch.manual_seed(c["seed"])
+        m.create_from_pcd(PC(points=pts, colors=cols, normals=nrm))
+        out.update({f"{name}/points": pts, f"{name}/colors": cols, f"{name}/normals": nrm, f"{name}/seed": np.int64(c["seed"]),
+                    f"{name}/bbox": np.asarray(c["bbox"] if c["bbox"] is not None else [], np.float64), f"{name}/back_culling": np.bool_(c["back_culling"]),
+                    f"{name}/max_sh": np.int64(c["max_sh"]), f"{name}/init_opacity": np.float64(c["sampling"].init_opacity),
+                    f"{name}/duplicate_count": np.int64(c["sampling"].duplicate_count), f"{name}/method": np.int64({"direct": 0, "random": 1, "grid": 2}[c["sampling"].sample_method]),
+                    f"{name}/n_sample_inside": np.int64(c["sampling"].n_sample_inside or -1), f"{name}/grid_size_outside": np.float64(c["sampling"].grid_size_outside or -1.0),
+                    f"{name}/vertex": m._vertex.detach().numpy(), f"{name}/opacity": m._opacity.detach().numpy(), f"{name}/f_dc": m._f_dc.detach().numpy(),
+                    f"{name}/f_rest": m._f_rest.detach().numpy()})
+    np.savez_compressed(os.path.join(HERE, "create_from_pcd.npz"), **out)
+    print("create_from_pcd.npz:", {k: out[f"{k}/vertex"].shape for k in cases})
+
+
 def model_update(rng):
     from types import SimpleNamespace as NS
     from copy import deepcopy
@@ -401,6 +449,8 @@ if __name__ == "__main__":
         depth_normal()
     elif len(sys.argv) > 1 and sys.argv[1] == "aux_losses":
         aux_losses()
+    elif len(sys.argv) > 1 and sys.argv[1] == "create_from_pcd":
+        create_from_pcd(np.random.default_rng(7))  # only this fixture (round 6)
     elif len(sys.argv) > 1 and sys.argv[1] == "model_update":
         model_update(np.random.default_rng(1))  # only this fixture (the others are unchanged since round 1)
     elif len(sys.argv) > 1 and sys.argv[1] == "schedules":

@@ -70,7 +70,7 @@ def _carve(buf, fields):
     return out
 
 
-def forward_integer_state(s, build="_ref2d_nofma_C", rich_info=True, back_culling=False, device="cuda"):
+def forward_integer_state(s, build="_ref2d_nofma_C", rich_info=True, back_culling=False, device="cuda", use_feature=False):
     """The integer / index state of ONE forward of the reference's 2D extension, read out of its three private buffers:
     num_rendered, radii, and -- decoded as the reference lays them out (GeometryState / BinningState / ImageState::fromChunk,
     R2D/src/param_struct.h:66-125) -- tiles_touched, point_offsets, the SORTED keys and instance list (point_list_keys, point_list) and the
@@ -80,7 +80,8 @@ def forward_integer_state(s, build="_ref2d_nofma_C", rich_info=True, back_cullin
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
     out = ref.rasterize_triangles(s["image_width"], s["image_height"], s["tanfovx"], s["tanfovy"], t(s["viewmatrix"]), t(s["projmatrix"]), t(s["campos"]),
                                   int(s["sh_degree"]), float(s["gamma"]), float(s["scale_modifier"]), float(s["background_depth"]), t(s["background"]),
-                                  t(s["vertex"]), t(s["shs"]), torch.empty(0, device=device), t(s["opacity"]), back_culling, rich_info, False)
+                                  t(s["vertex"]), torch.empty(0, device=device) if use_feature else t(s["shs"]),
+                                  t(s["feature"]) if use_feature else torch.empty(0, device=device), t(s["opacity"]), back_culling, rich_info, False)
     torch.cuda.synchronize()
     n, radii, gb, bb, ib = int(out[0]), out[2], out[7], out[8], out[9]
     P, W, H = s["vertex"].shape[0], s["image_width"], s["image_height"]

@@ -57,6 +57,11 @@ def _compare(a, b, rich, img_tol, grad_tol, what, s=None, of=None, variant=2):
     (1000, 320, 240, 3, {"mode": "maincu"}),      # the reference's own main.cu recipe
     (300_000, 800, 800, 3, {}),                   # configs[1]'s shape
     (1_000_000, 1920, 1080, 3, {}),               # the headline
+    # round 6: the modes that until now were only checked through _same_integer_state's tolerances against the contracting build
+    (12_000, 200, 144, 0, {"feature": True}),                                   # feature mode (colours handed in, no SH)
+    (15_000, 240, 160, 2, {"back_culling": True}),                              # back-face culling: the sign test on area2 (forward.cu:140-144)
+    (15_000, 240, 160, 1, {"gamma": 2.5}),                                      # gamma != 1 (the quadrant masks' support scale depends on it)
+    (150_000, 640, 360, 3, {"gamma": 7.0, "back_culling": True}),               # both, past the one-launch depth order and the small sort chunks
 ])
 def test_integer_chain_equals_the_references_uncontracted_build(P, W, H, D, kw):
     """product == oracle == REFERENCE for the integer / index state of the 2D path, bit for bit.  The product's per-triangle
@@ -66,10 +71,14 @@ def test_integer_chain_equals_the_references_uncontracted_build(P, W, H, D, kw):
     private state (read by the lab library).  The sorted list being equal also says that the product's two-stage ordering (depth per triangle,
     then tile bits per instance, both stable) resolves equal keys exactly as the reference's single stable 64-bit sort does.
     `_same_integer_state`'s tolerances remain in use only against the CONTRACTING build (_ref2d_C)."""
+    kw = dict(kw)
+    feat, bc, gamma = kw.pop("feature", False), kw.pop("back_culling", False), kw.pop("gamma", 1.0)
     s = synthetic.scene(P, W, H, D, seed=97 + P, **kw)
-    s["gamma"] = 1.0
-    ref = ref_build.forward_integer_state(s, "_ref2d_nofma_C")
-    hf = helpers.hip_forward_backward(s, True, False, backward=False)
+    s["gamma"] = gamma
+    if feat:
+        s["feature"] = np.random.default_rng(P).random((P, 3), dtype=np.float32)
+    ref = ref_build.forward_integer_state(s, "_ref2d_nofma_C", back_culling=bc, use_feature=feat)
+    hf = helpers.hip_forward_backward(s, True, bc, use_feature=feat, backward=False)
     assert hf["num_rendered"] == ref["num_rendered"]
     assert np.array_equal(hf["radii"], ref["radii"])
     assert np.array_equal(helpers.hip_state(hf, s, "tiles_touched").astype(np.uint32), ref["tiles_touched"])
@@ -80,7 +89,7 @@ def test_integer_chain_equals_the_references_uncontracted_build(P, W, H, D, kw):
     # the reference's sorted 64-bit keys (tile << 32 | bits of the fp32 depth, rasterizer.cu:62-66), rebuilt from the product's state by the lab reader
     assert np.array_equal(helpers.hip_state(hf, s, "keys").view(np.uint64).reshape(-1)[:n], ref["keys"])
     if P <= 20_000:  # and the oracle, which the CPU suite and every parity test lean on
-        of = helpers.oracle_forward(s, True, False)
+        of = helpers.oracle_forward(s, True, bc, use_feature=feat)
         assert of["num_rendered"] == n and np.array_equal(of["radii"], ref["radii"])
         assert np.array_equal(of["state"].field("vals").reshape(-1)[:n], ref["point_list"])
         assert np.array_equal(of["state"].field("keys").reshape(-1)[:n], ref["keys"])

@@ -60,3 +60,12 @@ def test_single_colour_tensor_trains_like_the_reference_layout():
     P = m._vertex.shape[0]
     assert m._shs.shape[0] == P and m.optimizer.state[m._shs]["exp_avg"].shape == m._shs.shape and torch.isfinite(m._shs).all()
     assert {"densification", "opacity_pruning"} <= {name for _, name, _, _ in m.log}
+
+
+def test_training_starts_from_create_from_pcd():
+    """Round 6: the loop started the way the reference's trainer starts it -- a point cloud through diff_recon_hip.create_from_pcd (distCUDA2 sizes the
+    equilateral triangles) -- still reduces the loss."""
+    import train_synthetic
+    losses, m, _ = train_synthetic.train("2D", iters=80, triangles=6000, width=192, height=144, views=2, views_per_step=1, log=None, updates=False,
+                                         init_from_pcd=True)
+    assert losses[-1] < 0.8 * losses[0], (losses[0], losses[-1])

@@ -115,30 +115,8 @@ def main():
     torch.cuda.synchronize()
     rows = {n: ms / max(k, 1) for n, ms, k in _C.profile_read()}
     _C.profile_enable(False)
-    n_render = int(out["pkg"]["render"].grad_fn is not None) and 0
-    # the same iteration with render + loss + backward + statistics replayed from ONE HIP graph
-    graph_ms, graph_err = None, None
-    try:
-        true_n = pkg2d.forward_overflowed  # noqa: F841
-        iteration()
-        torch.cuda.synchronize()
-        # the capacity of the sync-free forward: 1.3 x what the eager iteration rendered
-        import diff_triangle_rasterization_3D  # noqa: F401
-        node_n = _last_num_rendered(out["pkg"])
-        gs = D.GraphedStep(fwd_loss_bwd, instance_capacity=int(1.3 * node_n) + 4096)
-
-        def graphed():
-            gs.replay()
-            opt.step()
-        timed(graphed, 30)
-        graph_ms = timed(graphed, a.iters)
-        if gs.overflowed()[0]:
-            graph_err = "overflowed"
-    except Exception as e:  # report, do not lose the eager figures
-        graph_err = repr(e)[:200]
-    gc.enable()
-
     # the raster step alone: forward + backward with fixed upstream gradients at the rasterizer's resolution
+    node_n = _last_num_rendered(out["pkg"])
     raster_ms = raster_step_ms(s, c, W, H, dev, a.iters)
     n_img = 3 * c.h * c.w
     nparam = c.P * (9 + 1 + 3 * M)
@@ -161,14 +139,35 @@ def main():
     launches = {"downsample_fwd": 3, "downsample_bwd": 3}
     lib_ms = sum(ms * launches.get(n, 1) for n, ms in rows.items())
     raster_lib_ms = sum(ms for n, ms in rows.items() if n in raster_names)
-    line = {"config": a.config, "workload": f"P={c.P}, camera {c.w}x{c.h}, render_up_scale {c.up} (raster {W}x{H}), {c.rast}, SH degree {c.D}, gamma {c.gamma:g}, "
-                                             f"L1 + SSIM{' + %.2f x depth/normal' % c.w_geo if c.w_geo else ''}, FusedAdam, statistics",
-            "iteration_ms_eager": round(eager_ms, 4), "iteration_ms_graph": None if graph_ms is None else round(graph_ms, 4), "graph_note": graph_err,
-            "raster_step_ms": round(raster_ms, 4), "iteration_minus_raster_ms": round((graph_ms if graph_ms else eager_ms) - raster_ms, 4),
-            "library_kernels_ms_per_iteration": round(lib_ms, 4), "of_which_rasterizer": round(raster_lib_ms, 4),
-            "torch_glue_ms_per_iteration": round(max((graph_ms if graph_ms else eager_ms) - lib_ms, 0.0), 4),
-            "kernels": table}
-    print(json.dumps(line), flush=True)
+
+    def emit(graph_ms, graph_err):
+        it = graph_ms if graph_ms else eager_ms
+        line = {"config": a.config, "workload": f"P={c.P}, camera {c.w}x{c.h}, render_up_scale {c.up} (raster {W}x{H}), {c.rast}, SH degree {c.D}, gamma {c.gamma:g}, "
+                                                 f"L1 + SSIM{' + %.2f x depth/normal' % c.w_geo if c.w_geo else ''}, FusedAdam, statistics",
+                "iteration_ms_eager": round(eager_ms, 4), "iteration_ms_graph": None if graph_ms is None else round(graph_ms, 4), "graph_note": graph_err,
+                "raster_step_ms": round(raster_ms, 4), "iteration_minus_raster_ms": round(it - raster_ms, 4),
+                "library_kernels_ms_per_iteration": round(lib_ms, 4), "of_which_rasterizer": round(raster_lib_ms, 4),
+                "torch_glue_ms_per_iteration": round(max(it - lib_ms, 0.0), 4), "kernels": table}
+        print(json.dumps(line), flush=True)
+
+    emit(None, "eager only (the graph leg follows as a second line)")
+    # the same iteration with render + loss + backward + statistics replayed from ONE HIP graph; the autograd graph of the last eager iteration holds
+    # AccumulateGrad nodes created on the default stream -- a node that outlives its step breaks the capture: drop every reference first (bench.py)
+    out.clear()
+    vertex.grad = shs.grad = raw_opacity.grad = None
+    gc.collect()
+    try:
+        gs = D.GraphedStep(fwd_loss_bwd, instance_capacity=int(1.3 * node_n) + 4096)
+
+        def graphed():
+            gs.replay()
+            opt.step()
+        timed(graphed, 30)
+        graph_ms = timed(graphed, a.iters)
+        emit(graph_ms, "overflowed" if gs.overflowed()[0] else None)
+    except Exception as e:
+        emit(None, repr(e)[:200])
+    gc.enable()
 
 
 def _last_num_rendered(pkg):

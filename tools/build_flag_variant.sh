@@ -9,15 +9,21 @@ O=/tmp/ts2d_flagvar_$TAG
 mkdir -p $O $R/tools/bin
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-unused-result -DNDEBUG -fvisibility=hidden"
 pids=""
-for SRC in preprocess preprocess3d shgrad photometric depth_normal knn model_update optim binning render_group render3d_group api; do
+for SRC in preprocess preprocess3d shgrad photometric depth_normal aux_losses resample knn model_update optim binning select render3d_group api; do
   X=""
   case $SRC in
     render*) X="-mllvm -amdgpu-atomic-optimizer-strategy=None -fno-slp-vectorize";;
-    preprocess*|shgrad|depth_normal|optim) X="-ffp-contract=off";;
+    preprocess*|shgrad|depth_normal|aux_losses|resample|optim) X="-ffp-contract=off";;
   esac
   /opt/rocm/bin/hipcc $F $X "$@" -c $R/triangle-splatting_amd/csrc/$SRC.hip -o $O/$SRC.o &
   pids="$pids $!"
 done
+# the 2D blend kernels: one source, two translation units (build.py)
+BX="-mllvm -amdgpu-atomic-optimizer-strategy=None -fno-slp-vectorize"
+/opt/rocm/bin/hipcc $F $BX -DTSG_PART=1 -mllvm -amdgpu-sched-strategy=max-ilp "$@" -c $R/triangle-splatting_amd/csrc/render_group.hip -o $O/render_group_fwd.o &
+pids="$pids $!"
+/opt/rocm/bin/hipcc $F $BX -DTSG_PART=2 "$@" -c $R/triangle-splatting_amd/csrc/render_group.hip -o $O/render_group_bwd.o &
+pids="$pids $!"
 for p in $pids; do wait $p; done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/bin/libts2d_$TAG.so $O/*.o
 echo $R/tools/bin/libts2d_$TAG.so
@@ -30,7 +36,8 @@ for SRC in render render3d render_q8 lab_hooks api; do
     render*) X="-mllvm -amdgpu-atomic-optimizer-strategy=None -fno-slp-vectorize";;
     api) X="-DTS2D_LAB";;
   esac
-  /opt/rocm/bin/hipcc $F $X "$@" -c $R/triangle-splatting_amd/csrc/$SRC.hip -o $O/lab/$SRC.o &
+  D=$R/tools/lab; [ $SRC = api ] && D=$R/triangle-splatting_amd/csrc   # the lab kernels live in tools/lab/ since round 6
+  /opt/rocm/bin/hipcc $F $X -I$R/triangle-splatting_amd/csrc "$@" -c $D/$SRC.hip -o $O/lab/$SRC.o &
   pids="$pids $!"
 done
 for p in $pids; do wait $p; done

@@ -7,9 +7,10 @@ python $R/triangle-splatting_amd/build.py --lab > /dev/null
 B=$R/triangle-splatting_amd/build
 F="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -Wall -Wno-unused-function -Wno-unused-result -DNDEBUG -DTS2D_STATS -mllvm -amdgpu-atomic-optimizer-strategy=None -fno-slp-vectorize"
 mkdir -p $R/tools/bin /tmp/ts2d_stats
-for f in render_q8 render_group; do
-  /opt/rocm/bin/hipcc $F -c $R/triangle-splatting_amd/csrc/$f.hip -o /tmp/ts2d_stats/$f.o &
-done
+C=$R/triangle-splatting_amd/csrc
+/opt/rocm/bin/hipcc $F -I$C -c $R/tools/lab/render_q8.hip -o /tmp/ts2d_stats/render_q8.o &
+/opt/rocm/bin/hipcc $F -DTSG_PART=1 -c $C/render_group.hip -o /tmp/ts2d_stats/render_group_fwd.o &   # (two translation units since round 6)
+/opt/rocm/bin/hipcc $F -DTSG_PART=2 -c $C/render_group.hip -o /tmp/ts2d_stats/render_group_bwd.o &
 wait
 OBJS=""
 for o in $B/lab/*.o $B/*.o; do

@@ -21,6 +21,21 @@ __global__ void __launch_bounds__(256) stream64(const float4 *__restrict__ rec, 
     const float4 a = rec[i];
     if (a.x == 123.456f) out[i & 1023] = a.y;
 }
+// Round 6: the WRITE side.  fill64: a streaming dwordx4 store of known size (what the zero / per-triangle kernels do); scatter64: every lane stores ONE
+// 64-byte record at a pseudo-random index (the blend backward's row flush without the read-modify-write).   rocprofv3 --pmc WRITE_SIZE -- gather_calib
+__global__ void __launch_bounds__(256) fill64(float4 *__restrict__ rec, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 4 * n) rec[i] = make_float4(1.0f, 2.0f, 3.0f, 4.0f);
+}
+__global__ void __launch_bounds__(256) scatter64(float4 *__restrict__ rec, const unsigned *__restrict__ idx, int n)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float4 *p = rec + 4 * (size_t)idx[i];
+    const float4 v = make_float4((float)i, 1.0f, 2.0f, 3.0f);
+    p[0] = v; p[1] = v; p[2] = v; p[3] = v;
+}
 __global__ void make_perm(unsigned *idx, unsigned n, unsigned mult)
 {
     const unsigned i = blockIdx.x * 256 + threadIdx.x;
@@ -40,6 +55,8 @@ int main()
     {
         hipLaunchKernelGGL(gather64, dim3((n + 255) / 256), dim3(256), 0, 0, rec, idx, out, n);
         hipLaunchKernelGGL(stream64, dim3((4 * n + 255) / 256), dim3(256), 0, 0, rec, out, n);
+        hipLaunchKernelGGL(fill64, dim3((4 * n + 255) / 256), dim3(256), 0, 0, rec, n);
+        hipLaunchKernelGGL(scatter64, dim3((n + 255) / 256), dim3(256), 0, 0, rec, idx, n);
     }
     (void)hipDeviceSynchronize();
     printf("records %d, bytes per kernel %zu (+ %zu index bytes for gather64)\n", n, (size_t)n * 64, (size_t)n * 4);

@@ -5,7 +5,7 @@ gradient records (64 bytes per triangle, `--known-fill-bytes`), whose fill kerne
 import collections, csv, glob, json, re, sys
 
 NAMES = ["render_fwd_group", "render_bwd_group", "render_fwd", "render_bwd", "render3d_fwd", "render3d_bwd", "preprocess_fwd", "preprocess_bwd",
-         "scan_emit", "gather_blocksum", "rs_hist", "rs_prefix", "rs_scatter", "tile_ranges", "fillBuffer"]
+         "scan_emit", "gather_blocksum", "rs_hist", "rs_prefix", "rs_scatter", "tile_ranges", "fillBuffer", "zero_words4"]
 
 
 def short(k):
@@ -39,12 +39,31 @@ if len(sys.argv) > 4:
         gather_factor = (n_rec * 68.0) / (sum(acc["gather64"]) / len(acc["gather64"]) * 1024.0)  # 64 B record + 4 B index per lane
     if acc.get("stream64"):
         stream_factor = (n_rec * 64.0) / (sum(acc["stream64"]) / len(acc["stream64"]) * 1024.0)
+# optional 5th argument: a --pmc WRITE_SIZE pass of tools/bin/gather_calib (round 6: a streaming store and a 64-byte record scatter of KNOWN size)
+write_stream_factor = write_scatter_factor = None
+if len(sys.argv) > 5:
+    f = sorted(glob.glob(sys.argv[5] + "/*/*_counter_collection.csv"))[-1]
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == "WRITE_SIZE":
+            acc["fill64" if "fill64" in r["Kernel_Name"] else "scatter64" if "scatter64" in r["Kernel_Name"] else "other"].append(float(r["Counter_Value"]))
+    n_rec = 4 * 1000 * 1000 + 1
+    if acc.get("fill64") and sum(acc["fill64"]) > 0:
+        write_stream_factor = (n_rec * 64.0) / (sum(acc["fill64"]) / len(acc["fill64"]) * 1024.0)
+    if acc.get("scatter64") and sum(acc["scatter64"]) > 0:
+        write_scatter_factor = (n_rec * 64.0) / (sum(acc["scatter64"]) / len(acc["scatter64"]) * 1024.0)
 (fetch, nf), (write, nw) = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+# the step's own store of known size: the clear of the gradient records (a kernel since round 5: zero_words4_kernel; hipMemsetAsync's fill kernel before)
+fill_name = "zero_words4" if write.get("zero_words4", 0) > 0 else "fillBuffer"
+if known > 0 and not write.get(fill_name, 0) > 0:
+    sys.exit(f"WRITE_SIZE calibration failed: the fill of {int(known)} known bytes reported {write.get(fill_name, 0)} KiB (kernels seen: {sorted(write)})")
 wcal = 1.0
-if known > 0 and write.get("fillBuffer", 0) > 0:
-    wcal = known / (write["fillBuffer"] * 1024.0)
+if known > 0:
+    wcal = known / (write[fill_name] * 1024.0)
 out = {"_calibration": {"fetch_factor": 2.0, "write_factor": round(wcal, 4),
-                        "write_calibrated_on": f"fill kernel of {int(known)} known bytes: WRITE_SIZE reported {write.get('fillBuffer', 0):.1f} KiB",
+                        "write_calibrated_on": f"{fill_name} kernel of {int(known)} known bytes: WRITE_SIZE reported {write.get(fill_name, 0):.1f} KiB",
+                        "write_factor_measured_streaming_dwordx4_store": None if write_stream_factor is None else round(write_stream_factor, 4),
+                        "write_factor_measured_64B_record_scatter": None if write_scatter_factor is None else round(write_scatter_factor, 4),
                         "fetch_factor_measured_64B_record_gather": None if gather_factor is None else round(gather_factor, 4),
                         "fetch_factor_measured_streaming_dwordx4": None if stream_factor is None else round(stream_factor, 4),
                         "note": "FETCH_SIZE x2 per MI355X_MICROARCH.md (wide reads); WRITE_SIZE x write_factor (own calibration); the blend kernels read "

@@ -1,6 +1,7 @@
 #!/bin/bash
-# tools/lease.sh -- ONE parameterised script for every GPU lease (round 6 on; rounds 4-5 kept one script per lease, tools/r05_call*.sh were folded
-# into this).  A lease is a list of steps, each a shell function below:
+# tools/lease.sh -- ONE parameterised script for every GPU lease (round 6 on).  Rounds 3-5 kept one script per lease (tools/r03_prof.sh, r04_*.sh,
+# r05_call1.sh ... r05_call19.sh, final_*.sh: ~30 files, deleted in round 6 -- `git log -- tools/r05_call7.sh` has them; every one was a sequence of
+# the steps below: tests, bench lines, A/B of two libraries, rocprofv3 trace, counter pass).  A lease is a list of steps, each a shell function:
 #     gpurun --timeout 1500 -- 'bash tools/lease.sh r06_a "t tests/test_side_stream_gpu.py; bench head; ab r05 2; prof head"'
 # Output goes to gpurun_out/<tag>/ (merged back by gpurun); what is worth judging is copied from there into profiles/ by hand.
 R=${GRAFT_REPO_ROOT:-/root/repo}

@@ -3,8 +3,8 @@
     python triangle-splatting_amd/build.py [--force] [--verbose] [--lab]
 
 Output: triangle-splatting_amd/diff_triangle_rasterization_2D/libts2d.so (git-ignored, travels with gpurun).
---lab builds tools/bin/libts2d_lab.so instead: the same objects + the measurement kernels of earlier rounds (render.hip, render3d.hip,
-render_q8.hip) and api.hip compiled with -DTS2D_LAB, which reads TS2D_BLEND / TS2D_BWD / TS2D_ABLATE.  The product library contains
+--lab builds tools/bin/libts2d_lab.so instead: the same objects + the measurement kernels of earlier rounds (tools/lab/: render.hip, render3d.hip,
+render_q8.hip, lab_hooks.hip) and api.hip compiled with -DTS2D_LAB, which reads TS2D_BLEND / TS2D_BWD / TS2D_ABLATE.  The product library contains
 one blend path per variant and reads no environment; only tools/ and tests/ load the lab library (TS2D_LIBRARY_PATH, see _C.py).
 hipcc cross-compiles without a GPU.  Per-file flags matter:
   * preprocess.hip is built with -ffp-contract=off (bit-comparable integer state, see the file header);
@@ -58,6 +58,8 @@ LAB_SOURCES = {  # measurement kernels: libts2d_lab.so only
     "api.hip": ["-DTS2D_LAB"],
 }
 LAB_LIB = os.path.join(os.path.dirname(HERE), "tools", "bin", "libts2d_lab.so")
+LAB_SRC = os.path.join(os.path.dirname(HERE), "tools", "lab")  # render.hip, render3d.hip, render_q8.hip, lab_hooks.hip: measurement kernels of rounds 1-3 and the
+                                                                # test hooks -- out of the product's csrc/ since round 6; they include csrc's headers (-I)
 HEADERS = ["ts2d_common.h", "ts2d_lab.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_support.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", "ts2d_imgops.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
            os.path.join("..", "..", "include", "ts_knn.h"),
@@ -103,6 +105,9 @@ def build(force: bool = False, verbose: bool = False, lab: bool = False) -> str:
     for src, extra in sources.items():
         src, _, part = src.partition("@")  # "file.hip@tag": the same source compiled into file_tag.o with its own flags
         s = os.path.join(CSRC, os.path.basename(src))
+        if not os.path.exists(s):  # a lab-only source
+            s = os.path.join(LAB_SRC, os.path.basename(src))
+            extra = list(extra) + ["-I" + CSRC]
         o = os.path.join(OBJ_DIR, src.replace(".hip", ("_" + part if part else "") + ".o"))
         objs.append(o)
         cmd = [cc, *COMMON, *extra, "-c", s, "-o", o]

@@ -1224,7 +1224,7 @@ int ts2d_debug_read_state(const ts2d_state *state, int32_t P, int64_t N, int32_t
     return TS2D_OK;
 }
 
-// ts2d_test_sort_pairs / ts2d_test_inclusive_scan_rocprim: csrc/lab_hooks.hip (the rocPRIM comparators live there, outside the product's objects)
+// ts2d_test_sort_pairs / ts2d_test_inclusive_scan_rocprim: tools/lab/lab_hooks.hip (the rocPRIM comparators live there, outside the product's objects)
 void ts2d_lab_force_ticket_passes(int on) { ts_force_ticket_passes(on != 0); }
 void ts2d_lab_force_all_quadrants(int on) { g_lab_all_quadrants = on != 0; }
 void ts2d_lab_side_stream(int on) { g_lab_side_stream = on != 0; }

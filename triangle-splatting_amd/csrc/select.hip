@@ -24,28 +24,33 @@ struct SelState
 // (prefix, remaining rank) after `passes` passes, recomputed from the histograms by whoever needs it (256 threads, one block-wide scan per pass)
 __device__ __forceinline__ void sel_resolve(const SelState *st, int passes, unsigned long long rank, uint32_t &prefix, unsigned long long &rem)
 {
-    __shared__ uint32_t s_cnt[256];
     __shared__ uint32_t s_pick;
     __shared__ unsigned long long s_before;
     prefix = 0u;
     rem = rank;
+    __shared__ unsigned long long s_wave[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int p = 0; p < passes; p++)
     {
-        __syncthreads();
-        s_cnt[threadIdx.x] = st->hist[p][threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x == 0) // 256 additions: not worth a parallel scan
+        // inclusive scan of the 256 digit totals over the block's 256 threads (wave scan + four wave totals); the bin that holds the remaining
+        // rank is the one thread whose [exclusive, inclusive) interval contains it
+        const unsigned long long cnt = st->hist[p][threadIdx.x];
+        unsigned long long inc = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1)
         {
-            unsigned long long cum = 0;
-            uint32_t b = 0;
-            for (; b < 255u; b++)
-            {
-                if (cum + s_cnt[b] > rem) break;
-                cum += s_cnt[b];
-            }
-            s_pick = b;
-            s_before = cum;
+            const unsigned long long up = __shfl_up(inc, o);
+            if (lane >= o) inc += up;
         }
+        __syncthreads(); // (the previous pass's readers of s_pick / s_before / s_wave are done)
+        if (lane == 63) s_wave[wave] = inc;
+        __syncthreads();
+        unsigned long long off = 0;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        inc += off;
+        const unsigned long long exc = inc - cnt;
+        if (cnt > 0 && exc <= rem && rem < inc) { s_pick = threadIdx.x; s_before = exc; }
+        if (threadIdx.x == 255 && rem >= inc) { s_pick = 255u; s_before = exc; } // (a rank beyond the population: cannot happen for rank <= n - 1)
         __syncthreads();
         prefix |= s_pick << (24 - 8 * p);
         rem -= s_before;

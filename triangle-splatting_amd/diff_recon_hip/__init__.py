@@ -18,6 +18,8 @@
                           (reference: src/diff_recon/models/VanillaTS_model.py:108-124, src/diff_recon/trainers/VanillaTS_trainer.py:119-122)
     model_forward.py      render_view = the argument construction of VanillaTSModel.forward
                           (reference: src/diff_recon/models/VanillaTS_model.py:585-694)
+    model_init.py         create_from_pcd (point cloud -> distCUDA2 -> equilateral triangles, back-face twins), grid / random / direct sampling
+                          (reference: src/diff_recon/models/VanillaTS_model.py:761-804, 830-917; model_utils.py:34-57, 95-149)
     graphed.py            GraphedStep: a whole training step (sync-free forward, loss, backward, optimizer) captured once into a HIP graph and
                           replayed with one launch -- no counterpart in the reference, whose forward reads num_rendered back every step
 
@@ -32,3 +34,4 @@ from . import schedulers  # noqa: F401
 from .raw_triangle import RawTriangle  # noqa: F401
 from .optim import FusedAdam, ShardedAdam  # noqa: F401
 from .graphed import GraphedStep  # noqa: F401
+from .model_init import create_from_pcd, grid_sampling, grid_size_search, get_inside_mask, inter_point_distance, sample_points  # noqa: F401
