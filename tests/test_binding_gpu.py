@@ -87,3 +87,23 @@ def test_binding_checks_and_empty_input():
     out = ext.rasterize_triangles(32, 32, *cam, torch.empty((0, 3, 3), device="cuda"), torch.empty((0, 1, 3), device="cuda"), empty,
                                   torch.empty((0, 1), device="cuda"), False, True, False)
     assert out[0] == 0 and float(out[1].abs().sum()) == 0.0 and out[7].numel() == 0  # extension_interface.cu:130
+
+
+def test_the_package_runs_on_both_bindings():
+    """Round 6: the compiled binding is the package's default, ctypes the fallback -- every test that goes through the package
+    must be green on BOTH.  This process runs on the default (asserted); the structured parity cases, the speculative / sync-free forward tests
+    (device-tensor background depth, capacity overflow, graph replay) and the exchange-bucket tests (preallocated outputs, factored SH gradients,
+    ranged backward) run once more in a child process with TS2D_BINDING=ctypes."""
+    import os
+    import subprocess
+    import sys
+    from diff_triangle_rasterization_2D import _C
+    assert _C.binding() == "compiled" or os.environ.get("TS2D_BINDING") == "ctypes" or os.environ.get("TS2D_LIBRARY_PATH")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, TS2D_BINDING="ctypes")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        os.path.join(here, "test_parity_gpu.py"), os.path.join(here, "test_speculative_forward_gpu.py"), os.path.join(here, "test_async_forward_gpu.py"),
+                        os.path.join(here, "test_factored_gpu.py"), os.path.join(here, "test_parity3d_gpu.py"),
+                        "-k", "not full_size and not lab and not forced and not one_launch"], env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout

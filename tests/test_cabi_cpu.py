@@ -196,7 +196,8 @@ def test_missing_library_fails_loudly(tmp_path, hip_lib_built):
 
 def test_compiled_reference_side_binding_loads(hip_lib_built):
     """bindings/_ts2d_torch_C.so (torch C++ extension with the reference's ext.cpp signatures, linked against libts2d.so) builds
-    without a GPU and exports exactly the reference's two entry points (R2D/ext.cpp:4-9)."""
+    without a GPU and exports the reference's two entry points (R2D/ext.cpp:4-9) plus, since round 6, the package's own two (`*_ex`: the same
+    calls with the variant / capacity / preallocated-output arguments the package adds; diff_triangle_rasterization_2D/_C.py prefers them over ctypes)."""
     import importlib.util
     import torch  # noqa: F401
     spec = importlib.util.spec_from_file_location("ts2d_build_ext", os.path.join(ROOT, "triangle-splatting_amd", "bindings", "build_torch_ext.py"))
@@ -206,7 +207,10 @@ def test_compiled_reference_side_binding_loads(hip_lib_built):
     spec = importlib.util.spec_from_file_location("_ts2d_torch_C", so)
     ext = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ext)
-    assert sorted(n for n in dir(ext) if not n.startswith("_")) == ["rasterize_triangles", "rasterize_triangles_backward"]
+    assert sorted(n for n in dir(ext) if not n.startswith("_")) == ["rasterize_triangles", "rasterize_triangles_backward", "rasterize_triangles_backward_ex",
+                                                                    "rasterize_triangles_ex"]
+    from diff_triangle_rasterization_2D import _C
+    assert _C.binding() == ("ctypes" if (os.environ.get("TS2D_BINDING") == "ctypes" or os.environ.get("TS2D_LIBRARY_PATH")) else "compiled")
     with pytest.raises(RuntimeError):  # CPU tensors: the checks pass, the library refuses host pointers or the device guard raises
         z = torch.zeros
         ext.rasterize_triangles(8, 8, 0.3, 0.3, z(4, 4), z(4, 4), z(3), 0, 1.0, 1.0, 1.0, z(3), z(2, 3, 3), z(2, 1, 3), torch.empty(0), z(2, 1),

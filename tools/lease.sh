@@ -28,9 +28,9 @@ print('$1', j['ms_per_step'], 'dev_med=%s idle=%s host_med=%s' % (c['device_step
 bench() { local n=$1; shift; timeout 600 python bench.py "$@" 2>$O/$n.err | tee -a $O/$n.jsonl | _sum $n | tee -a $O/summary.txt; }
 
 # ab <libtag> <rounds> [bench.py args]: the product library and tools/bin/libts2d_<libtag>.so alternating on this box
-ab() { local L=$1 n=$2; shift 2; for i in $(seq $n); do
+ab() { local L=$1 n=$2; shift 2; export TS2D_BINDING=ctypes; for i in $(seq $n); do   # both sides through ctypes: the compiled binding is linked to the product library
     bench ab_product --no-cpu-baseline "$@"
-    TS2D_LIBRARY_PATH=$R/tools/bin/libts2d_$L.so bench ab_$L --no-cpu-baseline "$@"; done; }
+    TS2D_LIBRARY_PATH=$R/tools/bin/libts2d_$L.so bench ab_$L --no-cpu-baseline "$@"; done; unset TS2D_BINDING; }
 
 # abflag <rounds> <flag> [bench.py args]: the lab library with and without one bench.py switch (e.g. --no-side-stream), alternating
 abflag() { local n=$1 f=$2; shift 2; for i in $(seq $n); do

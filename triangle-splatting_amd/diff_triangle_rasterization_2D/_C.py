@@ -38,6 +38,33 @@ if not os.path.exists(_LIB_PATH):
     )
 _lib = C.CDLL(_LIB_PATH)
 
+# ---- the compiled binding (bindings/ts2d_torch_ext.cpp -> bindings/_ts2d_torch_C.so) is the default since round 6 ---------------------------------
+# The two hot entry points below cost 0.3-0.4 ms of host time per forward + backward through ctypes (argument marshalling, ~15 torch allocations from
+# Python) -- what bounds every scene below ~100 k triangles.  The torch extension built by __graft_entry__.build() does the same
+# work in C++ on the same libts2d.so; it is used whenever it exists.  ctypes remains (a) the fallback when the extension was not built, (b) the path
+# of every measurement that swaps the library (TS2D_LIBRARY_PATH: the extension is linked against the product library), (c) selectable with
+# TS2D_BINDING=ctypes (tests/test_binding_gpu.py runs the package through both).  Everything that is not on the per-step path (profile hooks,
+# capacity hints, sh_grad_expand, forward_status) stays on ctypes: same library instance, loaded once.
+_ext = None
+_EXT_PATH = os.path.join(os.path.dirname(_HERE), "bindings", "_ts2d_torch_C.so")
+if os.environ.get("TS2D_BINDING", "") != "ctypes" and not os.environ.get("TS2D_LIBRARY_PATH") and os.path.exists(_EXT_PATH):
+    try:
+        import importlib.util as _ilu
+        _spec = _ilu.spec_from_file_location("_ts2d_torch_C", _EXT_PATH)
+        _mod = _ilu.module_from_spec(_spec)
+        _spec.loader.exec_module(_mod)
+        if hasattr(_mod, "rasterize_triangles_ex") and hasattr(_mod, "rasterize_triangles_backward_ex"):
+            _ext = _mod
+    except (ImportError, OSError) as _e:  # a stale build against another torch: fall back, loudly
+        import warnings
+        warnings.warn(f"{_EXT_PATH} could not be loaded ({_e}); using the ctypes binding (rebuild with bindings/build_torch_ext.py --force)")
+
+
+def binding() -> str:
+    """'compiled' or 'ctypes': which binding rasterize_triangles / rasterize_triangles_backward go through."""
+    return "compiled" if _ext is not None else "ctypes"
+
+
 FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS, FLAG_3D, FLAG_SH_FACTORED = 1, 2, 4, 8, 16, 32
 MAX_CHANNELS = 3
 
@@ -206,6 +233,12 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
     instances, nothing is read back, and the returned `num_rendered` is the capacity (it only sizes the state for the backward
     call); whether the true count fitted is reported by `forward_status`.  Default None = the reference's sequence with its one
     blocking read of num_rendered."""
+    if _ext is not None:
+        bg_t = background_depth if isinstance(background_depth, torch.Tensor) else None
+        return _ext.rasterize_triangles_ex(int(image_width), int(image_height), tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, int(sh_degree), gamma,
+                                           scale_modifier, 0.0 if bg_t is not None else float(background_depth), background, vertex, shs, feature, opacity,
+                                           bool(back_culling), bool(rich_info), bool(debug), int(variant),
+                                           int(instance_capacity) if (instance_capacity is not None and vertex.size(0) > 0) else 0, bg_t)
     P = vertex.size(0)
     H, W = int(image_height), int(image_width)
     use_shs = _use_shs(shs, feature)
@@ -302,6 +335,15 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
     "color" = dL_dshs (P,M,3) or dL_dfeature (P,C)) that the library writes instead of fresh allocations (parallel.GradBucket).
     `range_events`: a list of K torch.cuda.Event (each recorded at least once before): the per-triangle kernel runs as K launches over
     consecutive triangle ranges of `backward_range_rows(P, K)` rows and event k is recorded behind range k (ts2d_backward_ranged)."""
+    if _ext is not None:
+        bg_t = background_depth if isinstance(background_depth, torch.Tensor) else None
+        o = out or {}
+        return _ext.rasterize_triangles_backward_ex(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, int(sh_degree), gamma, scale_modifier,
+                                                    0.0 if bg_t is not None else float(background_depth), background, vertex, shs, feature, opacity,
+                                                    int(num_rendered), radii, geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
+                                                    dL_dout_normal, bool(rich_info), bool(debug), int(variant), bool(sh_factored), o.get("vertex"),
+                                                    o.get("center2D"), o.get("color"), o.get("opacity"), bg_t,
+                                                    [int(e.cuda_event) for e in range_events] if range_events else [])
     P = vertex.size(0)
     H, W = dL_dout_feature.size(1), dL_dout_feature.size(2)  # extension_interface.cu:182-183
     use_shs = _use_shs(shs, feature)
