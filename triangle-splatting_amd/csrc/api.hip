@@ -18,6 +18,7 @@
 #pragma GCC visibility pop
 #include "ts2d_common.h"
 #include <atomic>
+#include <chrono>
 
 #include <cstdarg>
 #include <cstdio>
@@ -276,12 +277,19 @@ inline void cpu_relax()
 // does not burn a core while the GPU works through a queue of earlier launches, and a faulted launch surfaces as an error.
 int wait_early_count(const EarlyCount &early, unsigned long long *n_out)
 {
+    // Bounded by TIME (round 6): 250 us.  The count is published ~50-120 us after the per-triangle kernel starts (that kernel + the depth sort's first
+    // two launches).  A fixed iteration count (20 000 pauses = 20-60 us, rounds 3-5) was just long enough for the ctypes binding, whose own overhead
+    // delayed the wait; the compiled binding reaches this loop earlier, ran out of spins on small scenes and paid the sleep's wake-up latency on the
+    // critical path of EVERY step (10 k triangles: 0.30 ms per step against 0.20 through ctypes, profiles/r06_binding.txt).  A host thread still
+    // never spins unbounded: behind 250 us it sleeps on the event (eight ranks must not burn eight cores on a long queue).
     unsigned long long n = ~0ull;
-    for (unsigned spin = 0; spin < 20000u; spin++) // ~20-60 us
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spin = 0;; spin++)
     {
         n = __atomic_load_n(early.host, __ATOMIC_ACQUIRE);
         if (n != ~0ull) break;
         cpu_relax();
+        if ((spin & 63u) == 63u && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(250)) break;
     }
     if (n == ~0ull)
     {
