@@ -615,7 +615,7 @@ FP32_VECTOR_PEAK = 157.3e12                                   # MI355X_MICROARCH
 def compute_side(kernel, avg_ms, headline):
     """The roofline the blend kernels actually sit on (they are bound by VALU issue), from the committed SQ-counter
     pass of the same workload (profiles/blend_pmc.json, tools/collect_blend_pmc.sh), the static instruction mix of the kernel's step
-    loop (profiles/r05_valu_mix.json, tools/isa_mix.py) and the lane-group statistics (profiles/blend_stats.json).  Two bounds on the
+    loop (profiles/r06_valu_mix.json, tools/isa_mix.py) and the lane-group statistics (profiles/blend_stats.json).  Two bounds on the
     VALU time, both in the kernel's own cycles (GRBM_GUI_ACTIVE of the launch):
       valu_busy_frac_lower = SQ_INSTS_VALU x 2 cycles (every instruction at the full wave64-on-SIMD32 rate) / (SIMDs x cycles);
       valu_busy_frac_upper = SQ_INSTS_VALU x the step loop's mix priced with the issue costs measured in REAL shader cycles
@@ -634,7 +634,7 @@ def compute_side(kernel, avg_ms, headline):
                        transcendental_insts_per_launch=v.get("SQ_INSTS_VALU_TRANS_F32"), lds_busy_frac=v.get("lds_busy_frac"),
                        avg_waves_per_simd=v.get("avg_waves_per_simd"), wave_cycle_split=v.get("wave_cycle_split"),
                        kernel_cycles=v.get("kernel_cycles"))
-            mix = json.load(open(os.path.join(ROOT, "profiles", "r05_valu_mix.json"))).get(kernel)
+            mix = json.load(open(os.path.join(ROOT, "profiles", "r06_valu_mix.json"))).get(kernel)
             if mix and v.get("kernel_cycles"):
                 out.update(step_loop_mix={k: mix[k] for k in ("full", "half", "trans")},
                            priced_cycles_per_valu_instruction=mix["priced_cycles_per_valu_instruction"],

@@ -59,11 +59,14 @@ def innermost_loops(lines):
 def main():
     text = ""
     with tempfile.TemporaryDirectory() as tmp:
-        for name in ("render_group.hip", "render3d_group.hip"):
+        # the product's translation units with the product's flags (triangle-splatting_amd/build.py): since round 6 the 2D forward and backward are
+        # compiled separately, the forward with -amdgpu-sched-strategy=max-ilp
+        units = (("render_group.hip", ["-DTSG_PART=1", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]), ("render_group.hip", ["-DTSG_PART=2"]), ("render3d_group.hip", []))
+        for name, extra in units:
             src = os.path.join(ROOT, "triangle-splatting_amd", "csrc", name)
             asm = os.path.join(tmp, "k.s")
             subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-DNDEBUG", "-mllvm",
-                            "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src,
+                            "-amdgpu-atomic-optimizer-strategy=None", "-fno-slp-vectorize", *extra, "-I" + os.path.join(ROOT, "include"), "--cuda-device-only", "-S", src,
                             "-o", asm], check=True, capture_output=True)
             text += open(asm).read() + "\n"
     res = {}

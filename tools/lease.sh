@@ -61,4 +61,36 @@ for l in sys.stdin:
 # loss [H W]: tools/bench_loss.py (the fused L1 + SSIM against the eager-torch kernel sequence)
 loss() { timeout 600 python tools/bench_loss.py "$@" 2>/dev/null | tee -a $O/loss_bench.jsonl; }
 
+# final: everything a round's profiles/ needs from ONE box, with the committed tree -- the driver's command four times, its rocprofv3 kernel stats and
+# gaps, counter passes (HBM traffic with both calibrations, SQ counters of the blend kernels), the other configurations, forward-only lines, training
+# iterations, the loss kernels.  Copy what is worth judging from gpurun_out/<tag>/ into profiles/ (named r<NN>_*).
+final() {
+    t tests/test_side_stream_gpu.py tests/test_loss_gpu.py tests/test_model_init_gpu.py tests/test_binding_gpu.py
+    for i in 1 2 3 4; do bench bench_series --steps 20 --warmup 5 $([ $i -gt 1 ] && echo --no-cpu-baseline); done
+    prof driver --steps 20 --warmup 5
+    bash tools/prof_gaps.sh > $O/gaps.txt 2>&1; tail -20 $O/gaps.txt
+    bash tools/collect_hbm_traffic.sh > $O/hbm_traffic.log 2>&1; cp gpurun_out/hbm_traffic.json $O/ 2>/dev/null; tail -3 $O/hbm_traffic.log
+    bash tools/collect_blend_pmc.sh > $O/blend_pmc.log 2>&1; cp gpurun_out/blend_pmc.json $O/ 2>/dev/null; tail -3 $O/blend_pmc.log
+    c() { local n=$1; shift; bench configs --no-cpu-baseline "$@"; }
+    c 10k --triangles 10000 --width 256 --height 256 --sh-degree 0 --steps 200 --warmup 20
+    c 10k_graph --triangles 10000 --width 256 --height 256 --sh-degree 0 --steps 200 --warmup 20 --hip-graph
+    c 300k --triangles 300000 --width 800 --height 800 --steps 40 --warmup 5
+    c 2M --triangles 2000000 --steps 15 --warmup 4
+    c 93k3d --triangles 93000 --width 1600 --height 1600 --sh-degree 0 --rasterizer 3D --steps 100 --warmup 10
+    c 93k3d_graph --triangles 93000 --width 1600 --height 1600 --sh-degree 0 --rasterizer 3D --steps 100 --warmup 10 --hip-graph
+    c 93k3d_g50 --triangles 93000 --width 1600 --height 1600 --sh-degree 0 --rasterizer 3D --gamma 50 --steps 100 --warmup 10
+    c 5M3d --triangles 5000000 --sh-degree 0 --rasterizer 3D --steps 10 --warmup 3
+    c 5M2d --triangles 5000000 --sh-degree 0 --steps 10 --warmup 3
+    c head3d --rasterizer 3D --steps 20 --warmup 5
+    c head_syncfree --sync-free --steps 20 --warmup 5
+    c head_graph --hip-graph --steps 20 --warmup 5
+    c head_centered --scene-mode centered --steps 20 --warmup 5
+    c head_g50 --gamma 50 --steps 20 --warmup 5
+    c head_adam --with-optimizer --steps 20 --warmup 5
+    bench forward_only --forward-only --steps 40 --warmup 5
+    bench forward_only --forward-only --triangles 300000 --width 800 --height 800 --steps 80 --warmup 10
+    for cfg in headline lego300k mesh93k mesh93k_g50; do train $cfg; done
+    loss; loss 800 800; loss 2160 3840
+}
+
 eval "$@"
