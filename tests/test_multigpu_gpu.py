@@ -233,6 +233,21 @@ def _rccl_world1_worker(port, q):
                 got[0].mul_(1.0)
             torch.cuda.synchronize()
             errs[mode + "+ranges"] = [rel(g, w) for g, w in zip(list(got) + [got_shs], want)]
+            # a SECOND view under the same capture adds into the bucket behind the first backward's range events -- they no longer say
+            # "rows final", so the ranged exchange must fall back to ordering itself behind the compute stream as a whole.  Twice the same view:
+            # the bucket must hold exactly twice the single view's gradients (a race would show as a wrong sum or a torn bucket).
+            for it in range(3):
+                sink = parallel.ShGradSink()
+                from diff_triangle_rasterization_2D import TriangleRasterizationSettings  # noqa: F401
+                with rb.capture(), parallel.factored_sh_grads(sink):
+                    for _v in range(2):
+                        _render(s, _view(0), 2, dev, vertex, shs, opacity)
+                assert not rb._ranges_recorded  # invalidated by the second view's add_
+                rb.reduce_ranges_async()
+                got = rb.wait()
+                got[0].mul_(1.0)
+            torch.cuda.synchronize()
+            errs[mode + "+ranges, two views"] = [rel(g, 2 * w) for g, w in zip(list(got), want[:3])]
         ok = all(e < 2e-5 for v in errs.values() for e in v)
         q.put((bool(ok), errs))
     finally:
