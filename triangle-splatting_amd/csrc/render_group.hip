@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
             if (k < nflush)
             {
                 const unsigned long long fx48 = tsum[k];
-                if (TSG_PROBE != 5 && fx48 != 0ull) tile_stats_flush(fx48, tmax[k], ids[j], contrib_sum, contrib_max);
+                if (TSG_PROBE != 5 && fx48 != 0ull) tile_stats_flush(fx48, tmax[k], TSG_PROBE == 9 ? ((range.x + (uint32_t)k) & 0x3FFFFu) : ids[j], contrib_sum, contrib_max);
             }
         }
     }

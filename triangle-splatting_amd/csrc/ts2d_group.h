@@ -264,6 +264,13 @@ __device__ __forceinline__ void tile_stats_add(unsigned long long *tsum, int *tm
 }
 __device__ __forceinline__ void tile_stats_flush(unsigned long long fx48, int mxbits, uint32_t tid, float *contrib_sum, float *contrib_max)
 {
+#if defined(TSG_PROBE) && TSG_PROBE == 8 // profiling build (results wrong): plain scattered stores in place of the two atomics -- what the ATOMIC costs
+    contrib_sum[tid] = (float)((double)fx48 * 0x1p-48);
+    contrib_max[tid] = __int_as_float(mxbits);
+#elif defined(TSG_PROBE) && TSG_PROBE == 9 // profiling build (results wrong): ONE coalesced 8-byte store per instance at its list position
+    ((float2 *)contrib_sum)[tid] = make_float2((float)((double)fx48 * 0x1p-48), __int_as_float(mxbits));
+#else
     global_stats_add(tid, (float)((double)fx48 * 0x1p-48), __int_as_float(mxbits), contrib_sum, contrib_max);
+#endif
 }
 } // namespace
