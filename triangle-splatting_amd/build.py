@@ -60,7 +60,7 @@ LAB_SOURCES = {  # measurement kernels: libts2d_lab.so only
 LAB_LIB = os.path.join(os.path.dirname(HERE), "tools", "bin", "libts2d_lab.so")
 LAB_SRC = os.path.join(os.path.dirname(HERE), "tools", "lab")  # render.hip, render3d.hip, render_q8.hip, lab_hooks.hip: measurement kernels of rounds 1-3 and the
                                                                 # test hooks -- out of the product's csrc/ since round 6; they include csrc's headers (-I)
-HEADERS = ["ts2d_common.h", "ts2d_lab.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_support.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", "ts2d_imgops.h", os.path.join("..", "..", "include", "ts2d.h"),
+HEADERS = ["ts2d_common.h", "ts2d_lab.h", "ts2d_math.h", "ts2d_wave.h", "ts2d_group.h", "ts2d_support.h", "ts2d_sh.h", "ts2d_stage.h", "ts2d_preprocess_launch.h", "ts2d_imgops.h", "ts2d_select.h", os.path.join("..", "..", "include", "ts2d.h"),
            os.path.join("..", "..", "include", "ts_loss.h"),
            os.path.join("..", "..", "include", "ts_knn.h"),
            os.path.join("..", "..", "include", "ts_model.h"),

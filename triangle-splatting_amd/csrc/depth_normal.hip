@@ -16,14 +16,16 @@
 #include "../../include/ts_loss.h"
 #include "ts2d_common.h"
 #include "ts2d_imgops.h"
+#include "ts2d_select.h"
 
 namespace
 {
 struct Dims { int H, W, h, w; float r_down, r_up_y, r_up_x, A, B; }; // A = w / (2 tan_fovx), B = h / (2 tan_fovy)
 
-__global__ void __launch_bounds__(256) dn_downsample_kernel(Dims m, const float *__restrict__ depth, float *__restrict__ d)
+__global__ void __launch_bounds__(256) dn_downsample_kernel(Dims m, const float *__restrict__ depth, float *__restrict__ d, uint32_t *__restrict__ sel_words, int n_sel_words)
 {
     const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n_sel_words) sel_words[k] = 0u; // the quantile's select state (ts2d_select.h), cleared by the step's first launch instead of one of its own
     if (k >= m.h * m.w) return;
     const int i = k / m.w, j = k - i * m.w;
     if (m.h == m.H && m.w == m.W) { d[k] = depth[k]; return; }
@@ -65,10 +67,13 @@ __device__ __forceinline__ void fullres_normal(const Dims &m, const float *nraw,
 // per full-resolution pixel: G (for the quantile, twice: once to keep, once as sort key) and t = 1 - <n^, Dn>
 __global__ void __launch_bounds__(256) dn_fullres_kernel(Dims m, const float *__restrict__ nraw, const float *__restrict__ gnorm,
                                                           const float *__restrict__ normal, float *__restrict__ G, uint32_t *__restrict__ Gkey,
-                                                          float *__restrict__ t)
+                                                          float *__restrict__ t, SelState *__restrict__ sel)
 {
     const int k = blockIdx.x * 256 + threadIdx.x, HW = m.H * m.W;
-    if (k >= HW) return;
+    uint32_t my_key = 0u;
+    const bool live = k < HW;
+    if (live)
+    {
     const int y = k / m.W, x = k - y * m.W;
     float Nx, Ny, Nz;
     fullres_normal(m, nraw, y, x, Nx, Ny, Nz);
@@ -80,15 +85,22 @@ __global__ void __launch_bounds__(256) dn_fullres_kernel(Dims m, const float *__
     if (m.h == m.H && m.w == m.W) g = gnorm[k];
     else g = bilerp(gnorm, m.w, tap_of(y, m.r_up_y, m.h), tap_of(x, m.r_up_x, m.w));
     G[k] = g;
-    Gkey[k] = __float_as_uint(g); // G >= 0: the bit pattern is monotone
+    my_key = __float_as_uint(g);
+    Gkey[k] = my_key; // G >= 0: the bit pattern is monotone
     t[k] = 1.0f - dot;
+    }
+    // (the select's first histogram pass was fused in here and taken out again: one key per thread means 256 global adds per 256 keys on the same 256
+    //  counters -- sixteen times the standalone kernel's -- and depth_normal_fwd went 0.130 -> 0.150 ms, profiles/r06_loss_bench.jsonl)
+    (void)sel; (void)my_key;
 }
 
-__global__ void __launch_bounds__(256) dn_sum_kernel(int HW, const float *__restrict__ t, const float *__restrict__ G, const float *__restrict__ thr,
-                                                      double *__restrict__ partial)
+__global__ void __launch_bounds__(256) dn_sum_kernel(int HW, const float *__restrict__ t, const float *__restrict__ G, float *__restrict__ thr,
+                                                      double *__restrict__ partial, const SelState *__restrict__ sel, float q)
 {
     __shared__ double red[4];
-    const float th = *thr;
+    // torch.quantile from the finished select state: every block works it out for itself (four 256-thread scans), block 0 leaves it for the backward
+    const float th = sel_threshold_value(sel, (size_t)HW, q);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *thr = th;
     double s = 0.0;
     for (int k = blockIdx.x * 256 + threadIdx.x; k < HW; k += gridDim.x * 256)
         if (G[k] < th) s += (double)t[k];
@@ -297,12 +309,18 @@ hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int 
     const Carve c = carve(workspace, m);
     const int hw = m.h * m.w, HW = H * W;
     const dim3 lo((unsigned)((hw + 255) / 256)), hi((unsigned)((HW + 255) / 256));
-    hipLaunchKernelGGL(dn_downsample_kernel, lo, dim3(256), 0, s, m, depth, c.d);
+    // torch.quantile by radix select (select.hip; the norms are >= 0, their bit patterns order like the values), woven into this sequence: the state is
+    // cleared by the first kernel and the kernel that needs the threshold forms it (13 -> 11 dependent launches; at 800 x 800 every launch is ~8 us of
+    // latency, not work)
+    SelState *sel = (SelState *)ts_align_up((size_t)c.scratch);
+    const int nsel = (int)ts_quantile_state_words();
+    const dim3 lo0((unsigned)((max(hw, nsel) + 255) / 256));
+    hipLaunchKernelGGL(dn_downsample_kernel, lo0, dim3(256), 0, s, m, depth, c.d, (uint32_t *)sel, nsel);
     hipLaunchKernelGGL(dn_lowres_kernel, lo, dim3(256), 0, s, m, c.d, c.nraw, c.gnorm);
-    hipLaunchKernelGGL(dn_fullres_kernel, hi, dim3(256), 0, s, m, c.nraw, c.gnorm, normal, c.G, c.k[0], c.t);
-    ts_quantile_threshold(c.k[0], (size_t)HW, quantile, c.scratch, c.thr, s); // radix select (select.hip): the norms are >= 0, their bit patterns order like the values
+    hipLaunchKernelGGL(dn_fullres_kernel, hi, dim3(256), 0, s, m, c.nraw, c.gnorm, normal, c.G, c.k[0], c.t, sel);
+    ts_quantile_passes(c.k[0], (size_t)HW, quantile, c.scratch, 0, s);
     const int nb = min(SUM_BLOCKS, (HW + 255) / 256);
-    hipLaunchKernelGGL(dn_sum_kernel, dim3((unsigned)nb), dim3(256), 0, s, HW, c.t, c.G, c.thr, c.partial);
+    hipLaunchKernelGGL(dn_sum_kernel, dim3((unsigned)nb), dim3(256), 0, s, HW, c.t, c.G, c.thr, c.partial, sel, quantile);
     hipLaunchKernelGGL(dn_finish_kernel, dim3(1), dim3(64), 0, s, nb, HW, c.partial, out);
     return hipGetLastError();
 }

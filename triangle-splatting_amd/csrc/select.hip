@@ -10,77 +10,21 @@
 // Exact by construction (integers only until the final lerp, which is at::lerp's expression as before).  Five streaming launches over 4 n bytes.
 #include "ts2d_common.h"
 
+#include "ts2d_select.h"
+
 namespace
 {
-constexpr int SEL_BLOCK = 256, SEL_ITEMS = 16; // keys per thread and launch
-struct SelState
-{
-    uint32_t hist[4][256]; // digit totals of pass p (most significant first), among the keys that match passes 0 .. p - 1
-    unsigned long long count_le; // keys <= the selected value
-    uint32_t max_not_gt;         // ~(smallest key > the selected value), kept complemented so that the all-zero state means "none"
-    uint32_t pad;
-};
-
-// (prefix, remaining rank) after `passes` passes, recomputed from the histograms by whoever needs it (256 threads, one block-wide scan per pass)
-__device__ __forceinline__ void sel_resolve(const SelState *st, int passes, unsigned long long rank, uint32_t &prefix, unsigned long long &rem)
-{
-    __shared__ uint32_t s_pick;
-    __shared__ unsigned long long s_before;
-    prefix = 0u;
-    rem = rank;
-    __shared__ unsigned long long s_wave[4];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int p = 0; p < passes; p++)
-    {
-        // inclusive scan of the 256 digit totals over the block's 256 threads (wave scan + four wave totals); the bin that holds the remaining
-        // rank is the one thread whose [exclusive, inclusive) interval contains it
-        const unsigned long long cnt = st->hist[p][threadIdx.x];
-        unsigned long long inc = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1)
-        {
-            const unsigned long long up = __shfl_up(inc, o);
-            if (lane >= o) inc += up;
-        }
-        __syncthreads(); // (the previous pass's readers of s_pick / s_before / s_wave are done)
-        if (lane == 63) s_wave[wave] = inc;
-        __syncthreads();
-        unsigned long long off = 0;
-        for (int w = 0; w < wave; w++) off += s_wave[w];
-        inc += off;
-        const unsigned long long exc = inc - cnt;
-        if (cnt > 0 && exc <= rem && rem < inc) { s_pick = threadIdx.x; s_before = exc; }
-        if (threadIdx.x == 255 && rem >= inc) { s_pick = 255u; s_before = exc; } // (a rank beyond the population: cannot happen for rank <= n - 1)
-        __syncthreads();
-        prefix |= s_pick << (24 - 8 * p);
-        rem -= s_before;
-    }
-    __syncthreads();
-}
-
 __global__ void __launch_bounds__(SEL_BLOCK) sel_hist_kernel(const uint32_t *__restrict__ keys, size_t n, int pass, unsigned long long rank, SelState *st)
 {
-    __shared__ uint32_t s_h[256];
     uint32_t prefix;
     unsigned long long rem;
     sel_resolve(st, pass, rank, prefix, rem);
-    s_h[threadIdx.x] = 0u;
-    __syncthreads();
-    const uint32_t mask = pass == 0 ? 0u : (0xffffffffu << (32 - 8 * pass));
-    const int shift = 24 - 8 * pass;
     const size_t base = (size_t)blockIdx.x * (SEL_BLOCK * SEL_ITEMS);
-#pragma unroll
-    for (int i = 0; i < SEL_ITEMS; i++)
-    {
+    sel_block_hist(st, pass, prefix, SEL_ITEMS, [&](int i, bool &valid) {
         const size_t k = base + (size_t)i * SEL_BLOCK + threadIdx.x;
-        if (k < n)
-        {
-            const uint32_t v = keys[k];
-            if ((v & mask) == prefix) atomicAdd(&s_h[(v >> shift) & 255u], 1u);
-        }
-    }
-    __syncthreads();
-    if (s_h[threadIdx.x]) atomicAdd(&st->hist[pass][threadIdx.x], s_h[threadIdx.x]);
+        valid = k < n;
+        return valid ? keys[k] : 0u;
+    });
 }
 
 __global__ void __launch_bounds__(SEL_BLOCK) sel_neighbour_kernel(const uint32_t *__restrict__ keys, size_t n, unsigned long long rank, SelState *st)
@@ -115,22 +59,10 @@ __global__ void __launch_bounds__(SEL_BLOCK) sel_neighbour_kernel(const uint32_t
     }
 }
 
-// torch.quantile(G, q), interpolation = "linear": rank = q (n - 1) in float32 like torch, lerp between the two neighbours (at::lerp)
-__global__ void __launch_bounds__(SEL_BLOCK) sel_threshold_kernel(size_t n, float q, unsigned long long rank_lo, const SelState *st, float *__restrict__ thr)
+__global__ void __launch_bounds__(SEL_BLOCK) sel_threshold_kernel(size_t n, float q, const SelState *st, float *__restrict__ thr)
 {
-    uint32_t value;
-    unsigned long long rem;
-    sel_resolve(st, 4, rank_lo, value, rem);
-    if (threadIdx.x != 0) return;
-    const float rank = q * (float)(n - 1);
-    const unsigned long long lo = (unsigned long long)floorf(rank);
-    unsigned long long hi = (unsigned long long)ceilf(rank);
-    if (hi > n - 1) hi = n - 1;
-    const float a = __uint_as_float(value);
-    // rank lo + 1: the same value while it has duplicates beyond rank lo, else the next larger key
-    const float b = (hi == lo || st->count_le >= lo + 2) ? a : __uint_as_float(~st->max_not_gt);
-    const float wgt = rank - (float)lo;
-    *thr = (wgt < 0.5f) ? a + wgt * (b - a) : b - (b - a) * (1.0f - wgt);
+    const float v = sel_threshold_value(st, n, q);
+    if (threadIdx.x == 0) *thr = v;
 }
 } // namespace
 
@@ -140,12 +72,19 @@ size_t ts_quantile_scratch_bytes() { return sizeof(SelState) + TS_ALIGN; }
 void ts_quantile_threshold(const uint32_t *keys, size_t n, float q, void *scratch, float *thr, hipStream_t s)
 {
     SelState *st = (SelState *)ts_align_up((size_t)scratch);
-    const float rank = q * (float)(n - 1); // float32, like torch.quantile's rank
-    unsigned long long lo = (unsigned long long)floorf(rank);
-    if (lo > n - 1) lo = n - 1;
     ts_launch_zero_words((uint32_t *)st, sizeof(SelState) / 4, s);
-    const unsigned blocks = (unsigned)((n + SEL_BLOCK * SEL_ITEMS - 1) / (SEL_BLOCK * SEL_ITEMS));
-    for (int pass = 0; pass < 4; pass++) hipLaunchKernelGGL(sel_hist_kernel, dim3(blocks), dim3(SEL_BLOCK), 0, s, keys, n, pass, lo, st);
-    hipLaunchKernelGGL(sel_neighbour_kernel, dim3(blocks), dim3(SEL_BLOCK), 0, s, keys, n, lo, st);
-    hipLaunchKernelGGL(sel_threshold_kernel, dim3(1), dim3(SEL_BLOCK), 0, s, n, q, lo, st, thr);
+    ts_quantile_passes(keys, n, q, scratch, 0, s);
+    hipLaunchKernelGGL(sel_threshold_kernel, dim3(1), dim3(SEL_BLOCK), 0, s, n, q, st, thr);
 }
+
+// Passes first_pass .. 3 and the neighbour pass on a state whose earlier passes were filled by the caller's own kernels (ts2d_select.h: sel_block_hist);
+// the caller's consumer kernel then takes the threshold with sel_threshold_value.  The state must have been zeroed before pass 0.
+void ts_quantile_passes(const uint32_t *keys, size_t n, float q, void *scratch, int first_pass, hipStream_t s)
+{
+    SelState *st = (SelState *)ts_align_up((size_t)scratch);
+    const unsigned long long lo = sel_rank_lo(n, q);
+    const unsigned blocks = (unsigned)((n + SEL_BLOCK * SEL_ITEMS - 1) / (SEL_BLOCK * SEL_ITEMS));
+    for (int pass = first_pass; pass < 4; pass++) hipLaunchKernelGGL(sel_hist_kernel, dim3(blocks), dim3(SEL_BLOCK), 0, s, keys, n, pass, lo, st);
+    hipLaunchKernelGGL(sel_neighbour_kernel, dim3(blocks), dim3(SEL_BLOCK), 0, s, keys, n, lo, st);
+}
+size_t ts_quantile_state_words() { return sizeof(SelState) / 4; }

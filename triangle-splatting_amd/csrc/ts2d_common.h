@@ -264,6 +264,8 @@ void ts_sort_pairs(const BinningStateView &b, int64_t N, const unsigned long lon
 void ts_launch_tile_ranges(int64_t N, const unsigned long long *n_dev, const BinningStateView &b, const ImageStateView &im, hipStream_t s);
 size_t ts_quantile_scratch_bytes();                                                               // select.hip: torch.quantile of non-negative floats by radix select
 void ts_quantile_threshold(const uint32_t *keys, size_t n, float q, void *scratch, float *thr, hipStream_t s);
+void ts_quantile_passes(const uint32_t *keys, size_t n, float q, void *scratch, int first_pass, hipStream_t s); // for callers that weave the select into their own kernels (ts2d_select.h)
+size_t ts_quantile_state_words();
 size_t ts_radix_scratch_bytes(size_t n);                                                          // the same sort for other callers (knn.hip)
 int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s, bool force_tickets = false);
 void ts_force_ticket_passes(bool on); // lab library only (csrc/ts2d_lab.h): no exported entry point of the product library reaches it
