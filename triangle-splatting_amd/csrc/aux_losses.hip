@@ -133,14 +133,12 @@ __global__ void __launch_bounds__(256) aux_upsample_kernel(ADims m, const float 
         }
     }
 }
-__global__ void aux_minmax_finish_kernel(int nblocks, const float *__restrict__ pmin, const float *__restrict__ pmax, float *__restrict__ mm)
+__global__ void __launch_bounds__(64) aux_minmax_finish_kernel(int nblocks, const float *__restrict__ pmin, const float *__restrict__ pmax, float *__restrict__ mm)
 {
-    if (threadIdx.x == 0)
-    {
-        float mn = 3.4e38f, mx = -3.4e38f;
-        for (int b = 0; b < nblocks; b++) { mn = fminf(mn, pmin[b]); mx = fmaxf(mx, pmax[b]); }
-        mm[0] = mn; mm[1] = mx;
-    }
+    float mn = 3.4e38f, mx = -3.4e38f; // one wave instead of one thread walking the partials (round 6, see depth_normal.hip: dn_finish_kernel)
+    for (int b = threadIdx.x; b < nblocks; b += 64) { mn = fminf(mn, pmin[b]); mx = fmaxf(mx, pmax[b]); }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if (threadIdx.x == 0) { mm[0] = mn; mm[1] = mx; }
 }
 // DoG: normalised = (U - min) / (max - min), inverted for freq >= 50, mask = normalised >= 0.5 (trainer_utils.py:138-143)
 __global__ void __launch_bounds__(256) aux_dog_mask_kernel(int HW, const float *__restrict__ U, const float *__restrict__ mm, int invert, float *__restrict__ mask)
@@ -181,14 +179,12 @@ __device__ __forceinline__ void block_sum_to(double s, double *partial)
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void aux_finish_kernel(int nblocks, double count, const double *__restrict__ partial, float *__restrict__ out)
+__global__ void __launch_bounds__(64) aux_finish_kernel(int nblocks, double count, const double *__restrict__ partial, float *__restrict__ out)
 {
-    if (threadIdx.x == 0)
-    {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; b++) s += partial[b];
-        out[0] = (float)(s / count);
-    }
+    double s = 0.0; // fixed order per lane, then a butterfly: deterministic
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[b];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[0] = (float)(s / count);
 }
 // L1(img * mask, gt * mask) = mean over C H W of |img m - gt m| (trainer_utils.py:147-148, 323-324); the mask is one plane
 __global__ void __launch_bounds__(256) aux_masked_l1_sum_kernel(int C, int HW, const float *__restrict__ img, const float *__restrict__ gt,

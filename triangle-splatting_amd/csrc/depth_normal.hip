@@ -109,14 +109,14 @@ __global__ void __launch_bounds__(256) dn_sum_kernel(int HW, const float *__rest
     __syncthreads();
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
-__global__ void dn_finish_kernel(int nblocks, int HW, const double *__restrict__ partial, float *__restrict__ out)
+// One wave, fixed order (lane l adds partials l, l + 64, ...; then a butterfly): deterministic from run to run.  Until round 6 ONE thread walked the up
+// to 1024 partials -- a chain of dependent global loads that took 51 us, the longest kernel of the whole loss (profiles/r06_depth_normal_kernels.txt).
+__global__ void __launch_bounds__(64) dn_finish_kernel(int nblocks, int HW, const double *__restrict__ partial, float *__restrict__ out)
 {
-    if (threadIdx.x == 0)
-    {
-        double s = 0.0;
-        for (int b = 0; b < nblocks; b++) s += partial[b];
-        out[0] = (float)(s / (double)HW);
-    }
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 64) s += partial[b];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) out[0] = (float)(s / (double)HW);
 }
 
 // ---- backward ----------------------------------------------------------------------------------------------------------------------

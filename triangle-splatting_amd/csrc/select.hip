@@ -52,8 +52,15 @@ __global__ void __launch_bounds__(SEL_BLOCK) sel_neighbour_kernel(const uint32_t
         le += __shfl_xor(le, o);
         mn = min(mn, (uint32_t)__shfl_xor((int)mn, o));
     }
-    if ((threadIdx.x & 63) == 0)
+    // one pair of atomics per BLOCK: per wave, 4 x 157 blocks queued on two addresses took 21 us at 640 k keys
+    __shared__ unsigned long long s_le[4];
+    __shared__ uint32_t s_mn[4];
+    if ((threadIdx.x & 63) == 0) { s_le[threadIdx.x >> 6] = le; s_mn[threadIdx.x >> 6] = mn; }
+    __syncthreads();
+    if (threadIdx.x == 0)
     {
+        le = s_le[0] + s_le[1] + s_le[2] + s_le[3];
+        mn = min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3]));
         if (le) atomicAdd(&st->count_le, le);
         if (mn != 0xffffffffu) atomicMax(&st->max_not_gt, ~mn);
     }
