@@ -113,7 +113,9 @@ typedef struct ts2d_loss_grads
 {
     const float *dL_dout_feature; /* C*H*W */
     const float *dL_dout_depth;   /* H*W   (RICH_INFO only) */
-    const float *dL_dout_normal;  /* 3*H*W (RICH_INFO only) */
+    const float *dL_dout_normal;  /* 3*H*W (RICH_INFO only).  With RICH_INFO, depth and normal may BOTH be NULL: "no gradient arrives on
+                                   * them" = what two images of zeros give (the reference's autograd materialises those), by the colour-only
+                                   * pixel kernel and without the two fills */
 } ts2d_loss_grads;
 
 /* BackwardOutput, R2D/src/param_struct.h:183-190.  Every element is written by the library. */

@@ -60,6 +60,10 @@ int tsm_update_mask(int32_t P, int32_t mode, const float *opacity, const float *
 int tsm_clip(int32_t P, int32_t mode, const uint8_t *mask, float value, float *param, float *exp_avg, float *exp_avg_sq, void *stream);
 /* _opacity_reset (:524-537): opacity <- inverse_sigmoid(min(sigmoid(opacity), reset_value)); every row's Adam moments <- 0 */
 int tsm_opacity_reset(int32_t P, float reset_value, float *opacity, float *exp_avg, float *exp_avg_sq, void *stream);
+/* bg_depth of VanillaTSModel.forward (:623): out[0] <- max over the n_vertices rows of `vertex` (n_vertices, 3) of |camera_center - vertex|
+ * (camera_center: 3 floats in DEVICE memory; out: 1 float in device memory; 0 for n_vertices == 0).  One read of the vertices instead of
+ * torch's subtract / norm / max. */
+int tsm_max_vertex_distance(int32_t n_vertices, const float *vertex, const float *camera_center, float *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -53,6 +53,30 @@ typedef struct tso_adam_slice
  * 1.3e-5 off 0.001). */
 int tso_adam_step(const tso_adam_slice *slices, int32_t num_slices, double beta1, double beta2, double eps, void *stream);
 
+/* The Adam step of the SH coefficients from their FACTORED gradient.  In SH mode every view's dL/dshs is a rank-1 product per triangle,
+ *     dL_dshs[i, k, :] = sum_v basis_k(normalize(centre_i - campos_v)) * dL_dRGB_v[i, :]          (R2D/src/backward.cu:9-119),
+ * and ts2d_backward under TS2D_FLAG_SH_FACTORED leaves the (P, M, 3) array unwritten and returns dL_dRGB (P, 3) in its dL_dfeature slot.  This
+ * call forms the product in registers and applies the arithmetic above to it: bit-identical parameters and moments to tso_adam_step on the dense
+ * gradient, with 12 M bytes per triangle less written by the backward and 12 M - 12 V less read here.
+ * `vertex` must hold the values the backward passes ran on: call this BEFORE the step that updates the vertices.
+ * Coefficient 0 of triangle i lives at {param,exp_avg,exp_avg_sq}_dc + i * dc_stride, coefficient k >= 1 at ..._rest + i * rest_stride + 3 (k - 1)
+ * (strides in floats): the reference's two tensors f_dc (P, 1, 3) / f_rest (P, M - 1, 3) are strides 3 / 3 (M - 1); ONE (P, M, 3) tensor is
+ * dc = base, rest = base + 3, both strides 3 M.  Coefficients above sh_degree take a zero gradient (the reference's dense array holds zeros there). */
+typedef struct tso_sh_factored_step
+{
+    int32_t P, M, sh_degree, V;   /* M = (max degree + 1)^2 in {1, 4, 9, 16}; V views >= 1 */
+    const float *vertex;          /* P*9 */
+    const float *campos;          /* V*3, device memory */
+    const float *dL_dcolor;       /* V*P*3 */
+    float *param_dc, *exp_avg_dc, *exp_avg_sq_dc;
+    float *param_rest, *exp_avg_rest, *exp_avg_sq_rest; /* may be NULL for M == 1 */
+    int64_t dc_stride, rest_stride;
+    float step_size_dc, bias2_sqrt_dc, step_size_rest, bias2_sqrt_rest;
+    float grad_scale;
+} tso_sh_factored_step;
+
+int tso_adam_step_sh_factored(const tso_sh_factored_step *step, double beta1, double beta2, double eps, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

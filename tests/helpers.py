@@ -52,8 +52,10 @@ def hip_settings(s, rich_info=True, back_culling=False, debug=False, device="cud
 
 
 def hip_forward_backward(s, rich_info=True, back_culling=False, use_feature=False, backward=True, device="cuda", debug=False,
-                         variant=2):
-    """Runs the HIP path through the drop-in autograd module.  Returns numpy outputs + grads + raw state."""
+                         variant=2, depth_normal_grads="given"):
+    """Runs the HIP path through the drop-in autograd module.  Returns numpy outputs + grads + raw state.
+    depth_normal_grads: "given" = the scene's dL_dout_depth / dL_dout_normal; "zeros" = two images of zeros handed in; "none" = the loss reads
+    the colours only (autograd hands the module None for depth and normal)."""
     import torch
     if variant == 3:
         from diff_triangle_rasterization_3D import TriangleRasterizer
@@ -81,8 +83,9 @@ def hip_forward_backward(s, rich_info=True, back_culling=False, use_feature=Fals
     res["buffers"] = saved[5:8]
     if backward:
         loss = (out[0] * t(s["dL_dout_feature"])).sum()
-        if rich_info:
-            loss = loss + (out[2] * t(s["dL_dout_depth"])).sum() + (out[3] * t(s["dL_dout_normal"])).sum()
+        if rich_info and depth_normal_grads != "none":
+            k = 0.0 if depth_normal_grads == "zeros" else 1.0
+            loss = loss + (out[2] * (k * t(s["dL_dout_depth"]))).sum() + (out[3] * (k * t(s["dL_dout_normal"]))).sum()
         loss.backward()
         res.update(dL_dvertex=vertex.grad.cpu().numpy(), dL_dcenter2D=center2D.grad.cpu().numpy(),
                    dL_dopacity=opacity.grad.cpu().numpy())

@@ -176,6 +176,26 @@ def test_render_view_shim_matches_manual_pipeline():
     assert set(ev) == {"render"}
 
 
+@pytest.mark.parametrize("P", [0, 1, 85, 4099, 700001])
+def test_background_depth_equals_the_torch_expression(P):
+    """VanillaTS_model.py:623.  One kernel in place of subtract / norm / max; the sum of squares is formed in the order x, y, z without contraction, so
+    the difference to torch's vector norm is at most the last bit of the square root."""
+    import torch
+    from diff_recon_hip import background_depth
+    g = torch.Generator().manual_seed(P)
+    vertex = (torch.randn(P, 3, 3, generator=g) * 7.0).cuda()
+    campos = torch.tensor([0.3, -2.0, 11.0], device="cuda")
+    got = background_depth(vertex, campos)
+    assert got.shape == () and got.is_cuda and not got.requires_grad
+    if P == 0:
+        assert float(got) == 0.0
+        return
+    want = (campos.view(1, 1, 3) - vertex).norm(dim=-1).max()
+    assert abs(float(got) - float(want)) <= 2.0 * np.spacing(np.float32(float(want)))
+    # a vertex tensor that requires grad (the model's parameter) gives the same number and no graph
+    assert float(background_depth(vertex.requires_grad_(True), campos)) == float(got)
+
+
 def _dn_golden():
     import os
     return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "depth_normal.npz"))

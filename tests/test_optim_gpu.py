@@ -244,3 +244,88 @@ def test_sharded_adam_refuses_what_a_capture_cannot_fill():
     with opt.bucket.capture():
         with pytest.raises(RuntimeError, match="is not the parameter the bucket's optimizer owns"):
             out[0].sum().backward()
+
+
+@pytest.mark.parametrize("layout,max_deg,deg,views", [("one", 3, 3, 1), ("one", 3, 1, 2), ("one", 3, 2, 1), ("one", 1, 0, 2), ("one", 1, 1, 1), ("one", 2, 1, 2),
+                                                       ("split", 3, 2, 1), ("split", 1, 1, 3), ("one", 0, 0, 1), ("split", 0, 0, 2)])
+def test_adam_from_factored_sh_gradients_equals_adam_on_the_dense_gradient(layout, max_deg, deg, views):
+    """include/ts_optim.h, tso_adam_step_sh_factored: the colour parameters stepped from (dL_dRGB, camera centre) per view.  A real backward under
+    factored_sh_grads() provides the factors (and leaves the colour tensors without a .grad); the dense dL_dshs of the SAME factors comes from the
+    expansion kernel (bit-identical to what the backward writes, tests/test_factored_gpu.py).  Two optimizers, two steps each (the second on
+    non-zero moments): parameters and both moments must be EQUAL -- the same expressions in the same order -- for the one-tensor layout with its
+    two learning rates and for the reference's f_dc / f_rest pair, with coefficients above the active degree and with several views."""
+    import torch
+    import helpers
+    import synthetic
+    from diff_recon_hip import FusedAdam, ShFactors
+    from diff_triangle_rasterization_2D import TriangleRasterizer, _C
+    from diff_triangle_rasterization_2D.parallel import ShGradSink, factored_sh_grads
+    dev = "cuda"
+    P, M = 5003, (max_deg + 1) ** 2
+    s = synthetic.scene(P, 128, 96, max_deg, seed=31 + max_deg)
+    s["sh_degree"] = deg
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def make():
+        p = {"vertex": t(s["vertex"]).requires_grad_(), "opacity": t(s["opacity"]).requires_grad_()}
+        if layout == "one":
+            p["shs"] = t(s["shs"]).requires_grad_()
+            groups = [{"params": [p["shs"]], "lr": 1e-2, "lr_tail": 5e-4, "tail_period": 3 * M, "tail_split": 3}]
+        else:
+            p["f_dc"] = t(s["shs"][:, :1]).requires_grad_()
+            p["f_rest"] = t(s["shs"][:, 1:]).requires_grad_()
+            groups = [{"params": [p["f_dc"]], "lr": 1e-2}, {"params": [p["f_rest"]], "lr": 5e-4}]
+        groups += [{"params": [p["vertex"]], "lr": 3e-2}, {"params": [p["opacity"]], "lr": 5e-2}]
+        return p, FusedAdam(groups, lr=0.0, eps=1e-15)
+
+    (a, opt_a), (b, opt_b) = make(), make()
+    g = torch.Generator(device=dev).manual_seed(7)
+    cams = [s["campos"] + np.float32(0.37 * v) * np.array([1.0, -0.5, 0.25], np.float32) for v in range(views)]
+    with factored_sh_grads() as sink:
+        for v in range(views):
+            sv = dict(s, campos=cams[v])
+            c2d = torch.zeros((P, 2), device=dev, requires_grad=True)
+            shs = b["shs"] if layout == "one" else torch.cat((b["f_dc"], b["f_rest"]), dim=1)
+            out = TriangleRasterizer(helpers.hip_settings(sv, True))(b["vertex"], c2d, b["opacity"], shs=shs)
+            (out[0] * torch.rand(out[0].shape, device=dev, generator=g)).sum().backward()
+    assert len(sink.colors) == views
+    assert all(b[k].grad is None for k in b if k in ("shs", "f_dc", "f_rest"))  # the dense gradient was never formed
+    assert b["vertex"].grad is not None
+    colors = [c.clone() for c in sink.colors]
+    campos = torch.stack([c.clone() for c in sink.campos])
+    dense = _C.sh_grad_expand(b["vertex"].detach(), campos, torch.stack([c.reshape(P, 3) for c in colors]), deg, M)
+    assert float(dense.abs().max()) > 0 and (deg == max_deg or float(dense[:, (deg + 1) ** 2:].abs().max()) == 0.0)
+    gv, go = b["vertex"].grad.clone(), b["opacity"].grad.clone()
+    for step in range(2):
+        # dense side
+        a["vertex"].grad, a["opacity"].grad = gv.clone(), go.clone()
+        if layout == "one":
+            a["shs"].grad = dense.clone()
+        else:
+            a["f_dc"].grad, a["f_rest"].grad = dense[:, :1].contiguous(), dense[:, 1:].contiguous()
+        opt_a.step()
+        # factored side: the same factors, the same vertex / opacity gradients
+        b["vertex"].grad, b["opacity"].grad = gv.clone(), go.clone()
+        sk = ShGradSink()
+        for c, cp in zip(colors, campos):
+            sk.append(c.clone(), cp)
+        # NOTE the direction comes from the vertices of the backward: the dense array was formed from b's vertices BEFORE step 0, so step 1 reads
+        # those too (`vertex=` takes any tensor with the backward's values)
+        vert0 = t(s["vertex"])
+        f = ShFactors(sk, vert0, deg, shs=b["shs"]) if layout == "one" else ShFactors(sk, vert0, deg, f_dc=b["f_dc"], f_rest=b["f_rest"])
+        opt_b.step(sh_factors=f)
+        assert not sk.colors  # consumed
+    torch.cuda.synchronize()
+    for k in a:
+        assert torch.equal(a[k].detach(), b[k].detach()), k
+        assert not torch.equal(a[k].detach(), t(s["shs"] if k == "shs" else s["shs"][:, :1] if k == "f_dc" else s["shs"][:, 1:] if k == "f_rest" else s[k])) or a[k].numel() == 0, k
+        sa, sb = opt_a.state[a[k]], opt_b.state[b[k]]
+        assert sa["step"] == sb["step"] == 2
+        assert torch.equal(sa["exp_avg"], sb["exp_avg"]) and torch.equal(sa["exp_avg_sq"], sb["exp_avg_sq"]), k
+    # a dense .grad beside the factors is refused instead of dropped
+    if layout == "one":
+        b["shs"].grad = dense.clone()
+        sk = ShGradSink()
+        sk.append(colors[0].clone(), campos[0])
+        with pytest.raises(RuntimeError, match="also holds a dense .grad"):
+            opt_b.step(sh_factors=ShFactors(sk, t(s["vertex"]), deg, shs=b["shs"]))

@@ -391,3 +391,22 @@ def test_ranged_backward_equals_the_single_launch(variant, P, K):
     for name, x in zip(("dL_dvertex", "dL_dcenter2D", "dL_dshs", None, "dL_dopacity"), got):
         if name:
             assert helpers.rel_l2(x.cpu().numpy().reshape(hf[name].shape), hf[name]) < 1e-6, name
+
+
+@pytest.mark.parametrize("variant,gamma,use_feature", [(2, 1.0, False), (2, 2.5, False), (2, 1.0, True), (3, 1.0, False), (3, 2.5, False), (3, 1.0, True)])
+def test_colour_only_loss_on_a_rich_forward_equals_zero_depth_and_normal_gradients(variant, gamma, use_feature):
+    """rich_info forward, loss on the colours only.  The reference's autograd hands its kernel two images of zeros for depth and normal
+    (rasterizer.cu:290-300 runs the RICH_INFO kernels on them); here the module passes "no gradient" (include/ts2d.h: ts2d_loss_grads with both
+    NULL) and the colour-only pixel kernel runs over the rich records.  Every depth / normal term is an exact zero in the reference's kernel
+    (backward.cu:419-437), so the gradients must agree up to the order of the atomic adds."""
+    s = synthetic.scene(6000, 200, 136, 2, seed=4242 + variant)
+    s["gamma"] = gamma
+    if use_feature:
+        rng = np.random.default_rng(5)
+        s["feature"] = rng.random((s["vertex"].shape[0], 3), dtype=np.float32)
+    a = helpers.hip_forward_backward(s, True, use_feature=use_feature, variant=variant, depth_normal_grads="none")
+    b = helpers.hip_forward_backward(s, True, use_feature=use_feature, variant=variant, depth_normal_grads="zeros")
+    assert np.array_equal(a["out_feature"], b["out_feature"])
+    for k in ("dL_dvertex", "dL_dcenter2D", "dL_dopacity", "dL_dfeature" if use_feature else "dL_dshs"):
+        assert np.abs(b[k]).max() > 0
+        assert helpers.rel_l2(a[k], b[k]) < 2e-6, k

@@ -34,6 +34,7 @@ import synthetic
 import diff_recon_hip as D
 from diff_triangle_rasterization_2D import _C
 import diff_triangle_rasterization_2D as pkg2d
+from diff_triangle_rasterization_2D.parallel import ShGradSink, factored_sh_grads
 
 CONFIGS = {
     # name: triangles, camera width, height, render_up_scale, SH degree stored / active, rasterizer, gamma, w_geometry
@@ -59,6 +60,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS))
     ap.add_argument("--iters", type=int, default=40)
+    ap.add_argument("--dense-adam", action="store_true", help="the colour parameters stepped from the dense dL_dshs (the form of rounds 4-5) instead of "
+                    "the factored gradient (FusedAdam.step(sh_factors=...), include/ts_optim.h: tso_adam_step_sh_factored)")
     a = ap.parse_args()
     c = NS(**CONFIGS[a.config])
     dev = torch.device("cuda")
@@ -87,13 +90,23 @@ def main():
         loss = D.photometric_loss(pkg["render"], gt, 0.8, 0.2)
         if geo is not None:
             loss = loss + c.w_geo * geo(pkg["depth"], pkg["normal"], cam.tan_fovx, cam.tan_fovy)
-        loss.backward()
+        with factored_sh_grads(enabled=not a.dense_adam) as sink:
+            loss.backward()
+        out["factors"] = (list(sink.colors), list(sink.campos))  # tensors of this iteration (of the capture, under graph replay)
+        sink.clear()
         stats.update(pkg)
         out["loss"], out["pkg"] = loss.detach(), pkg
 
+    def step():
+        if a.dense_adam:
+            return opt.step()
+        sk = ShGradSink()
+        sk.colors, sk.campos = list(out["factors"][0]), list(out["factors"][1])
+        opt.step(sh_factors=D.ShFactors(sk, vertex, c.D, shs=shs))
+
     def iteration():
         fwd_loss_bwd()
-        opt.step()
+        step()
 
     def timed(fn, n):
         torch.cuda.synchronize()
@@ -120,8 +133,11 @@ def main():
     raster_ms = raster_step_ms(s, c, W, H, dev, a.iters)
     n_img = 3 * c.h * c.w
     nparam = c.P * (9 + 1 + 3 * M)
+    V = 1
+    alg_sh = {"adam_step": 28 * c.P * 10, "adam_step_sh_factored": c.P * (36 + 12 * V + 36 * M + 36 * M)} if not a.dense_adam else {}
     alg = {"photometric_fwd": 5 * 4 * n_img, "photometric_bwd": 6 * 4 * n_img, "adam_step": 28 * nparam, "training_statistic": 68 * c.P,
            "depth_normal_fwd": 16 * c.h * c.w, "depth_normal_bwd": 32 * c.h * c.w}
+    alg.update(alg_sh)
     if c.up > 1:
         per = (c.up * c.up + 1) * 4 * c.h * c.w  # per channel plane; render 3 + depth 1 + normal 3 planes in three launches: average per launch
         alg["downsample_fwd"] = per * 7 / 3
@@ -143,7 +159,7 @@ def main():
     def emit(graph_ms, graph_err):
         it = graph_ms if graph_ms else eager_ms
         line = {"config": a.config, "workload": f"P={c.P}, camera {c.w}x{c.h}, render_up_scale {c.up} (raster {W}x{H}), {c.rast}, SH degree {c.D}, gamma {c.gamma:g}, "
-                                                 f"L1 + SSIM{' + %.2f x depth/normal' % c.w_geo if c.w_geo else ''}, FusedAdam, statistics",
+                                                 f"L1 + SSIM{' + %.2f x depth/normal' % c.w_geo if c.w_geo else ''}, FusedAdam{'' if a.dense_adam else ' (colours from the factored gradient)'}, statistics",
                 "iteration_ms_eager": round(eager_ms, 4), "iteration_ms_graph": None if graph_ms is None else round(graph_ms, 4), "graph_note": graph_err,
                 "raster_step_ms": round(raster_ms, 4), "iteration_minus_raster_ms": round(it - raster_ms, 4),
                 "library_kernels_ms_per_iteration": round(lib_ms, 4), "of_which_rasterizer": round(raster_lib_ms, 4),
@@ -159,9 +175,12 @@ def main():
     try:
         gs = D.GraphedStep(fwd_loss_bwd, instance_capacity=int(1.3 * node_n) + 4096)
 
+        factors = out["factors"]  # the capture's tensors: every replay refills them
+
         def graphed():
             gs.replay()
-            opt.step()
+            out["factors"] = factors
+            step()
         timed(graphed, 30)
         graph_ms = timed(graphed, a.iters)
         emit(graph_ms, "overflowed" if gs.overflowed()[0] else None)

@@ -698,8 +698,14 @@ int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint
     hipStream_t s = (hipStream_t)stream;
     const int P = geom->P, W = cam->width, H = cam->height;
     if (P == 0) return TS2D_OK; // extension_interface.cu:242
-    if (!loss->dL_dout_feature || (rich && (!loss->dL_dout_depth || !loss->dL_dout_normal)))
-        return fail(TS2D_ERR_INVALID, "upstream gradients are null");
+    if (!loss->dL_dout_feature) return fail(TS2D_ERR_INVALID, "upstream gradients are null");
+    if (rich && ((loss->dL_dout_depth == nullptr) != (loss->dL_dout_normal == nullptr)))
+        return fail(TS2D_ERR_INVALID, "dL_dout_depth and dL_dout_normal: both or neither");
+    // RICH_INFO state, but no gradient arrives on the depth and normal images (a training iteration whose loss reads the colours only: the reference's
+    // autograd then hands its kernel two images of zeros).  With dd = dn = 0 every depth / normal term of the pixel kernel is an exact zero
+    // (backward.cu:419-437), i.e. it is the colour-only kernel over the same records: that one runs, grad_rec columns 10..15 stay at the zeros they
+    // were cleared to, and the per-triangle kernel below is unchanged.
+    const bool colour_only = rich && !loss->dL_dout_depth;
     const bool factored = use_shs && (flags & TS2D_FLAG_SH_FACTORED);
     if (!out->dL_dvertex || !out->dL_dcenter2D || !out->dL_dfeature || !out->dL_dopacity || (use_shs && !factored && !out->dL_dshs))
         return fail(TS2D_ERR_INVALID, "gradient outputs are null");
@@ -715,7 +721,8 @@ int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint
     ts_carve_geometry((char *)state->geometry, P, g);
     if (N > 0) ts_carve_binning((char *)state->binning, ts_binning_capacity(state->binning_bytes, W, H), W, H, b); // as the forward carved it
     ts_carve_image((char *)state->image, W, H, im);
-    const RenderArgs r = make_render(cam, geom, flags);
+    RenderArgs r = make_render(cam, geom, flags);
+    if (colour_only) r.rich_info = false; // selects the pixel kernel's template only (the launchers dispatch on it)
     float *grad_rec = (float *)ts_align_up((size_t)scratch);
 
     {
@@ -1033,6 +1040,25 @@ int tso_adam_step(const tso_adam_slice *slices, int32_t num_slices, double beta1
     return TS2D_OK;
 }
 
+int tso_adam_step_sh_factored(const tso_sh_factored_step *a, double beta1, double beta2, double eps, void *stream)
+{
+    if (!a) return fail(TS2D_ERR_INVALID, "null step");
+    if (!(beta1 >= 0.0 && beta1 < 1.0) || !(beta2 >= 0.0 && beta2 < 1.0)) return fail(TS2D_ERR_INVALID, "betas must be in [0, 1)");
+    if (!(eps >= 0.0)) return fail(TS2D_ERR_INVALID, "Invalid epsilon value");
+    if (a->P < 0 || a->V < 1) return fail(TS2D_ERR_INVALID, "P must be >= 0 and V >= 1");
+    if (a->M != 1 && a->M != 4 && a->M != 9 && a->M != 16) return fail(TS2D_ERR_INVALID, "M must be 1, 4, 9 or 16");
+    if (a->sh_degree < 0 || (a->sh_degree + 1) * (a->sh_degree + 1) > a->M) return fail(TS2D_ERR_INVALID, "sh_degree does not fit M");
+    if (a->P == 0) return TS2D_OK;
+    if (!a->vertex || !a->campos || !a->dL_dcolor || !a->param_dc || !a->exp_avg_dc || !a->exp_avg_sq_dc) return fail(TS2D_ERR_INVALID, "null pointer");
+    if (a->M > 1 && (!a->param_rest || !a->exp_avg_rest || !a->exp_avg_sq_rest)) return fail(TS2D_ERR_INVALID, "null f_rest pointer");
+    if (a->dc_stride < 3 || (a->M > 1 && a->rest_stride < 3 * (a->M - 1))) return fail(TS2D_ERR_INVALID, "row strides too small");
+    if (!(a->bias2_sqrt_dc > 0.0f) || (a->M > 1 && !(a->bias2_sqrt_rest > 0.0f))) return fail(TS2D_ERR_INVALID, "bias2_sqrt must be positive (step >= 1)");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope ps("adam_step_sh_factored", st);
+    TS_HIP(ts_optim_adam_step_sh_factored(*a, beta1, beta2, eps, st));
+    return TS2D_OK;
+}
+
 // ---- include/ts_model.h -----------------------------------------------------------------------------------------------
 int tsm_training_statistic(int32_t P, int32_t num_views, const int32_t *radii, const float *center2D_grad, const float *contrib_sum,
                            const float *contrib_max, float *gradient_accum, float *gradient_denom, float *max_radii2D,
@@ -1120,6 +1146,14 @@ int tsm_opacity_reset(int32_t P, float reset_value, float *opacity, float *exp_a
     if (P < 0) return fail(TS2D_ERR_INVALID, "P must be >= 0");
     if (P > 0 && (!opacity || ((exp_avg == nullptr) != (exp_avg_sq == nullptr)))) return fail(TS2D_ERR_INVALID, "null pointer");
     TS_HIP(ts_model_opacity_reset(P, reset_value, opacity, exp_avg, exp_avg_sq, (hipStream_t)stream));
+    return TS2D_OK;
+}
+
+int tsm_max_vertex_distance(int32_t n_vertices, const float *vertex, const float *camera_center, float *out, void *stream)
+{
+    if (n_vertices < 0) return fail(TS2D_ERR_INVALID, "n_vertices must be >= 0");
+    if (!out || (n_vertices > 0 && (!vertex || !camera_center))) return fail(TS2D_ERR_INVALID, "null pointer");
+    TS_HIP(ts_model_max_distance(n_vertices, vertex, camera_center, out, (hipStream_t)stream));
     return TS2D_OK;
 }
 

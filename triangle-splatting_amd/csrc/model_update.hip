@@ -261,6 +261,28 @@ __global__ void __launch_bounds__(256) opacity_reset_kernel(int P, float reset_v
     opacity[i] = logf(x / (1.0f - x)); // inverse_sigmoid, model_utils.py
     if (exp_avg) { exp_avg[i] = 0.0f; exp_avg_sq[i] = 0.0f; }
 }
+// bg_depth of VanillaTSModel.forward (:623): max over all vertices of |camera_center - vertex|.  torch spends three kernels on it (subtract, norm, max:
+// 61 us per view at 1 M triangles, profiles/r06_train_step_kernels.txt); this is one read of the vertices.  Distances are >= 0, so the unsigned bit
+// pattern orders like the value and one atomicMax per block lands the result (`out` zeroed by max_distance_zero_kernel in front).
+__global__ void max_distance_zero_kernel(uint32_t *__restrict__ out) { out[0] = 0u; }
+
+__global__ void __launch_bounds__(256) max_distance_kernel(int n, const float *__restrict__ vertex, const float *__restrict__ campos,
+                                                           uint32_t *__restrict__ out)
+{
+    __shared__ float wmax[4];
+    const float cx = campos[0], cy = campos[1], cz = campos[2];
+    float m = 0.0f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+    {
+        const float dx = cx - vertex[3 * (size_t)i], dy = cy - vertex[3 * (size_t)i + 1], dz = cz - vertex[3 * (size_t)i + 2];
+        m = fmaxf(m, __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz)));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(out, __float_as_uint(sqrtf(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3])))));
+}
 } // namespace
 
 hipError_t ts_model_training_statistic(int P, int V, const int32_t *radii, const float *c2d_grad, const float *csum, const float *cmax,
@@ -343,5 +365,16 @@ hipError_t ts_model_opacity_reset(int P, float reset_value, float *opacity, floa
 {
     if (P <= 0) return hipSuccess;
     hipLaunchKernelGGL(opacity_reset_kernel, dim3((P + 255) / 256), dim3(256), 0, s, P, reset_value, opacity, exp_avg, exp_avg_sq);
+    return hipGetLastError();
+}
+
+hipError_t ts_model_max_distance(int n_vertices, const float *vertex, const float *campos, float *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(max_distance_zero_kernel, dim3(1), dim3(1), 0, s, (uint32_t *)out);
+    if (n_vertices > 0)
+    {
+        const int blocks = (n_vertices + 255) / 256;
+        hipLaunchKernelGGL(max_distance_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, n_vertices, vertex, campos, (uint32_t *)out);
+    }
     return hipGetLastError();
 }

@@ -6,7 +6,10 @@
 // dwords (a slice of a flat buffer may start at any multiple of 4 bytes).  Built with -ffp-contract=off: torch's operation order, every
 // operation rounded on its own.
 #include "ts2d_common.h"
+#include "ts2d_sh.h"
 #include "../../include/ts_optim.h"
+
+using namespace ts;
 
 namespace
 {
@@ -19,7 +22,12 @@ struct AdamTable
     float beta1, beta2, w1, w2, eps;
 };
 
-__device__ __forceinline__ void adam_element(float &p, float g, float &m, float &v, const AdamTable &t, float step_size, float bias2_sqrt, float grad_scale)
+struct AdamCoeffs
+{
+    float beta2, w1, w2, eps;
+};
+
+__device__ __forceinline__ void adam_element(float &p, float g, float &m, float &v, const AdamCoeffs &t, float step_size, float bias2_sqrt, float grad_scale)
 {
     g = g * grad_scale;
     // exp_avg.lerp_(grad, 1 - beta1): ATen's lerp (aten/src/ATen/native/Lerp.h) takes  self + w (end - self)  for |w| < 0.5 and
@@ -63,7 +71,7 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable t)
         {
             float step = s.step_size;
             if (s.period > 0 && (int)((s.index0 + i0 + j) % s.period) >= s.split) step = s.step_size_tail;
-            adam_element(p[j], g[j], m[j], v[j], t, step, s.bias2_sqrt, s.grad_scale);
+            adam_element(p[j], g[j], m[j], v[j], AdamCoeffs{t.beta2, t.w1, t.w2, t.eps}, step, s.bias2_sqrt, s.grad_scale);
         }
     if (t.vec4[k] && n == 4)
     {
@@ -78,7 +86,159 @@ __global__ void __launch_bounds__(256) adam_kernel(const AdamTable t)
             if (j < n) { s.param[i0 + j] = p[j]; s.exp_avg[i0 + j] = m[j]; s.exp_avg_sq[i0 + j] = v[j]; }
     }
 }
+
+// ---- Adam on the SH coefficients from their FACTORED gradient (include/ts_optim.h: tso_adam_step_sh_factored) -------------------------------
+// dL_dshs[i, k, :] = sum_v basis_k(normalize(centre_i - campos_v)) * dL_dRGB_v[i, :] (backward.cu:9-119; shgrad.hip writes exactly this out as a
+// dense (P, M, 3) array).  Here the product is formed in registers by the thread that owns coefficient k of triangle i and fed to adam_element:
+// the 12 M bytes per triangle of the dense gradient are neither written by the backward nor read here (1 M triangles, degree 3: 192 MB less
+// written, 144 MB less read per iteration).  Same expressions in the same order as sh_grad_expand_kernel / sh_grad_store, same -ffp-contract=off:
+// the gradient value is bit-identical to the dense one, hence the updated parameters and moments are too.
+struct ShFactoredArgs
+{
+    tso_sh_factored_step a;
+    float beta2, w1, w2, eps;
+};
+
+template <int MAXDEG>
+__global__ void __launch_bounds__(256) adam_sh_factored_kernel(const ShFactoredArgs t)
+{
+    constexpr int M = (MAXDEG + 1) * (MAXDEG + 1);
+    const tso_sh_factored_step &a = t.a;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = q / M;
+    const int k = (int)(q - i * M);
+    if (i >= a.P) return;
+    f3 g = {0.0f, 0.0f, 0.0f};
+    const int NB = (a.sh_degree + 1) * (a.sh_degree + 1);
+    if (k < NB)
+    {
+        const float *vp = a.vertex + 9 * i;
+        const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
+        const f3 center = divf(add(add(v1, v2), v3), 3.0f); // forward.cu:87
+        for (int v = 0; v < a.V; v++)
+        {
+            const f3 cp = {a.campos[3 * v], a.campos[3 * v + 1], a.campos[3 * v + 2]};
+            const float *gp = a.dL_dcolor + ((size_t)v * a.P + i) * 3;
+            const f3 c = {gp[0], gp[1], gp[2]};
+            const f3 dir_orig = sub(center, cp);
+            const f3 dir = divf(dir_orig, norm(dir_orig));
+            float b[16] = {};
+            sh_basis(MAXDEG < a.sh_degree ? MAXDEG : a.sh_degree, dir, b); // the first bound: lets the compiler drop the degrees this M cannot hold
+            float bk = b[0];
+#pragma unroll
+            for (int j = 1; j < M; j++) bk = (k == j) ? b[j] : bk;
+            g = add(g, scale(bk, c));
+        }
+    }
+    const bool rest = k > 0;
+    const int64_t off = rest ? i * a.rest_stride + 3 * (k - 1) : i * a.dc_stride;
+    float *P_ = (rest ? a.param_rest : a.param_dc) + off, *M_ = (rest ? a.exp_avg_rest : a.exp_avg_dc) + off,
+          *V_ = (rest ? a.exp_avg_sq_rest : a.exp_avg_sq_dc) + off;
+    const float step = rest ? a.step_size_rest : a.step_size_dc, b2 = rest ? a.bias2_sqrt_rest : a.bias2_sqrt_dc;
+    AdamCoeffs co{t.beta2, t.w1, t.w2, t.eps};
+    float p[3] = {P_[0], P_[1], P_[2]}, m[3] = {M_[0], M_[1], M_[2]}, vv[3] = {V_[0], V_[1], V_[2]};
+    const float gg[3] = {g.x, g.y, g.z};
+#pragma unroll
+    for (int c = 0; c < 3; c++) adam_element(p[c], gg[c], m[c], vv[c], co, step, b2, a.grad_scale);
+#pragma unroll
+    for (int c = 0; c < 3; c++) { P_[c] = p[c]; M_[c] = m[c]; V_[c] = vv[c]; }
+}
+
+// The same step for ONE (P, M, 3) tensor with 3 M a multiple of four floats (M = 4, 16) on 16-byte aligned rows: a thread owns four consecutive
+// floats of a triangle's row = dwordx4 loads and stores (the per-coefficient kernel above moves single dwords 12 bytes apart: 5.2 TB/s at 1 M
+// triangles against 6.1 of the dense kernel).  Twelve floats are four coefficients, so the thread's float4 is one of three patterns
+// (k0 k0 k0 k1 | k1 k1 k2 k2 | k2 k3 k3 k3) x (r g b r | g b r g | b r g b) of the coefficient quadruple 4 (j / 3) .. + 3.
+template <int MAXDEG>
+__global__ void __launch_bounds__(256) adam_sh_factored_vec4_kernel(const ShFactoredArgs t)
+{
+    constexpr int M = (MAXDEG + 1) * (MAXDEG + 1), Q = 3 * M / 4; // float4 per triangle
+    static_assert((3 * M) % 4 == 0, "rows of 3 M floats must be whole float4");
+    const tso_sh_factored_step &a = t.a;
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = q / Q;
+    const int j = (int)(q - i * Q);
+    if (i >= a.P) return;
+    const int kbase = 4 * (j / 3), jj = j - 3 * (j / 3);
+    float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int NB = (a.sh_degree + 1) * (a.sh_degree + 1);
+    if (kbase < NB)
+    {
+        const float *vp = a.vertex + 9 * i;
+        const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
+        const f3 center = divf(add(add(v1, v2), v3), 3.0f); // forward.cu:87
+        f3 acc[4] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
+        for (int v = 0; v < a.V; v++)
+        {
+            const f3 cp = {a.campos[3 * v], a.campos[3 * v + 1], a.campos[3 * v + 2]};
+            const float *gp = a.dL_dcolor + ((size_t)v * a.P + i) * 3;
+            const f3 c = {gp[0], gp[1], gp[2]};
+            const f3 dir_orig = sub(center, cp);
+            const f3 dir = divf(dir_orig, norm(dir_orig));
+            float b[16] = {};
+            const int nb = sh_basis(MAXDEG < a.sh_degree ? MAXDEG : a.sh_degree, dir, b);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+            {
+                float bk = b[u];
+#pragma unroll
+                for (int w = 1; w < M / 4; w++) bk = (kbase == 4 * w) ? b[4 * w + u] : bk;
+                if (kbase + u < nb) acc[u] = add(acc[u], scale(bk, c)); // coefficients above the active degree: zeros (the dense array's)
+            }
+        }
+        // element u of this float4 = component (4 j + u) % 3 of coefficient (4 j + u) / 3
+        const f3 e0 = jj == 0 ? acc[0] : (jj == 1 ? acc[1] : acc[2]);
+        const f3 e1 = jj == 0 ? acc[0] : (jj == 1 ? acc[1] : acc[3]);
+        const f3 e2 = jj == 0 ? acc[0] : (jj == 1 ? acc[2] : acc[3]);
+        const f3 e3 = jj == 0 ? acc[1] : (jj == 1 ? acc[2] : acc[3]);
+        g[0] = jj == 0 ? e0.x : (jj == 1 ? e0.y : e0.z);
+        g[1] = jj == 0 ? e1.y : (jj == 1 ? e1.z : e1.x);
+        g[2] = jj == 0 ? e2.z : (jj == 1 ? e2.x : e2.y);
+        g[3] = jj == 0 ? e3.x : (jj == 1 ? e3.y : e3.z);
+    }
+    const int64_t off = i * (3 * M) + 4 * j;
+    float4 *P_ = (float4 *)(a.param_dc + off), *M_ = (float4 *)(a.exp_avg_dc + off), *V_ = (float4 *)(a.exp_avg_sq_dc + off);
+    const float4 P4 = *P_, M4 = *M_, V4 = *V_;
+    float p[4] = {P4.x, P4.y, P4.z, P4.w}, m[4] = {M4.x, M4.y, M4.z, M4.w}, vv[4] = {V4.x, V4.y, V4.z, V4.w};
+    const AdamCoeffs co{t.beta2, t.w1, t.w2, t.eps};
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+        const bool dc = j == 0 && u < 3;
+        adam_element(p[u], g[u], m[u], vv[u], co, dc ? a.step_size_dc : a.step_size_rest, dc ? a.bias2_sqrt_dc : a.bias2_sqrt_rest, a.grad_scale);
+    }
+    *P_ = make_float4(p[0], p[1], p[2], p[3]);
+    *M_ = make_float4(m[0], m[1], m[2], m[3]);
+    *V_ = make_float4(vv[0], vv[1], vv[2], vv[3]);
+}
 } // namespace
+
+hipError_t ts_optim_adam_step_sh_factored(const tso_sh_factored_step &a, double beta1, double beta2, double eps, hipStream_t s)
+{
+    if (a.P <= 0) return hipSuccess;
+    ShFactoredArgs t{a, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps};
+    // one tensor (coefficient 0 in front of the others in rows of 3 M floats), rows of whole float4, 16-byte aligned: the dwordx4 kernel
+    const bool one_tensor = a.M > 1 && a.dc_stride == 3 * a.M && a.rest_stride == 3 * a.M && a.param_rest == a.param_dc + 3 &&
+                            a.exp_avg_rest == a.exp_avg_dc + 3 && a.exp_avg_sq_rest == a.exp_avg_sq_dc + 3;
+    if (one_tensor && (a.M == 4 || a.M == 16) && (((size_t)a.param_dc | (size_t)a.exp_avg_dc | (size_t)a.exp_avg_sq_dc) & 15) == 0)
+    {
+        const int64_t n4 = (int64_t)a.P * (3 * a.M / 4);
+        const dim3 grid4((unsigned)((n4 + 255) / 256));
+        if (a.M == 4) hipLaunchKernelGGL(adam_sh_factored_vec4_kernel<1>, grid4, dim3(256), 0, s, t);
+        else hipLaunchKernelGGL(adam_sh_factored_vec4_kernel<3>, grid4, dim3(256), 0, s, t);
+        return hipGetLastError();
+    }
+    const int64_t threads = (int64_t)a.P * a.M;
+    const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    switch (a.M)
+    {
+    case 1: hipLaunchKernelGGL(adam_sh_factored_kernel<0>, grid, block, 0, s, t); break;
+    case 4: hipLaunchKernelGGL(adam_sh_factored_kernel<1>, grid, block, 0, s, t); break;
+    case 9: hipLaunchKernelGGL(adam_sh_factored_kernel<2>, grid, block, 0, s, t); break;
+    case 16: hipLaunchKernelGGL(adam_sh_factored_kernel<3>, grid, block, 0, s, t); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
 
 hipError_t ts_optim_adam_step(const tso_adam_slice *slices, int n, double beta1, double beta2, double eps, hipStream_t s)
 {

@@ -282,22 +282,22 @@ __global__ void __launch_bounds__(256) ssim_l1_fwd_kernel(const float *__restric
     } while (PERSISTENT && have);
 }
 
-__global__ void __launch_bounds__(256) loss_finish_kernel(const float2 *__restrict__ partial, int nblocks, double inv_n, float w_l1,
-                                                           float w_ssim, float *__restrict__ out)
+// 1024 threads: at 1080p there are 12 240 partial pairs, and 256 threads walking 48 of them each + an 8-level LDS tree of doubles took 15 us
+// (profiles/r06_train_step_kernels.txt); this is 12 each, a wave shuffle network and one LDS exchange between the 16 waves.
+__global__ void __launch_bounds__(1024) loss_finish_kernel(const float2 *__restrict__ partial, int nblocks, double inv_n, float w_l1,
+                                                            float w_ssim, float *__restrict__ out)
 {
-    __shared__ double rs[256], rl[256];
+    __shared__ double rs[16], rl[16];
     double s = 0.0, l = 0.0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) { s += (double)partial[i].x; l += (double)partial[i].y; }
-    rs[threadIdx.x] = s; rl[threadIdx.x] = l;
+    for (int i = threadIdx.x; i < nblocks; i += 1024) { const float2 p = partial[i]; s += (double)p.x; l += (double)p.y; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); l += __shfl_xor(l, o); }
+    if ((threadIdx.x & 63) == 0) { rs[threadIdx.x >> 6] = s; rl[threadIdx.x >> 6] = l; }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1)
-    {
-        if ((int)threadIdx.x < o) { rs[threadIdx.x] += rs[threadIdx.x + o]; rl[threadIdx.x] += rl[threadIdx.x + o]; }
-        __syncthreads();
-    }
     if (threadIdx.x == 0)
     {
-        const double l1 = rl[0] * inv_n, ssim_loss = 1.0 - rs[0] * inv_n; // trainer_utils.py:76,103
+        double ts = 0.0, tl = 0.0;
+        for (int w = 0; w < 16; ++w) { ts += rs[w]; tl += rl[w]; }
+        const double l1 = tl * inv_n, ssim_loss = 1.0 - ts * inv_n; // trainer_utils.py:76,103
         out[0] = (float)((double)w_l1 * l1 + (double)w_ssim * ssim_loss);
         out[1] = (float)l1;
         out[2] = (float)ssim_loss;
@@ -447,7 +447,7 @@ hipError_t ts_loss_forward(const float *image, const float *gt, int C, int H, in
     if (need_grad) { if (vec) TS_SSIM_FWD(true, true); else TS_SSIM_FWD(true, false); }
     else { if (vec) TS_SSIM_FWD(false, true); else TS_SSIM_FWD(false, false); }
 #undef TS_SSIM_FWD
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(256), 0, s, c.partial, c.nblocks, 1.0 / ((double)C * H * W), w_l1, w_ssim, out);
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(1024), 0, s, c.partial, c.nblocks, 1.0 / ((double)C * H * W), w_l1, w_ssim, out);
     return hipGetLastError();
 }
 

@@ -363,7 +363,9 @@ hipError_t ts_knn_nearest_other(int P, int group, const float *points, uint32_t 
 
 // ---- fused Adam step (optim.hip, include/ts_optim.h) -------------------------------------------------------------------
 struct tso_adam_slice;
+struct tso_sh_factored_step;
 hipError_t ts_optim_adam_step(const tso_adam_slice *slices, int n, double beta1, double beta2, double eps, hipStream_t s);
+hipError_t ts_optim_adam_step_sh_factored(const tso_sh_factored_step &a, double beta1, double beta2, double eps, hipStream_t s);
 
 // ---- per-iteration model-update statistics (model_update.hip, include/ts_model.h) --------------------------------------
 hipError_t ts_model_training_statistic(int P, int V, const int32_t *radii, const float *c2d_grad, const float *csum, const float *cmax,
@@ -380,3 +382,4 @@ hipError_t ts_model_update_mask(int P, int mode, const float *opacity, const flo
                                 hipStream_t s);
 hipError_t ts_model_clip(int P, int mode, const uint8_t *mask, float value, float *param, float *exp_avg, float *exp_avg_sq, hipStream_t s);
 hipError_t ts_model_opacity_reset(int P, float reset_value, float *opacity, float *exp_avg, float *exp_avg_sq, hipStream_t s);
+hipError_t ts_model_max_distance(int n_vertices, const float *vertex, const float *campos, float *out, hipStream_t s);

@@ -27,11 +27,11 @@ Native code: libts2d.so (include/ts_loss.h, include/ts_model.h, include/ts_optim
 """
 from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss, DepthNormalLoss, DoGLoss, SmoothnessLoss, dogLoss, smoothnessLoss, downsample_bilinear  # noqa: F401
 from .triangle_renderer import TriangleRenderer  # noqa: F401
-from .model_forward import gamma_rescale_ratio, rescale_triangles, ste_opacity, render_view  # noqa: F401
+from .model_forward import background_depth, gamma_rescale_ratio, rescale_triangles, ste_opacity, render_view  # noqa: F401
 from .model_update import (DensificationStats, prune_points, densification, opacity_pruning, opacity_clipping, scale_pruning,  # noqa: F401
                            scale_clipping, opacity_reset, contribution_pruning, set_gamma, set_sh_degree, run_model_update)
 from . import schedulers  # noqa: F401
 from .raw_triangle import RawTriangle  # noqa: F401
-from .optim import FusedAdam, ShardedAdam  # noqa: F401
+from .optim import FusedAdam, ShardedAdam, ShFactors  # noqa: F401
 from .graphed import GraphedStep  # noqa: F401
 from .model_init import create_from_pcd, grid_sampling, grid_size_search, get_inside_mask, inter_point_distance, sample_points  # noqa: F401

@@ -6,18 +6,22 @@ scope) and performs, in the reference's order:
   * shs = cat(f_dc, f_rest) (:79-80), opacity = sigmoid(raw) (:83-84);
   * gamma rescale of every triangle about its centroid by 1 / sqrt(2^b b Gamma(b)), b = 1 / gamma (:614-618, :445-446);
   * straight-through binarised opacity (:620-621);
-  * bg_depth = max |camera_center - vertex| (:623; stays a 0-dim device tensor, converted by the rasterizer package);
+  * bg_depth = max |camera_center - vertex| (:623; `background_depth`: one kernel, stays a 0-dim device tensor that the rasterizer
+    package converts);
   * render_up_scale: render at s x resolution, bilinear resize of render / depth / normal back, radii // s (:625-659);
   * rich_info = is_training, sh_degree = min(active, max) (:639-641).
 """
 from __future__ import annotations
 
 import copy
+import ctypes
 import math
 from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F
+
+from diff_triangle_rasterization_2D import _C as _native
 
 from .losses import downsample_bilinear
 from .triangle_renderer import TriangleRenderer
@@ -43,6 +47,27 @@ def ste_opacity(opacity: torch.Tensor, threshold: float) -> torch.Tensor:
     return ((opacity > threshold).float() - opacity).detach() + opacity
 
 
+_lib = _native._lib
+_lib.tsm_max_vertex_distance.restype = ctypes.c_int
+_lib.tsm_max_vertex_distance.argtypes = [ctypes.c_int32] + [ctypes.c_void_p] * 4
+
+
+def background_depth(vertex: torch.Tensor, camera_center: torch.Tensor) -> torch.Tensor:
+    """VanillaTS_model.py:623, `(camera_center - vertex).norm(dim=-1).max()`: a 0-dim device tensor, by one read of the vertices
+    (include/ts_model.h: tsm_max_vertex_distance) instead of torch's three kernels.  It is a raster SETTING (the rasterizer package reads it
+    as a number), so it carries no gradient here as it carries none into the reference's rasterizer."""
+    v = vertex.detach()
+    if not v.is_cuda:
+        raise RuntimeError("background_depth: the vertices live on the GPU (there is no CPU path)")
+    if v.dtype != torch.float32 or not v.is_contiguous():
+        v = v.float().contiguous()
+    c = camera_center.detach().to(device=v.device, dtype=torch.float32).contiguous()
+    out = torch.empty((), device=v.device, dtype=torch.float32)
+    _native._check(_lib.tsm_max_vertex_distance(v.numel() // 3, v.data_ptr(), c.data_ptr(), out.data_ptr(),
+                                                torch.cuda.current_stream(v.device).cuda_stream), "tsm_max_vertex_distance")
+    return out
+
+
 def render_view(camera, vertex: torch.Tensor, f_dc: torch.Tensor, f_rest: torch.Tensor, raw_opacity: torch.Tensor, *,
                 bg_color: torch.Tensor, gamma: float = 1.0, active_sh_degree: int = 0, max_sh_degree: int = 3,
                 is_training: bool = True, back_culling: bool = False, gamma_rescale: bool = False,
@@ -58,7 +83,7 @@ def render_view(camera, vertex: torch.Tensor, f_dc: torch.Tensor, f_rest: torch.
     opacity = torch.sigmoid(raw_opacity)
     v_render = rescale_triangles(vertex, gamma_rescale_ratio(gamma)) if gamma_rescale else vertex
     o_render = ste_opacity(opacity, ste_threshold) if ste_threshold is not None else opacity
-    bg_depth = (camera.camera_center.view(1, 1, 3) - vertex).norm(dim=-1).max()
+    bg_depth = background_depth(vertex, camera.camera_center)
 
     w, h = camera.image_width, camera.image_height
     up = int(render_up_scale) if render_up_scale and render_up_scale > 1 else 1

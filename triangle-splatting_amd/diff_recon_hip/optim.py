@@ -40,6 +40,35 @@ _lib.tso_adam_step.restype = C.c_int
 _lib.tso_adam_step.argtypes = [C.POINTER(_Slice), C.c_int32, C.c_double, C.c_double, C.c_double, _fp]
 
 
+class _ShFactoredStep(C.Structure):  # tso_sh_factored_step, include/ts_optim.h
+    _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("sh_degree", C.c_int32), ("V", C.c_int32), ("vertex", _fp), ("campos", _fp), ("dL_dcolor", _fp),
+                ("param_dc", _fp), ("exp_avg_dc", _fp), ("exp_avg_sq_dc", _fp), ("param_rest", _fp), ("exp_avg_rest", _fp), ("exp_avg_sq_rest", _fp),
+                ("dc_stride", C.c_int64), ("rest_stride", C.c_int64), ("step_size_dc", C.c_float), ("bias2_sqrt_dc", C.c_float),
+                ("step_size_rest", C.c_float), ("bias2_sqrt_rest", C.c_float), ("grad_scale", C.c_float)]
+
+
+_lib.tso_adam_step_sh_factored.restype = C.c_int
+_lib.tso_adam_step_sh_factored.argtypes = [C.POINTER(_ShFactoredStep), C.c_double, C.c_double, C.c_double, _fp]
+
+
+class ShFactors:
+    """The SH gradient of one training iteration in factored form, for `FusedAdam.step(sh_factors=...)`.
+
+        with factored_sh_grads() as sink:        # diff_triangle_rasterization_2D.parallel: the backward passes leave dL_dshs unwritten and
+            loss.backward()                      #   hand the sink (dL_dRGB (P, 3), camera centre) per view
+        opt.step(sh_factors=ShFactors(sink, vertex, sh_degree, shs=shs))          # or f_dc=..., f_rest=... (the reference's two tensors)
+
+    `vertex` is the tensor the rasterizer saw (the SH direction is centroid - camera): the step reads it before it updates it.  The colour
+    parameters must reach the rasterizer WITHOUT an operation that changes their gradient (the one-tensor `shs` itself, or cat(f_dc, f_rest)):
+    the factored gradient is the gradient with respect to the rasterizer's `shs` input."""
+
+    def __init__(self, sink, vertex: torch.Tensor, sh_degree: int, shs: Optional[torch.Tensor] = None, f_dc: Optional[torch.Tensor] = None,
+                 f_rest: Optional[torch.Tensor] = None, grad_scale: float = 1.0):
+        if (shs is None) == (f_dc is None) or (f_dc is None) != (f_rest is None):
+            raise ValueError("ShFactors: pass either shs (P, M, 3) or f_dc (P, 1, 3) + f_rest (P, M - 1, 3)")
+        self.sink, self.vertex, self.sh_degree, self.shs, self.f_dc, self.f_rest, self.grad_scale = sink, vertex, int(sh_degree), shs, f_dc, f_rest, grad_scale
+
+
 def _corrections(lr: float, step: int, beta1: float, beta2: float) -> Tuple[float, float]:
     """(step_size, bias2_sqrt) exactly as torch/optim/adam.py forms them (Python doubles)."""
     bias_correction1 = 1 - beta1 ** step
@@ -88,12 +117,81 @@ class FusedAdam(torch.optim.Optimizer):
             raise ValueError(f"Invalid beta parameters: {betas}")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
+    def _group_of(self, p):
+        for group in self.param_groups:
+            if any(q is p for q in group["params"]):
+                return group
+        raise ValueError("FusedAdam.step(sh_factors=...): the colour tensor is not one of this optimizer's parameters")
+
+    def _moments(self, p):
+        st = self.state[p]
+        if len(st) == 0:
+            st["step"] = 0
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        st["step"] = int(st["step"]) + 1
+        return st
+
+    def _step_sh_factored(self, f: ShFactors):
+        """include/ts_optim.h, tso_adam_step_sh_factored: the colour parameters stepped from (dL_dRGB, camera centre) per view -- the same numbers
+        as step() on the dense dL_dshs, which then is neither written by the backward nor read here."""
+        sink = f.sink
+        if not sink.colors:
+            raise RuntimeError("FusedAdam.step(sh_factors=...): no SH-mode backward pass ran under factored_sh_grads()")
+        one = f.shs is not None
+        tensors = (f.shs,) if one else (f.f_dc, f.f_rest)
+        for t in tensors + (f.vertex,):
+            if not t.is_cuda:
+                raise RuntimeError("the fused Adam step needs tensors on a HIP device; there is no CPU fallback")
+            if t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError("the fused Adam step takes contiguous float32 tensors")
+        if any(t.grad is not None for t in tensors):
+            raise RuntimeError("FusedAdam.step(sh_factors=...): the colour tensor also holds a dense .grad -- a backward pass ran outside "
+                               "factored_sh_grads(); stepping it from the factors would drop that gradient")
+        P = f.vertex.shape[0]
+        M = f.shs.shape[1] if one else 1 + f.f_rest.shape[1]
+        if tensors[0].shape[0] != P or (not one and (f.f_dc.shape[1] != 1 or f.f_rest.shape[0] != P)):
+            raise ValueError("ShFactors: vertex and colour tensors disagree on the number of triangles")
+        V = len(sink.colors)
+        dev = f.vertex.device
+        colors = sink.colors[0].reshape(P, 3).contiguous() if V == 1 else torch.stack([c.reshape(P, 3) for c in sink.colors])
+        campos = torch.stack(list(sink.campos)).to(dev, torch.float32).contiguous()
+        groups = [self._group_of(t) for t in tensors]
+        betas, eps = groups[0]["betas"], groups[0]["eps"]
+        if any(g["betas"] != betas or g["eps"] != eps for g in groups):
+            raise ValueError("ShFactors: f_dc and f_rest must share betas and eps")
+        states = [self._moments(t) for t in tensors]
+        if one:
+            g, st = groups[0], states[0]
+            lr_rest = g["lr_tail"] if g.get("tail_period") else g["lr"]
+            if g.get("tail_period") and (int(g["tail_period"]) != 3 * M or int(g["tail_split"]) != 3):
+                raise ValueError("ShFactors: the tail of a one-tensor colour group must be (tail_period, tail_split) = (3 M, 3)")
+            (s_dc, b_dc), (s_rest, b_rest) = _corrections(g["lr"], st["step"], *betas), _corrections(lr_rest, st["step"], *betas)
+            ptr = lambda t, off: t.data_ptr() + 4 * off
+            row = _ShFactoredStep(P, M, f.sh_degree, V, f.vertex.data_ptr(), campos.data_ptr(), colors.data_ptr(),
+                                  ptr(f.shs, 0), ptr(st["exp_avg"], 0), ptr(st["exp_avg_sq"], 0),
+                                  ptr(f.shs, 3) if M > 1 else None, ptr(st["exp_avg"], 3) if M > 1 else None, ptr(st["exp_avg_sq"], 3) if M > 1 else None,
+                                  3 * M, 3 * M, s_dc, b_dc, s_rest, b_rest, f.grad_scale)
+        else:
+            (s_dc, b_dc) = _corrections(groups[0]["lr"], states[0]["step"], *betas)
+            (s_rest, b_rest) = _corrections(groups[1]["lr"], states[1]["step"], *betas)
+            row = _ShFactoredStep(P, M, f.sh_degree, V, f.vertex.data_ptr(), campos.data_ptr(), colors.data_ptr(),
+                                  f.f_dc.data_ptr(), states[0]["exp_avg"].data_ptr(), states[0]["exp_avg_sq"].data_ptr(),
+                                  f.f_rest.data_ptr() if M > 1 else None, states[1]["exp_avg"].data_ptr() if M > 1 else None,
+                                  states[1]["exp_avg_sq"].data_ptr() if M > 1 else None, 3, 3 * (M - 1), s_dc, b_dc, s_rest, b_rest, f.grad_scale)
+        with torch.cuda.device(dev):
+            _native._check(_lib.tso_adam_step_sh_factored(C.byref(row), betas[0], betas[1], eps, torch.cuda.current_stream().cuda_stream),
+                           "adam_step_sh_factored")
+        sink.clear()
+
     @torch.no_grad()
-    def step(self, closure=None):
+    def step(self, closure=None, sh_factors: Optional[ShFactors] = None):
         loss = None
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        if sh_factors is not None:
+            self._step_sh_factored(sh_factors)  # FIRST: it reads the vertices the backward ran on, the launch below updates them
         by_hyper: Dict[Tuple[float, float, float, torch.device], List[dict]] = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
@@ -102,12 +200,7 @@ class FusedAdam(torch.optim.Optimizer):
                     continue
                 if p.grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients")
-                st = self.state[p]
-                if len(st) == 0:
-                    st["step"] = 0
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] = int(st["step"]) + 1
+                st = self._moments(p)
                 step_size, bias2_sqrt = _corrections(group["lr"], st["step"], beta1, beta2)
                 row = dict(param=p, grad=p.grad if p.grad.is_contiguous() else p.grad.contiguous(), exp_avg=st["exp_avg"], exp_avg_sq=st["exp_avg_sq"],
                            step_size=step_size, bias2_sqrt=bias2_sqrt)

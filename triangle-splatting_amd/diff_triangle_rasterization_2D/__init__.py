@@ -192,10 +192,13 @@ class _RasterizeTriangles(torch.autograd.Function):
         H, W = rs.image_height, rs.image_width
         zeros = lambda *shape: torch.zeros(shape, device=vertex.device, dtype=vertex.dtype)
         g_feature = grads_out[0] if grads_out[0] is not None else zeros(ctx.num_channels, H, W)
-        if rs.rich_info:
+        if rs.rich_info and (grads_out[2] is not None or grads_out[3] is not None):
             g_depth = grads_out[2] if grads_out[2] is not None else zeros(H, W)
             g_normal = grads_out[3] if grads_out[3] is not None else zeros(3, H, W)
-        else:  # FIX of the reference's unbound names
+        else:
+            # rich_info False: FIX of the reference's unbound names.  rich_info True and a loss that reads the colours only: empty = "no gradient
+            # on depth and normal" (include/ts2d.h, ts2d_loss_grads) -- the values two images of zeros give, without the two fills and by the
+            # colour-only pixel kernel
             g_depth = g_normal = torch.empty((0,), device=vertex.device, dtype=vertex.dtype)
         native_args = _camera_and_geometry_args(rs, ctx.bg_depth) + (
             vertex, shs, feature, opacity, ctx.num_rendered, radii, geometryBuffer, binningBuffer, imageBuffer,
