@@ -30,6 +30,7 @@ import torch
 import synthetic
 import diff_recon_hip as D
 from diff_recon_hip import DensificationStats, DepthNormalLoss, photometric_loss, render_view
+from diff_triangle_rasterization_2D.parallel import ShGradSink, factored_sh_grads
 
 
 class Camera:
@@ -100,9 +101,12 @@ class SyntheticModel(DensificationStats):
 
 
 def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, seed=0, views=2, views_per_step=2, log=print, updates=True,
-          w_geometry=0.0, single_sh=False, init_from_pcd=False):
+          w_geometry=0.0, single_sh=False, init_from_pcd=False, factored_sh=False):
     """w_geometry > 0 adds the depth / normal consistency term of the *_VanillaTS_mesh.yaml configurations (geometry_loss: w_geometry 0.05,
-    scale_factor 0.5, from iteration start_iter on; VanillaTS_trainer.py:30-31,64-65,84,111) -- the producer of dL_dout_depth / dL_dout_normal."""
+    scale_factor 0.5, from iteration start_iter on; VanillaTS_trainer.py:30-31,64-65,84,111) -- the producer of dL_dout_depth / dL_dout_normal.
+    factored_sh: the backward passes hand the optimizer (dL_dRGB, camera centre) per view instead of writing the dense dL_dshs, and FusedAdam
+    steps the colour parameters from those (include/ts_optim.h: tso_adam_step_sh_factored) -- the same numbers, 12 M bytes per triangle less
+    written and as many less read."""
     dev = torch.device("cuda")
     geometry_loss = DepthNormalLoss(scale_factor=0.5) if w_geometry > 0 else None
     g_start_iter = iters // 2  # the reference's configs start it at half of the schedule (15 000 of 30 000)
@@ -132,6 +136,7 @@ def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, se
     for it in range(1, iters + 1):
         m.optimizer.zero_grad(set_to_none=True)
         pkgs, total = [], torch.zeros((), device=dev)  # the loss stays on the device: no host synchronisation inside an iteration
+        sink = ShGradSink()
         for k in range(views_per_step):  # the views of one step: gradients are summed, like ranks' gradients in image-parallel training
             v = (it * views_per_step + k) % views
             colour = dict(shs=m._shs) if m.single_sh else {}
@@ -140,10 +145,15 @@ def train(rasterizer="2D", iters=200, triangles=20000, width=256, height=192, se
             loss = photometric_loss(pkg["render"], gts[v], 0.8, 0.2)  # w_L1 = 1 - w_ssim, VanillaTS_trainer.py:72,111
             if geometry_loss is not None and it > g_start_iter:
                 loss = loss + w_geometry * geometry_loss(pkg["depth"], pkg["normal"], cams[v].tan_fovx, cams[v].tan_fovy)
-            loss.backward()
+            with factored_sh_grads(sink, enabled=factored_sh):
+                loss.backward()
             pkgs.append(pkg)
             total += loss.detach()
-        m.optimizer.step()
+        if factored_sh:
+            colour = dict(shs=m._shs) if m.single_sh else dict(f_dc=m._f_dc, f_rest=m._f_rest)
+            m.optimizer.step(sh_factors=D.ShFactors(sink, m._vertex, m.active_sh_degree, **colour))
+        else:
+            m.optimizer.step()
         if updates:
             m.model_update(it, pkgs)
         else:
@@ -165,9 +175,11 @@ if __name__ == "__main__":
     ap.add_argument("--views", type=int, default=4)
     ap.add_argument("--single-sh-tensor", action="store_true", help="one (P, M, 3) colour parameter with two learning rates instead of f_dc + f_rest")
     ap.add_argument("--init-from-pcd", action="store_true", help="start from diff_recon_hip.create_from_pcd (point cloud -> distCUDA2 -> equilateral triangles) like the reference's trainer")
+    ap.add_argument("--factored-sh", action="store_true", help="Adam on the SH coefficients from the factored gradient (dL_dRGB per view) instead of the dense dL_dshs")
     ap.add_argument("--w-geometry", type=float, default=0.0, help="weight of the depth / normal consistency loss (0.05 in the *_VanillaTS_mesh configs)")
     a = ap.parse_args()
-    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views, w_geometry=a.w_geometry, single_sh=a.single_sh_tensor, init_from_pcd=a.init_from_pcd)
+    losses, m, sec = train(a.rasterizer, a.iters, a.triangles, views=a.views, w_geometry=a.w_geometry, single_sh=a.single_sh_tensor, init_from_pcd=a.init_from_pcd,
+                           factored_sh=a.factored_sh)
     for row in m.log:
         print("  update", row)
     print(f"{a.rasterizer}: loss {losses[0]:.5f} -> {losses[-1]:.5f} in {a.iters} iterations, {sec * 1e3:.2f} ms/iteration (incl. Python)")

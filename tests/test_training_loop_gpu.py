@@ -62,6 +62,29 @@ def test_single_colour_tensor_trains_like_the_reference_layout():
     assert {"densification", "opacity_pruning"} <= {name for _, name, _, _ in m.log}
 
 
+@pytest.mark.parametrize("single_sh", [False, True])
+def test_training_on_factored_sh_gradients_follows_the_dense_loop(single_sh):
+    """Round 6: the loop with the SH coefficients stepped from the factored gradient (dL_dRGB per view, FusedAdam.step(sh_factors=...)) against the
+    loop on the dense dL_dshs: the same arithmetic (tests/test_optim_gpu.py: equal bit for bit on equal factors), so the losses follow each other
+    up to the order of the backward's float atomics -- through two views per step, the growing SH degree, and the structural updates."""
+    import torch
+    import train_synthetic
+    kw = dict(iters=40, triangles=3000, width=128, height=96, views=2, views_per_step=2, log=None, updates=False, single_sh=single_sh)
+    dense, _, _ = train_synthetic.train("2D", **kw)
+    fact, m, _ = train_synthetic.train("2D", factored_sh=True, **kw)
+    for a, b in zip(dense, fact):
+        assert abs(a - b) <= 2e-3 * abs(a), (a, b)
+    assert min(fact[-5:]) < 0.8 * fact[0]
+    colour = [m._shs] if single_sh else [m._f_dc, m._f_rest]
+    assert all(c.grad is None for c in colour) and all(m.optimizer.state[c]["step"] == 40 for c in colour)
+    losses, m, _ = train_synthetic.train("3D", iters=160, triangles=4000, width=160, height=112, views=3, views_per_step=2, log=None, single_sh=single_sh,
+                                         factored_sh=True)
+    assert all(l == l for l in losses) and min(losses[-10:]) < 0.8 * losses[0]
+    assert {"densification", "opacity_pruning"} <= {name for _, name, _, _ in m.log}
+    colour = [m._shs] if single_sh else [m._f_dc, m._f_rest]
+    assert all(bool(torch.isfinite(c).all()) for c in colour)
+
+
 def test_training_starts_from_create_from_pcd():
     """Round 6: the loop started the way the reference's trainer starts it -- a point cloud through diff_recon_hip.create_from_pcd (distCUDA2 sizes the
     equilateral triangles) -- still reduces the loss."""

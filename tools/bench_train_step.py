@@ -62,10 +62,14 @@ def main():
     ap.add_argument("--iters", type=int, default=40)
     ap.add_argument("--dense-adam", action="store_true", help="the colour parameters stepped from the dense dL_dshs (the form of rounds 4-5) instead of "
                     "the factored gradient (FusedAdam.step(sh_factors=...), include/ts_optim.h: tso_adam_step_sh_factored)")
+    ap.add_argument("--mimic-dense-alloc", action="store_true", help="experiment: the factored iteration with the dense iteration's allocation pattern "
+                    "(a (P, M, 3) tensor allocated and dropped where the backward would have allocated dL_dshs)")
+    ap.add_argument("--hold-mb", type=int, default=0, help="experiment: a tensor of this many MB allocated before anything else and kept")
     a = ap.parse_args()
     c = NS(**CONFIGS[a.config])
     dev = torch.device("cuda")
     W, H = c.w * c.up, c.h * c.up  # the rasterizer's resolution
+    hold = torch.empty(a.hold_mb << 20, dtype=torch.uint8, device=dev) if a.hold_mb else None  # noqa: F841
     s = synthetic.scene(c.P, W, H, c.D, seed=42)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     cam = Camera(s, c.w, c.h, dev)
@@ -90,6 +94,8 @@ def main():
         loss = D.photometric_loss(pkg["render"], gt, 0.8, 0.2)
         if geo is not None:
             loss = loss + c.w_geo * geo(pkg["depth"], pkg["normal"], cam.tan_fovx, cam.tan_fovy)
+        if a.mimic_dense_alloc:
+            dummy = torch.empty((c.P, M, 3), device=dev)  # noqa: F841  (freed at the end of this function: back in the allocator's pool like dL_dshs after the step)
         with factored_sh_grads(enabled=not a.dense_adam) as sink:
             loss.backward()
         out["factors"] = (list(sink.colors), list(sink.campos))  # tensors of this iteration (of the capture, under graph replay)

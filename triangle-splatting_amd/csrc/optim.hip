@@ -144,71 +144,80 @@ __global__ void __launch_bounds__(256) adam_sh_factored_kernel(const ShFactoredA
     for (int c = 0; c < 3; c++) { P_[c] = p[c]; M_[c] = m[c]; V_[c] = vv[c]; }
 }
 
-// The same step for ONE (P, M, 3) tensor with 3 M a multiple of four floats (M = 4, 16) on 16-byte aligned rows: a thread owns four consecutive
-// floats of a triangle's row = dwordx4 loads and stores (the per-coefficient kernel above moves single dwords 12 bytes apart: 5.2 TB/s at 1 M
-// triangles against 6.1 of the dense kernel).  Twelve floats are four coefficients, so the thread's float4 is one of three patterns
-// (k0 k0 k0 k1 | k1 k1 k2 k2 | k2 k3 k3 k3) x (r g b r | g b r g | b r g b) of the coefficient quadruple 4 (j / 3) .. + 3.
+// The same step for ONE (P, M, 3) tensor with 3 M a multiple of four floats (M = 4, 16) on 16-byte aligned rows: dwordx4 loads and stores (the
+// per-coefficient kernel above moves single dwords 12 bytes apart: 5.2 TB/s at 1 M triangles against 6.1 of the dense kernel).  A workgroup owns 64
+// triangles: wave w forms coefficients 4 w .. 4 w + 3 of their gradient rows -- one lane per triangle: direction, basis, 12 products -- into LDS, then all four waves
+// walk the 64 x 3 M / 4 float4 of the three arrays.  (A first version let each of a row's 12 float4 threads form the basis for itself: twelve times instead of four times
+// the arithmetic, hidden under the memory time but not free -- the blend kernels of the next iteration ran 5-8 % slower on a power-limited box,
+// profiles/r06_train_step.jsonl.)  Rows of 3 M + 4 floats in LDS: 16-byte chunks 13 i + c, distinct over eight neighbouring lanes.
 template <int MAXDEG>
 __global__ void __launch_bounds__(256) adam_sh_factored_vec4_kernel(const ShFactoredArgs t)
 {
-    constexpr int M = (MAXDEG + 1) * (MAXDEG + 1), Q = 3 * M / 4; // float4 per triangle
+    constexpr int M = (MAXDEG + 1) * (MAXDEG + 1), Q = 3 * M / 4, LROW = 3 * M + 4; // Q float4 per triangle
     static_assert((3 * M) % 4 == 0, "rows of 3 M floats must be whole float4");
+    __shared__ __attribute__((aligned(16))) float grow[64 * LROW];
     const tso_sh_factored_step &a = t.a;
-    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int64_t i = q / Q;
-    const int j = (int)(q - i * Q);
-    if (i >= a.P) return;
-    const int kbase = 4 * (j / 3), jj = j - 3 * (j / 3);
-    float g[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int NB = (a.sh_degree + 1) * (a.sh_degree + 1);
-    if (kbase < NB)
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const int wave = threadIdx.x >> 6; // wave w forms coefficients 4 w .. 4 w + 3 of the 64 rows (M = 4: wave 0 alone)
+    if (4 * wave < M)
     {
-        const float *vp = a.vertex + 9 * i;
-        const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
-        const f3 center = divf(add(add(v1, v2), v3), 3.0f); // forward.cu:87
+        const int64_t i = i0 + (threadIdx.x & 63);
         f3 acc[4] = {{0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 0.0f}};
-        for (int v = 0; v < a.V; v++)
+        if (i < a.P && 4 * wave < (a.sh_degree + 1) * (a.sh_degree + 1))
         {
-            const f3 cp = {a.campos[3 * v], a.campos[3 * v + 1], a.campos[3 * v + 2]};
-            const float *gp = a.dL_dcolor + ((size_t)v * a.P + i) * 3;
-            const f3 c = {gp[0], gp[1], gp[2]};
-            const f3 dir_orig = sub(center, cp);
-            const f3 dir = divf(dir_orig, norm(dir_orig));
-            float b[16] = {};
-            const int nb = sh_basis(MAXDEG < a.sh_degree ? MAXDEG : a.sh_degree, dir, b);
-#pragma unroll
-            for (int u = 0; u < 4; u++)
+            const float *vp = a.vertex + 9 * i;
+            const f3 v1 = {vp[0], vp[1], vp[2]}, v2 = {vp[3], vp[4], vp[5]}, v3 = {vp[6], vp[7], vp[8]};
+            const f3 center = divf(add(add(v1, v2), v3), 3.0f); // forward.cu:87
+            for (int v = 0; v < a.V; v++)
             {
-                float bk = b[u];
+                const f3 cp = {a.campos[3 * v], a.campos[3 * v + 1], a.campos[3 * v + 2]};
+                const float *gp = a.dL_dcolor + ((size_t)v * a.P + i) * 3;
+                const f3 c = {gp[0], gp[1], gp[2]};
+                const f3 dir_orig = sub(center, cp);
+                const f3 dir = divf(dir_orig, norm(dir_orig));
+                float b[16] = {};
+                const int nb = sh_basis(MAXDEG < a.sh_degree ? MAXDEG : a.sh_degree, dir, b);
 #pragma unroll
-                for (int w = 1; w < M / 4; w++) bk = (kbase == 4 * w) ? b[4 * w + u] : bk;
-                if (kbase + u < nb) acc[u] = add(acc[u], scale(bk, c)); // coefficients above the active degree: zeros (the dense array's)
+                for (int u = 0; u < 4; u++)
+                {
+                    float bk = b[u]; // wave-uniform choice of the quadruple
+#pragma unroll
+                    for (int w = 1; w < M / 4; w++) bk = (wave == w) ? b[4 * w + u] : bk;
+                    if (4 * wave + u < nb) acc[u] = add(acc[u], scale(bk, c)); // coefficients above the active degree: zeros (the dense array's)
+                }
             }
         }
-        // element u of this float4 = component (4 j + u) % 3 of coefficient (4 j + u) / 3
-        const f3 e0 = jj == 0 ? acc[0] : (jj == 1 ? acc[1] : acc[2]);
-        const f3 e1 = jj == 0 ? acc[0] : (jj == 1 ? acc[1] : acc[3]);
-        const f3 e2 = jj == 0 ? acc[0] : (jj == 1 ? acc[2] : acc[3]);
-        const f3 e3 = jj == 0 ? acc[1] : (jj == 1 ? acc[2] : acc[3]);
-        g[0] = jj == 0 ? e0.x : (jj == 1 ? e0.y : e0.z);
-        g[1] = jj == 0 ? e1.y : (jj == 1 ? e1.z : e1.x);
-        g[2] = jj == 0 ? e2.z : (jj == 1 ? e2.x : e2.y);
-        g[3] = jj == 0 ? e3.x : (jj == 1 ? e3.y : e3.z);
+        float *row = grow + (threadIdx.x & 63) * LROW + 12 * wave; // four coefficients = three float4
+        *(float4 *)(row) = make_float4(acc[0].x, acc[0].y, acc[0].z, acc[1].x);
+        *(float4 *)(row + 4) = make_float4(acc[1].y, acc[1].z, acc[2].x, acc[2].y);
+        *(float4 *)(row + 8) = make_float4(acc[2].z, acc[3].x, acc[3].y, acc[3].z);
     }
-    const int64_t off = i * (3 * M) + 4 * j;
-    float4 *P_ = (float4 *)(a.param_dc + off), *M_ = (float4 *)(a.exp_avg_dc + off), *V_ = (float4 *)(a.exp_avg_sq_dc + off);
-    const float4 P4 = *P_, M4 = *M_, V4 = *V_;
-    float p[4] = {P4.x, P4.y, P4.z, P4.w}, m[4] = {M4.x, M4.y, M4.z, M4.w}, vv[4] = {V4.x, V4.y, V4.z, V4.w};
+    __syncthreads();
     const AdamCoeffs co{t.beta2, t.w1, t.w2, t.eps};
+    const int64_t left = a.P - i0;
+    const int n4 = (int)(left < 64 ? left : 64) * Q;
 #pragma unroll
-    for (int u = 0; u < 4; u++)
+    for (int u = 0; u < (64 * Q + 255) / 256; u++)
     {
-        const bool dc = j == 0 && u < 3;
-        adam_element(p[u], g[u], m[u], vv[u], co, dc ? a.step_size_dc : a.step_size_rest, dc ? a.bias2_sqrt_dc : a.bias2_sqrt_rest, a.grad_scale);
+        const int q = threadIdx.x + 256 * u; // float4 q of this workgroup's contiguous 64 x 3 M floats
+        if (q >= n4) break;
+        const int il = q / Q, j = q - il * Q;
+        const float4 G4 = *(const float4 *)(grow + il * LROW + 4 * j);
+        const int64_t off = i0 * (3 * M) + 4 * (int64_t)q;
+        float4 *P_ = (float4 *)(a.param_dc + off), *M_ = (float4 *)(a.exp_avg_dc + off), *V_ = (float4 *)(a.exp_avg_sq_dc + off);
+        const float4 P4 = *P_, M4 = *M_, V4 = *V_;
+        float p[4] = {P4.x, P4.y, P4.z, P4.w}, m[4] = {M4.x, M4.y, M4.z, M4.w}, vv[4] = {V4.x, V4.y, V4.z, V4.w};
+        const float g[4] = {G4.x, G4.y, G4.z, G4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+        {
+            const bool dc = j == 0 && e < 3;
+            adam_element(p[e], g[e], m[e], vv[e], co, dc ? a.step_size_dc : a.step_size_rest, dc ? a.bias2_sqrt_dc : a.bias2_sqrt_rest, a.grad_scale);
+        }
+        *P_ = make_float4(p[0], p[1], p[2], p[3]);
+        *M_ = make_float4(m[0], m[1], m[2], m[3]);
+        *V_ = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
-    *P_ = make_float4(p[0], p[1], p[2], p[3]);
-    *M_ = make_float4(m[0], m[1], m[2], m[3]);
-    *V_ = make_float4(vv[0], vv[1], vv[2], vv[3]);
 }
 } // namespace
 
@@ -221,8 +230,7 @@ hipError_t ts_optim_adam_step_sh_factored(const tso_sh_factored_step &a, double 
                             a.exp_avg_rest == a.exp_avg_dc + 3 && a.exp_avg_sq_rest == a.exp_avg_sq_dc + 3;
     if (one_tensor && (a.M == 4 || a.M == 16) && (((size_t)a.param_dc | (size_t)a.exp_avg_dc | (size_t)a.exp_avg_sq_dc) & 15) == 0)
     {
-        const int64_t n4 = (int64_t)a.P * (3 * a.M / 4);
-        const dim3 grid4((unsigned)((n4 + 255) / 256));
+        const dim3 grid4((unsigned)((a.P + 63) / 64)); // 64 triangles per workgroup
         if (a.M == 4) hipLaunchKernelGGL(adam_sh_factored_vec4_kernel<1>, grid4, dim3(256), 0, s, t);
         else hipLaunchKernelGGL(adam_sh_factored_vec4_kernel<3>, grid4, dim3(256), 0, s, t);
         return hipGetLastError();
