@@ -116,6 +116,8 @@ def main():
                     help="NOT the headline metric: every step also runs the fused Adam step (diff_recon_hip.FusedAdam: vertex, opacity and the SH tensor "
                          "with the reference's f_dc / f_rest learning-rate split, one launch) on the step's gradients, with all learning rates 0 so that "
                          "the scene stays the one BASELINE.json names; reported as config.optimizer")
+    ap.add_argument("--depth-lsd", action="store_true", help="lab library only: the LSD depth sort of rounds 2-5 at every size instead of the sampled-splitter "
+                    "form (binning.hip: depth_split_*), for A/B runs")
     ap.add_argument("--force-depth-pass4", action="store_true",
                     help="NOT the headline: the depth sort runs its fourth pass although every depth of the synthetic scene shares the top key byte "
                          "(what a scene spanning more than a factor of four in depth costs).  Needs the lab library: "
@@ -185,6 +187,12 @@ def main():
         if not hasattr(_C._lib, "ts2d_lab_force_depth_pass4"):
             raise SystemExit("--force-depth-pass4 needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
         _C._lib.ts2d_lab_force_depth_pass4(1)
+    if args.depth_lsd:
+        if not hasattr(_C._lib, "ts2d_lab_depth_split"):
+            raise SystemExit("--depth-lsd needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
+        import ctypes
+        _C._lib.ts2d_lab_depth_split.argtypes = [ctypes.c_int, ctypes.c_int]
+        _C._lib.ts2d_lab_depth_split(1, 0)
     if args.side_stream:
         if not hasattr(_C._lib, "ts2d_lab_side_stream"):
             raise SystemExit("--side-stream needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")

@@ -51,6 +51,60 @@ if os.environ.get("LAB_DEPTH_ORDER") == "1":
         out.append(e)
     print("LAB_RESULT " + json.dumps(out))
     sys.exit(0)
+if os.environ.get("LAB_DEPTH_SPLIT") == "1":
+    # Round 6: the depth order of mid-sized scenes by sampled splitters + per-bucket sorts in LDS (binning.hip: depth_split_* / depth_bucket_sort_kernel,
+    # the product's path between 12 288 and 500 000 triangles; here up to the 1.6 M it supports) against the LSD passes (ts2d_lab_depth_split(1, 0)) and against itself
+    # with a per-bucket register capacity of 512 pairs (ts2d_lab_depth_split(2, 512): every ordinary bucket takes the kernel's global-memory
+    # path).  Depth permutation, instance offsets (= tiles in depth order + block sums + scan), instance count, sorted instance list and image
+    # must be IDENTICAL, on scenes that bend the buckets: a third of the triangles culled (key 0), half of them at ONE depth (a bucket of equal
+    # keys larger than the registers: the copy), depths quantised to 40 values (oversize buckets of few distinct keys), a far background (the
+    # splitters follow the sample, not the key range), depths that cross several powers of four (the fourth LSD pass is not skipped).
+    import ctypes
+    from diff_triangle_rasterization_2D import _C
+    _C._lib.ts2d_lab_depth_split.argtypes = [ctypes.c_int, ctypes.c_int]
+
+    def bend(s, kind):
+        v = s["vertex"]
+        P = v.shape[0]
+        zc = v[:, :, 2].mean(axis=1, keepdims=True)
+        if kind == "culled":
+            v[::3, :, 2] += 5000.0
+        elif kind == "one_depth":
+            v[: P // 2, :, 2] = zc[: P // 2].mean()  # every vertex of these triangles at ONE z: one depth key, bit for bit
+        elif kind == "quantised":
+            q = np.round(zc / 20.0) * 20.0
+            v[:, :, 2] = q
+        elif kind == "background":
+            v[: P // 50, :, 2] -= 30000.0  # 2 % of the triangles five octaves behind the rest: the key RANGE is mostly empty, the sample is not
+        elif kind == "octaves":
+            scale = np.exp2(np.random.default_rng(1).uniform(-3.0, 0.0, size=(P, 1, 1))).astype(np.float32)
+            v[:, :, 2] = (s["campos"][2] + (v[:, :, 2] - s["campos"][2]) * scale[:, :, 0])
+        return s
+
+    cases = [(12289, "plain"), (20000, "culled"), (93000, "plain"), (93000, "quantised"), (150000, "one_depth"), (300000, "background"), (300000, "octaves"),
+             (1000003, "plain"), (1600000, "quantised")]
+    for P, kind in cases:
+        s = bend(synthetic.scene(P, 320, 200, 1, seed=700 + P % 97), kind)
+        got = {}
+        for form, (mode, cap) in {"split": (2, 0), "lsd": (1, 0), "split_cap512": (2, 512)}.items():  # 2: the form at every size it supports (the product: to 500 000)
+            if form == "split_cap512" and P > 400000:
+                continue  # the global-memory path on a million pairs is slow by design; the smaller scenes cover it
+            _C._lib.ts2d_lab_depth_split(mode, cap)
+            hf = helpers.hip_forward_backward(s, True, backward=False)
+            got[form] = (int(hf["num_rendered"]), helpers.hip_state(hf, s, "depth_perm").copy(), helpers.hip_state(hf, s, "point_offsets").copy(),
+                         helpers.hip_state(hf, s, "vals").copy() if hf["num_rendered"] > 0 else np.zeros(0, np.int32), hf["out_feature"].copy())
+        _C._lib.ts2d_lab_depth_split(0, 0)
+        a = got["lsd"]
+        e = {"P": P, "kind": kind, "num_rendered": a[0]}
+        for form in got:
+            if form == "lsd":
+                continue
+            b = got[form]
+            e[form] = float(a[0] != b[0] or not np.array_equal(a[1], b[1]) or not np.array_equal(a[2], b[2]) or not np.array_equal(a[3], b[3])
+                            or not np.array_equal(a[4], b[4]))
+        out.append(e)
+    print("LAB_RESULT " + json.dumps(out))
+    sys.exit(0)
 if os.environ.get("LAB_SIDE_STREAM") == "1":
     # Round 6's side-stream experiment (lab library only; csrc/api.hip: SideLane): the per-triangle kernel without the SH colours + a colour kernel
     # on a library-owned stream beside the ordering chain.  Same scene with it (ts2d_lab_side_stream) and without (the product's one launch):

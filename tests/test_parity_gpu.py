@@ -285,6 +285,25 @@ def test_one_launch_depth_order_equals_the_multi_launch_forms():
         assert (case["num_rendered"] == 0) == case["culled"], case
 
 
+def test_split_depth_order_equals_the_multi_launch_forms():
+    """Round 6: the sampled-splitter depth order (the product's path between 12 288 and 500 000 triangles; tested up to the 1.6 M it supports) against the LSD passes and against its own
+    global-memory path, on scenes that bend the buckets -- tests/lab_worker.py, LAB_DEPTH_SPLIT."""
+    import json
+    import subprocess
+    import sys
+    if not os.path.exists(LAB_LIB):
+        pytest.skip("tools/bin/libts2d_lab.so not built")
+    e = dict(os.environ, TS2D_LIBRARY_PATH=LAB_LIB, LAB_DEPTH_SPLIT="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab_worker.py")], env=e, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("LAB_RESULT ")][-1][len("LAB_RESULT "):])
+    assert len(res) == 9
+    for case in res:
+        assert case["split"] == 0.0 and case.get("split_cap512", 0.0) == 0.0, case
+        assert case["num_rendered"] > 0, case
+
+
 @pytest.mark.parametrize("P,W,H,D,variant,gamma", [
     (1_000_000, 1920, 1080, 3, 2, 1.0),   # bench.py headline
     (300_000, 800, 800, 3, 2, 1.0),       # BASELINE.json configs[1]

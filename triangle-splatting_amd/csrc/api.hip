@@ -1272,6 +1272,7 @@ void ts2d_lab_force_all_quadrants(int on) { g_lab_all_quadrants = on != 0; }
 void ts2d_lab_side_stream(int on) { g_lab_side_stream = on != 0; }
 void ts2d_lab_colour_blocks(int blocks) { g_lab_colour_blocks = blocks; }
 void ts2d_lab_force_depth_pass4(int on) { ts_force_depth_pass4(on != 0); }
+void ts2d_lab_depth_split(int mode, int bucket_cap) { ts_lab_depth_split(mode, bucket_cap); }
 #endif // TS2D_LAB
 
 void ts2d_profile_enable(int on)

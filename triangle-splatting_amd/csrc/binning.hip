@@ -1155,6 +1155,554 @@ __global__ void __launch_bounds__(64 * DS_WAVES) depth_order_small_kernel(int P,
         if (host_out) __hip_atomic_store(host_out, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
+
+// ---- mid-sized scenes: the depth order by SAMPLED SPLITTERS + per-bucket sorts in LDS (round 6) -------------------------------------------------
+// Above TS_DEPTH_SMALL_MAX triangles the LSD sort above is eight dependent launches (census histogram, four scatters, three histograms; the fourth
+// pair returns at once on most scenes) + the launch of the block sums: 57 us for 0.7 MB of pairs at 93 k triangles, 59 at 300 k, 75 at 1 M --
+// launch and load -> LDS -> store latency, not bytes.  Four launches instead:
+//   K0  depth_split_sample_kernel   4096 keys taken at equal index strides; workgroup b finds splitter b (the sample of rank 16 b + 15) by a radix select.
+//                                   (Splitters from a SAMPLE, not from the key range: the buckets hold P / 256 +- 25 % pairs whatever the depth
+//                                   distribution is -- a far background, an object that fills one octave -- where equal slices of the bit range
+//                                   would put most of the scene into a few of them.)
+//   K1  depth_split_hist_kernel     bucket(key) = number of splitters below the key (8-step search in LDS) -> a byte per key, the chunk's bucket
+//                                   counts (table + per-slab totals, like rs_hist_direct_kernel), the chunk's part of N
+//   K2  depth_split_scatter_kernel  the stable scatter of rs_scatter_body<IDENTITY, DIRECT> on those bytes: (key, id) pairs bucket by bucket in
+//                                   sk[0] / sv[0]; chunk 0 leaves the 256 bucket starts and publishes N (device word + pinned host word)
+//   K3  depth_bucket_sort_kernel    one workgroup per bucket (4 waves below 300 k triangles, 16 above): its pairs in registers, a stable LSD sort in
+//                                   LDS on the bits of (key - smallest visible key of the bucket) that vary inside the bucket (13 of them = two
+//                                   passes, 8 + 5 ballots, where the full key needs three or four of 8), then what gather_blocksum_kernel did:
+//                                   tiles_sorted and the raw block sums (64-bit atomics; the sums were cleared by K0).
+// bucket() is monotone in the key and K2 is stable, K3 is a stable sort by the full key inside a bucket: sk[1] / sv[1] hold exactly the (key, id)
+// order of the LSD passes -- checked form against form in tests/test_parity_gpu.py::test_split_depth_order_equals_the_multi_launch_forms.  A bucket
+// larger than K3's registers (16 384 pairs: many equal or nearly equal depths) is sorted by the same workgroup through global memory, tile by tile --
+// slow, correct.
+// Measured against the LSD passes alternating on one box (profiles/r06_depth_split.txt): 93 k triangles 57 -> 43 us (step 0.335 -> 0.321 ms), 300 k
+// 59 -> 47 (0.613 -> 0.605), 1 M 75 -> 65 us of kernels and NO difference in the step (the largest bucket holds 7 500 pairs = 8 steps x 2 passes of
+// a ranking that is issue-bound with 16 waves on the compute unit: K3 takes 35 us there) -- hence the switch-over below.
+constexpr int TS_DEPTH_SPLIT_MAX = 500000;       // the product's switch-over: measured level with the LSD passes at 1 M triangles, ahead below
+constexpr int TS_DEPTH_SPLIT_HARD_MAX = 1600000; // what the form supports (buckets of P / 256 pairs on average against DB_CAP = 16384): lab library, mode 2
+constexpr int DSPL_SAMPLES = 4096, DSPL_PER = DSPL_SAMPLES / NB;
+constexpr int DB_WAVES = 16, DB_KB = 16, DB_CAP = 64 * DB_WAVES * DB_KB; // the large form of depth_bucket_sort_kernel
+constexpr int DB_SMALL_WAVES = 4, DB_SMALL_BELOW = 300000; // below: buckets of P / 256 < 1200 pairs on average against 4096
+int g_depth_split_mode = 0; // lab library: 0 = by size, 1 = never (the LSD passes), 2 = up to TS_DEPTH_SPLIT_HARD_MAX
+int g_depth_bucket_cap = DB_CAP; // lab library: a smaller register capacity sends ordinary buckets through K3's global-memory path
+
+struct DepthSplit
+{
+    uint32_t *splitters;           // 256 words: splitter b, b < 255; [255] = ~0
+    uint32_t *bucket_start;        // 256 words
+    unsigned long long *chunk_sum; // per chunk: sum of tiles_touched
+    uint8_t *digit;                // P bytes (lives in sv[1] until K3 overwrites it)
+    uint32_t *ticket;              // zero between steps
+};
+__host__ __device__ inline DepthSplit depth_split_of(const GeometryStateView &g)
+{
+    // scratch inside the state: `offsets` is written by scan_emit_kernel, after K3 (P > TS_DEPTH_SMALL_MAX words: room for 1024 + 2 chunks)
+    DepthSplit d;
+    d.splitters = g.offsets;
+    d.bucket_start = g.offsets + NB;
+    d.chunk_sum = (unsigned long long *)(g.offsets + 1024);
+    d.digit = (uint8_t *)g.sv[1];
+    d.ticket = g.rs.tickets + g.rs.slabs + 5; // TS_RS_TICKET_EXTRA words behind the slab tickets: [4] = top_const, [5] = this
+    return d;
+}
+
+// Depth keys are positive floats' bit patterns, and 0 for culled triangles.  Inside K0 and K3 the keys are taken relative to the smallest VISIBLE key
+// (monotone; culled stay 0): the bytes that all visible keys share -- and that 0 does not -- then cost no pass.
+__device__ __forceinline__ uint32_t depth_key_adjust(uint32_t key, uint32_t kmin_visible) { return key ? key - kmin_visible + 1u : 0u; }
+__device__ __forceinline__ uint32_t depth_key_restore(uint32_t adj, uint32_t kmin_visible) { return adj ? adj - 1u + kmin_visible : 0u; }
+
+// K0: workgroup b finds splitter b = the sample of rank DSPL_PER b + DSPL_PER - 1 by a radix SELECT over the samples it holds in registers
+// (most-significant-digit passes: histogram of the candidates' digit in LDS, scan, the digit whose run holds the rank) -- 255 independent
+// workgroups on an otherwise idle chip.  The select runs on (sample - smallest sample) and only over the bytes the samples' range needs: depth keys
+// share their top bytes, and a pass on a byte that every sample shares is 4096 atomic adds on ONE LDS word (the same select over all four bytes
+// of the raw keys: 12 us; one workgroup sorting the samples with a bitonic network: 13; eight workgroups ranking them by counting: 53).
+__global__ void __launch_bounds__(256) depth_split_sample_kernel(int P, GeometryStateView g, DepthSplit ds)
+{
+    __shared__ uint32_t hist[NB], wtot[4], pick[2], rmin[4], rmax[4];
+    constexpr int K = DSPL_SAMPLES / 256;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const uint32_t *keys = (const uint32_t *)g.depth;
+    const int nblocks = (P + SB - 1) / SB;
+    for (int i = blockIdx.x * 256 + t; i < nblocks; i += gridDim.x * 256) g.blocksum[i] = 0ull; // K3 adds into them
+    uint32_t smp[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) smp[k] = keys[(int)(((unsigned long long)(t + 256 * k) * (unsigned long long)P) / DSPL_SAMPLES)];
+    // culled triangles carry key 0: they stay 0, the visible ones become key - (smallest visible key) + 1 (monotone)
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u;
+#pragma unroll
+    for (int k = 0; k < K; k++) { kmin = min(kmin, smp[k] ? smp[k] : 0xFFFFFFFFu); kmax = max(kmax, smp[k]); }
+    for (int o = 32; o > 0; o >>= 1) { kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o)); }
+    if (lane == 0) { rmin[wave] = kmin; rmax[wave] = kmax; }
+    __syncthreads();
+    kmin = min(min(rmin[0], rmin[1]), min(rmin[2], rmin[3]));
+    kmax = max(max(rmax[0], rmax[1]), max(rmax[2], rmax[3]));
+    const uint32_t range = kmax ? kmax - kmin + 1u : 0u; // of the adjusted samples (no visible sample: all 0)
+    const int top = range == 0u ? -8 : 8 * ((31 - __clz((int)range)) / 8); // shift of the highest byte in which two samples differ
+#pragma unroll
+    for (int k = 0; k < K; k++) smp[k] = depth_key_adjust(smp[k], kmin);
+    uint32_t r = (uint32_t)(DSPL_PER * blockIdx.x + DSPL_PER - 1), prefix = 0u, mask = 0u;
+#pragma unroll 1
+    for (int shift = top; shift >= 0; shift -= 8)
+    {
+        hist[t] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < K; k++)
+            if ((smp[k] & mask) == prefix) atomicAdd(&hist[(smp[k] >> shift) & 0xFFu], 1u);
+        __syncthreads();
+        const uint32_t c = hist[t];
+        const uint32_t inc = wave_inclusive_scan(c, lane);
+        if (lane == 63) wtot[wave] = inc;
+        __syncthreads();
+        uint32_t excl = inc - c;
+        for (int w = 0; w < wave; w++) excl += wtot[w];
+        if (excl <= r && r < excl + c) { pick[0] = (uint32_t)t; pick[1] = r - excl; } // exactly one digit's run holds the rank
+        __syncthreads();
+        prefix |= pick[0] << shift;
+        mask |= 0xFFu << shift;
+        r = pick[1];
+    }
+    if (t == 0) ds.splitters[blockIdx.x] = depth_key_restore(prefix, kmin);
+    if (blockIdx.x == 0 && t == 1) ds.splitters[NB - 1] = 0xFFFFFFFFu;
+}
+
+// number of splitters below the key: the first index whose splitter is >= key (sp[255] = ~0 stops every search)
+__device__ __forceinline__ uint32_t depth_bucket_of(const uint32_t *sp, uint32_t key)
+{
+    uint32_t lo = 0u;
+#pragma unroll
+    for (int step = NB / 2; step > 0; step >>= 1)
+        lo += (sp[lo + step - 1] < key) ? step : 0u;
+    return lo;
+}
+
+template <int CH>
+__global__ void __launch_bounds__(256) depth_split_hist_kernel(int64_t n, GeometryStateView g, RadixScratchView r, uint32_t *__restrict__ acc, DepthSplit ds)
+{
+    __shared__ uint32_t bins[NB], sp[NB];
+    __shared__ unsigned long long csum[4];
+    const int t = threadIdx.x, chunk = rs_chunk_of_block(r.chunks);
+    if (chunk < 0) return;
+    bins[t] = 0u;
+    sp[t] = ds.splitters[t];
+    __syncthreads();
+    const uint32_t *keys = (const uint32_t *)g.depth;
+    const int64_t base = (int64_t)chunk * CH;
+    unsigned long long tsum = 0;
+#pragma unroll
+    for (int b = 0; b < CH / 256; b++)
+    {
+        const int64_t i = base + 256 * b + t;
+        if (i < n)
+        {
+            const uint32_t d = depth_bucket_of(sp, keys[i]);
+            ds.digit[i] = (uint8_t)d;
+            atomicAdd(&bins[d], 1u);
+            tsum += g.tiles_touched[i];
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) tsum += __shfl_xor(tsum, o);
+    if ((t & 63) == 0) csum[t >> 6] = tsum;
+    __syncthreads();
+    const uint32_t c = bins[t];
+    r.table[(size_t)chunk * NB + t] = c;
+    if (c) __hip_atomic_fetch_add(acc + (size_t)(chunk >> 6) * NB + t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0) ds.chunk_sum[chunk] = csum[0] + csum[1] + csum[2] + csum[3];
+}
+
+// rs_scatter_body<IDENTITY_VALUES, CH, DIRECT> with the digit read from K1's byte array (and parked in LDS beside the pair, for the way out)
+template <int CH>
+__global__ void __launch_bounds__(256) depth_split_scatter_kernel(int64_t n, GeometryStateView g, RadixScratchView r, const uint32_t *__restrict__ acc, DepthSplit ds,
+                                                                   unsigned long long *host_out)
+{
+    constexpr int KB = CH / 256;
+    constexpr int SK = CH < 8 * NB ? 8 * NB : CH, SV = CH < 4 * NB ? 4 * NB : CH;
+    __shared__ __attribute__((aligned(16))) uint32_t stage_k[SK], stage_v[SV];
+    __shared__ uint8_t stage_d[CH];
+    __shared__ uint32_t wcnt[4][NB];
+    __shared__ int32_t gdelta[NB];
+    __shared__ uint32_t wtot[4], gtot[4];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int chunk = rs_chunk_of_block(r.chunks);
+    if (chunk < 0) return;
+    const uint32_t *kin = (const uint32_t *)g.depth;
+    const int64_t base = (int64_t)chunk * CH + (int64_t)wave * (CH / 4);
+    const int64_t here = n - base;
+    const int mine = here >= CH / 4 ? CH / 4 : (here > 0 ? (int)here : 0);
+    uint32_t key[KB], dg[KB], rk[KB];
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+    {
+        const int i = 64 * b + lane;
+        key[b] = 0xFFFFFFFFu;
+        dg[b] = 0u;
+        if (i < mine) { key[b] = kin[base + i]; dg[b] = ds.digit[base + i]; }
+    }
+    uint4 p_within = make_uint4(0u, 0u, 0u, 0u), p_before = p_within, p_total = p_within;
+    {
+        const int slab = chunk >> 6, c0 = slab * 64;
+        const uint4 *tab4 = (const uint4 *)r.table + (size_t)c0 * (NB / 4) + lane;
+        const uint4 *acc4 = (const uint4 *)acc + lane;
+#pragma unroll 4
+        for (int k = 0; k < 16; k++)
+        {
+            const int c = wave + 4 * k;
+            if (c0 + c < chunk)
+            {
+                const uint4 v = tab4[(size_t)c * (NB / 4)];
+                p_within.x += v.x; p_within.y += v.y; p_within.z += v.z; p_within.w += v.w;
+            }
+        }
+#pragma unroll 4
+        for (int k = 0; k < TS_DIRECT_MAX_SLABS / 4; k++)
+        {
+            const int sl = wave + 4 * k;
+            if (sl < r.slabs)
+            {
+                const uint4 v = acc4[(size_t)sl * (NB / 4)];
+                p_total.x += v.x; p_total.y += v.y; p_total.z += v.z; p_total.w += v.w;
+                if (sl < slab) { p_before.x += v.x; p_before.y += v.y; p_before.z += v.z; p_before.w += v.w; }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NB / 64; k++) wcnt[wave][lane + 64 * k] = 0u;
+    wave_lds_order();
+    uint32_t *cnt = wcnt[wave];
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+    {
+        const bool valid = 64 * b + lane < mine;
+        const uint32_t d = dg[b];
+        const unsigned long long vm = ballot64(valid);
+        uint32_t mis_lo = ~(uint32_t)vm, mis_hi = ~(uint32_t)(vm >> 32);
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++)
+        {
+            const unsigned long long bb = ballot64((d >> bit) & 1u);
+            const uint32_t e = 0u - ((d >> bit) & 1u);
+            mis_lo |= (uint32_t)bb ^ e;
+            mis_hi |= (uint32_t)(bb >> 32) ^ e;
+        }
+        const uint32_t m_lo = ~mis_lo, m_hi = ~mis_hi;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        const uint32_t c = (uint32_t)(__popc(m_lo) + __popc(m_hi));
+        uint32_t seen = 0;
+        if (valid) seen = cnt[d];
+        wave_lds_order();
+        if (valid && rank == c - 1u) cnt[d] = seen + c;
+        wave_lds_order();
+        rk[b] = seen + rank;
+    }
+    *(uint4 *)(stage_k + wave * NB + 4 * lane) = p_within;
+    *(uint4 *)(stage_k + (4 + wave) * NB + 4 * lane) = p_before;
+    *(uint4 *)(stage_v + wave * NB + 4 * lane) = p_total;
+    __syncthreads();
+    {
+        uint32_t d_within = 0u, d_before = 0u, d_total = 0u; // thread t = bucket t
+#pragma unroll
+        for (int w = 0; w < 4; w++)
+        {
+            d_within += stage_k[w * NB + t];
+            d_before += stage_k[(4 + w) * NB + t];
+            d_total += stage_v[w * NB + t];
+        }
+        const uint32_t c0 = wcnt[0][t], c1 = wcnt[1][t], c2 = wcnt[2][t], c3 = wcnt[3][t];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        const uint32_t inc = wave_inclusive_scan(tot, lane);
+        if (lane == 63) wtot[wave] = inc;
+        const uint32_t ginc = wave_inclusive_scan(d_total, lane);
+        if (lane == 63) gtot[wave] = ginc;
+        __syncthreads();
+        uint32_t dbase = inc - tot, gbase = ginc - d_total;
+        for (int w = 0; w < wave; w++) { dbase += wtot[w]; gbase += gtot[w]; }
+        wcnt[0][t] = dbase; wcnt[1][t] = dbase + c0; wcnt[2][t] = dbase + c0 + c1; wcnt[3][t] = dbase + c0 + c1 + c2;
+        gdelta[t] = (int32_t)(gbase + d_before + d_within - dbase);
+        if (chunk == 0) ds.bucket_start[t] = gbase; // where bucket t begins in sk[0] / sv[0]
+    }
+    __syncthreads();
+    const int64_t left = n - (int64_t)chunk * CH;
+    const int count = left < CH ? (int)left : CH;
+#pragma unroll
+    for (int b = 0; b < KB; b++)
+        if (64 * b + lane < mine)
+        {
+            const uint32_t p = wcnt[wave][dg[b]] + rk[b];
+            stage_k[p] = key[b];
+            stage_v[p] = (uint32_t)(base + 64 * b + lane);
+            stage_d[p] = (uint8_t)dg[b];
+        }
+    __syncthreads();
+    for (int p = t; p < count; p += 256)
+    {
+        const int64_t dst = (int64_t)gdelta[stage_d[p]] + p;
+        g.sk[0][dst] = stage_k[p];
+        g.sv[0][dst] = stage_v[p];
+    }
+    if (chunk == 0) // N = the chunks' sums of K1: to the device word the scan reads and to the pinned host word (publish_census of the LSD form)
+    {
+        __shared__ unsigned long long psum[4];
+        unsigned long long sum = 0;
+        for (int c = t; c < r.chunks; c += 256) sum += ds.chunk_sum[c];
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (lane == 0) psum[wave] = sum;
+        __syncthreads();
+        if (t == 0)
+        {
+            const unsigned long long N = psum[0] + psum[1] + psum[2] + psum[3];
+            g.blocksum[((int)n + SB - 1) / SB] = N; // behind the block sums K3 adds up (= DepthCensus::n_out)
+            *g.top_const = 0u;                      // the order is always in sk[1] / sv[1]
+            if (host_out) __hip_atomic_store(host_out, N, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// One stable LSD pass of a 16-wave workgroup over the `mine` pairs each wave holds in registers (wave w: positions [w per, w per + mine) of the
+// tile, 64 consecutive ones per step), on digit (key - kmin) >> shift: the ranking of depth_order_small_kernel.  Leaves, for every pair, its
+// position among the tile's pairs in (digit, wave, step, lane) order in rk[], and the tile's digit counts in tile_cnt (thread d < 256: digit d).
+template <int KBX, int W>
+__device__ __forceinline__ void bucket_rank_pass(const uint32_t (&key)[KBX], uint32_t (&rk)[KBX], uint32_t kmin, int shift, int nbits, int per, int mine,
+                                                 uint32_t (*wcnt)[NB], uint32_t *wtot, uint32_t &tile_cnt)
+{
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    uint32_t *cnt = wcnt[wave];
+#pragma unroll
+    for (int k = 0; k < NB / 64; k++) cnt[lane + 64 * k] = 0u;
+    wave_lds_order();
+#pragma unroll
+    for (int b = 0; b < KBX; b++)
+    {
+        if (64 * b >= per) continue; // wave-uniform
+        const bool valid = 64 * b + lane < mine;
+        const uint32_t d = ((key[b] - kmin) >> shift) & 0xFFu;
+        const unsigned long long vm = ballot64(valid);
+        uint32_t mis_lo = ~(uint32_t)vm, mis_hi = ~(uint32_t)(vm >> 32);
+        for (int bit = 0; bit < nbits; bit++) // the digit's bits above nbits are zero in every key of the bucket
+        {
+            const unsigned long long bb = ballot64((d >> bit) & 1u);
+            const uint32_t e = 0u - ((d >> bit) & 1u);
+            mis_lo |= (uint32_t)bb ^ e;
+            mis_hi |= (uint32_t)(bb >> 32) ^ e;
+        }
+        const uint32_t m_lo = ~mis_lo, m_hi = ~mis_hi;
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi(m_hi, __builtin_amdgcn_mbcnt_lo(m_lo, 0u));
+        const uint32_t c = (uint32_t)(__popc(m_lo) + __popc(m_hi));
+        uint32_t seen = 0;
+        if (valid) seen = cnt[d];
+        wave_lds_order();
+        if (valid && rank == c - 1u) cnt[d] = seen + c;
+        wave_lds_order();
+        rk[b] = seen + rank;
+    }
+    __syncthreads();
+    uint32_t c[W], tot = 0u, inc = 0u;
+    if (t < NB) // thread d = digit d
+    {
+#pragma unroll
+        for (int w = 0; w < W; w++) { c[w] = wcnt[w][t]; tot += c[w]; }
+        inc = wave_inclusive_scan(tot, lane);
+        if (lane == 63) wtot[wave] = inc;
+    }
+    __syncthreads();
+    if (t < NB)
+    {
+        uint32_t run = inc - tot;
+        for (int w = 0; w < wave; w++) run += wtot[w];
+#pragma unroll
+        for (int w = 0; w < W; w++) { wcnt[w][t] = run; run += c[w]; }
+    }
+    tile_cnt = tot;
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < KBX; b++)
+        if (64 * b + lane < mine) rk[b] += cnt[((key[b] - kmin) >> shift) & 0xFFu];
+}
+
+// What gather_blocksum_kernel does, for 64 consecutive depth-order positions (first one `pos0`, this lane's `pos`): the tile counts in depth order
+// and their sums per scan block -- 64 consecutive positions meet at most two blocks; the sums were cleared by K0.
+__device__ __forceinline__ void bucket_emit_tiles(const GeometryStateView &g, int pos0, int pos, bool in, uint32_t tt, int lane)
+{
+    if (in) g.tiles_sorted[pos] = tt;
+    const int blk0 = pos0 / SB;
+    // tile counts are < 2^32 each, the sum of 64 of them may not be
+    unsigned long long a = (in && pos / SB == blk0) ? (unsigned long long)tt : 0ull, b = (in && pos / SB != blk0) ? (unsigned long long)tt : 0ull;
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if (lane == 0)
+    {
+        if (a) __hip_atomic_fetch_add((unsigned long long *)g.blocksum + blk0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (b) __hip_atomic_fetch_add((unsigned long long *)g.blocksum + blk0 + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+static_assert(2 * DB_CAP * 4 + DB_WAVES * NB * 4 + 1024 <= 160 * 1024 - 8 * 1024, "depth_bucket_sort_kernel: static LDS must leave 8 KB of the 160 KB");
+// W waves per workgroup: 16 (64 KB + 64 KB of staging, one workgroup per compute unit) for buckets of thousands of pairs, 4 for the buckets of a
+// few hundred that scenes below DB_SMALL_BELOW triangles have (a barrier among four waves, four columns per digit in the scan)
+template <int W>
+__global__ void __launch_bounds__(64 * W) depth_bucket_sort_kernel(int P, GeometryStateView g, DepthSplit ds, int cap)
+{
+    constexpr int DB_WAVES = W, DB_CAP = 64 * W * DB_KB;
+    __shared__ __attribute__((aligned(16))) uint32_t stage_k[DB_CAP], stage_v[DB_CAP];
+    __shared__ uint32_t wcnt[DB_WAVES][NB];
+    __shared__ uint32_t wtot[4], rmin[DB_WAVES], rmax[DB_WAVES], dstart[NB];
+    const int t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const int bucket = blockIdx.x;
+    const int s0 = (int)ds.bucket_start[bucket], e0 = bucket + 1 < NB ? (int)ds.bucket_start[bucket + 1] : P;
+    const int n = e0 - s0;
+    if (n <= 0) return;
+    const bool fits = n <= cap;
+    // the whole bucket in registers when it fits (wave w: `per` consecutive positions, 64 per step); the key range either way
+    const int per = ((n + 64 * DB_WAVES - 1) / (64 * DB_WAVES)) * 64;
+    const int base = wave * per;
+    const int mine = !fits ? 0 : (n - base < per ? (n - base > 0 ? n - base : 0) : per);
+    uint32_t key[DB_KB], val[DB_KB], rk[DB_KB];
+    uint32_t kmin = 0xFFFFFFFFu, kmax = 0u; // kmin: over the VISIBLE keys (depth_key_adjust)
+    if (fits)
+    {
+        // branch-free loads (a lane past the end reads the bucket's first pair): all of a wave's steps are in flight together.  (With the loads under
+        // `in ? load : constant` and the minimum taken in the same loop, every step waited for its predecessor: ten round trips in a row.)
+#pragma unroll
+        for (int b = 0; b < DB_KB; b++)
+        {
+            if (64 * b >= per) { key[b] = 0xFFFFFFFFu; val[b] = 0u; continue; } // wave-uniform
+            const int i = 64 * b + lane;
+            const int src = s0 + (i < mine ? base + i : 0);
+            key[b] = g.sk[0][src];
+            val[b] = g.sv[0][src];
+        }
+#pragma unroll
+        for (int b = 0; b < DB_KB; b++)
+        {
+            const bool in = 64 * b + lane < mine;
+            kmin = min(kmin, in && key[b] ? key[b] : 0xFFFFFFFFu);
+            kmax = max(kmax, in ? key[b] : 0u);
+        }
+    }
+    else
+        for (int i = t; i < n; i += 64 * DB_WAVES)
+        {
+            const uint32_t k = g.sk[0][s0 + i];
+            kmin = min(kmin, k ? k : 0xFFFFFFFFu);
+            kmax = max(kmax, k);
+        }
+    for (int o = 32; o > 0; o >>= 1) { kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, o)); kmax = max(kmax, (uint32_t)__shfl_xor((int)kmax, o)); }
+    if (lane == 0) { rmin[wave] = kmin; rmax[wave] = kmax; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < DB_WAVES; w++) { kmin = min(kmin, rmin[w]); kmax = max(kmax, rmax[w]); }
+    // sorted on the adjusted keys (culled 0, visible key - kmin + 1): `range` = the largest of them
+    const uint32_t range = kmax ? kmax - kmin + 1u : 0u;
+    const int kbits = range == 0u ? 0 : 32 - __clz((int)range), passes = (kbits + 7) / 8; // the bits that vary inside the bucket
+    if (fits)
+    {
+#pragma unroll
+        for (int b = 0; b < DB_KB; b++) key[b] = 64 * b + lane < mine ? depth_key_adjust(key[b], kmin) : 0xFFFFFFFFu;
+    }
+    if (fits)
+    {
+        // after every pass the pairs change owners through LDS
+#pragma nounroll
+        for (int pass = 0; pass < passes; pass++)
+        {
+            uint32_t unused;
+            bucket_rank_pass<DB_KB, W>(key, rk, 0u, 8 * pass, min(8, kbits - 8 * pass), per, mine, wcnt, wtot, unused);
+#pragma unroll
+            for (int b = 0; b < DB_KB; b++)
+                if (64 * b + lane < mine) { stage_k[rk[b]] = key[b]; stage_v[rk[b]] = val[b]; }
+            __syncthreads();
+#pragma unroll
+            for (int b = 0; b < DB_KB; b++)
+                if (64 * b < per) { key[b] = stage_k[base + 64 * b + lane]; val[b] = stage_v[base + 64 * b + lane]; }
+            __syncthreads();
+        }
+        // the tile counts of all steps are requested before any of them is used: one gather latency per wave, not one per step
+#pragma unroll
+        for (int b = 0; b < DB_KB; b++)
+        {
+            if (64 * b >= per) continue;
+            const bool in = 64 * b + lane < mine;
+            const int pos = s0 + base + 64 * b + lane;
+            if (in) { g.sk[1][pos] = depth_key_restore(key[b], kmin); g.sv[1][pos] = val[b]; }
+            rk[b] = g.tiles_touched[in ? val[b] : 0u]; // branch-free, like the loads above
+        }
+#pragma unroll
+        for (int b = 0; b < DB_KB; b++)
+        {
+            if (64 * b >= per) continue;
+            bucket_emit_tiles(g, s0 + base + 64 * b, s0 + base + 64 * b + lane, 64 * b + lane < mine, 64 * b + lane < mine ? rk[b] : 0u, lane);
+        }
+    }
+    else
+    {
+        // larger than the registers: the same passes through global memory, tile after tile, between (sk[0], sv[0]) and (sk[1], sv[1]) of this
+        // bucket's range (nobody else touches it); an odd number of passes ends in [1], an even one -- and a bucket of equal keys -- is copied
+        const int tile = (cap & ~(64 * DB_WAVES - 1)) ? (cap & ~(64 * DB_WAVES - 1)) : 64 * DB_WAVES; // pairs per tile: whole 64-pair steps per wave
+        int src = 0;
+        for (int pass = 0; pass < passes; pass++, src ^= 1)
+        {
+            const uint32_t *kin = g.sk[src] + s0, *vin = g.sv[src] + s0;
+            uint32_t *kout = g.sk[src ^ 1] + s0, *vout = g.sv[src ^ 1] + s0;
+            if (t < NB) dstart[t] = 0u;
+            __syncthreads();
+            for (int i = t; i < n; i += 64 * DB_WAVES) atomicAdd(&dstart[(depth_key_adjust(peer_load(kin + i), kmin) >> (8 * pass)) & 0xFFu], 1u);
+            __syncthreads();
+            {
+                uint32_t tot = 0u, inc = 0u;
+                if (t < NB) { tot = dstart[t]; inc = wave_inclusive_scan(tot, lane); if (lane == 63) wtot[wave] = inc; }
+                __syncthreads();
+                if (t < NB)
+                {
+                    uint32_t run = inc - tot;
+                    for (int w = 0; w < wave; w++) run += wtot[w];
+                    dstart[t] = run; // where digit t begins in the bucket
+                }
+                __syncthreads();
+            }
+            for (int t0 = 0; t0 < n; t0 += tile)
+            {
+                const int nt = n - t0 < tile ? n - t0 : tile;
+                const int tper = ((nt + 64 * DB_WAVES - 1) / (64 * DB_WAVES)) * 64;
+                const int tbase = wave * tper;
+                const int tmine = nt - tbase < tper ? (nt - tbase > 0 ? nt - tbase : 0) : tper;
+#pragma unroll
+                for (int b = 0; b < DB_KB; b++)
+                {
+                    const int i = 64 * b + lane;
+                    const bool in = i < tmine;
+                    key[b] = in ? depth_key_adjust(peer_load(kin + t0 + tbase + i), kmin) : 0xFFFFFFFFu; // past this compute unit's L1: an earlier pass of this workgroup wrote them
+                    val[b] = in ? peer_load(vin + t0 + tbase + i) : 0u;
+                }
+                uint32_t tile_cnt;
+                bucket_rank_pass<DB_KB, W>(key, rk, 0u, 8 * pass, min(8, kbits - 8 * pass), tper, tmine, wcnt, wtot, tile_cnt);
+                // rk = position inside the tile's (digit, order) arrangement; the digit's pairs of this tile go behind the earlier tiles' ones:
+                // global position = dstart[d] + (rk - start of d inside the tile) = dstart[d] + rk - wcnt[0][d]
+#pragma unroll
+                for (int b = 0; b < DB_KB; b++)
+                    if (64 * b + lane < tmine)
+                    {
+                        const uint32_t d = (key[b] >> (8 * pass)) & 0xFFu;
+                        const uint32_t p = dstart[d] + rk[b] - wcnt[0][d];
+                        peer_store(kout + p, depth_key_restore(key[b], kmin));
+                        peer_store(vout + p, val[b]);
+                    }
+                __syncthreads();
+                if (t < NB) dstart[t] += tile_cnt;
+                __syncthreads();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the next pass of this workgroup reads what other waves of it wrote to global memory
+            __syncthreads();
+        }
+        if (src == 0)
+            for (int i = t; i < n; i += 64 * DB_WAVES) { peer_store(g.sk[1] + s0 + i, peer_load(g.sk[0] + s0 + i)); peer_store(g.sv[1] + s0 + i, peer_load(g.sv[0] + s0 + i)); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int i0 = 64 * wave; i0 < n; i0 += 64 * DB_WAVES)
+        {
+            const bool in = i0 + lane < n;
+            bucket_emit_tiles(g, s0 + i0, s0 + i0 + lane, in, in ? g.tiles_touched[peer_load(g.sv[1] + s0 + i0 + lane)] : 0u, lane);
+        }
+    }
+}
 } // namespace
 
 // Step 1: (depth bits, id) -> sorted ids.  Depth keys are view-space z of visible triangles (> 0, so the unsigned bit
@@ -1163,6 +1711,13 @@ __global__ void __launch_bounds__(64 * DS_WAVES) depth_order_small_kernel(int P,
 // launches (the 4th pass returns at once when the census found the top byte constant: then sk[0] / sv[0] hold the order).
 // The one-launch form (depth_order_small_kernel) -- never under the lab library's switches, which exist to run the multi-launch forms on small scenes.
 static bool depth_small_ok(int32_t P) { return P <= TS_DEPTH_SMALL_MAX && !g_force_tickets && !g_force_pass4; }
+// The sampled-splitter form: every size between the one-launch form and TS_DEPTH_SPLIT_MAX whose scratch takes the ticket-free passes; never under the
+// lab library's switches that ask for the LSD forms.
+static bool depth_split_ok(int32_t P, const RadixScratchView &r)
+{
+    return P > TS_DEPTH_SMALL_MAX && P <= (g_depth_split_mode == 2 ? TS_DEPTH_SPLIT_HARD_MAX : TS_DEPTH_SPLIT_MAX) && g_depth_split_mode != 1 && !g_force_tickets &&
+           !g_force_pass4 && radix_direct_ok(r);
+}
 void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s)
 {
     if (P <= 0) return;
@@ -1170,6 +1725,16 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
     {
         hipLaunchKernelGGL(depth_order_small_kernel, dim3(1), dim3(64 * DS_WAVES), 0, s, P, g, host_out);
         return;
+    }
+    if (depth_split_ok(P, g.rs))
+    {
+        const DepthSplit ds = depth_split_of(g);
+        const dim3 grid((unsigned)g.rs.chunks);
+        hipLaunchKernelGGL(depth_split_sample_kernel, dim3(NB - 1), dim3(256), 0, s, P, g, ds);
+        TS_WITH_CHUNK(g.rs.chunk,
+                      hipLaunchKernelGGL((depth_split_hist_kernel<CH>), grid, dim3(256), 0, s, (int64_t)P, g, g.rs, g.rs.slabacc[0], ds);
+                      hipLaunchKernelGGL((depth_split_scatter_kernel<CH>), grid, dim3(256), 0, s, (int64_t)P, g, g.rs, (const uint32_t *)g.rs.slabacc[0], ds, host_out))
+        return; // N is out; the buckets' sorts belong to `finish`
     }
     DepthCensus c;
     c.tiles_touched = g.tiles_touched;
@@ -1199,6 +1764,14 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
 void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
     if (P <= 0 || depth_small_ok(P)) return;
+    if (depth_split_ok(P, g.rs))
+    {
+        if (P < DB_SMALL_BELOW)
+            hipLaunchKernelGGL(depth_bucket_sort_kernel<DB_SMALL_WAVES>, dim3(NB), dim3(64 * DB_SMALL_WAVES), 0, s, P, g, depth_split_of(g),
+                               min(g_depth_bucket_cap, 64 * DB_SMALL_WAVES * DB_KB));
+        else hipLaunchKernelGGL(depth_bucket_sort_kernel<DB_WAVES>, dim3(NB), dim3(64 * DB_WAVES), 0, s, P, g, depth_split_of(g), g_depth_bucket_cap);
+        return;
+    }
     if (!radix_direct_ok(g.rs))
     {
         radix_scatter((const uint32_t *)g.depth, nullptr, g.sk[0], g.sv[0], P, nullptr, 0, 8, g.rs, s);
@@ -1217,7 +1790,7 @@ void ts_sort_by_depth_finish(const GeometryStateView &g, int32_t P, hipStream_t 
 static bool scan_two_level(int32_t P) { return g_force_tickets || (P + SB - 1) / SB > 2048; }
 void ts_scan_offsets(const GeometryStateView &g, int32_t P, hipStream_t s)
 {
-    if (P <= 0 || depth_small_ok(P)) return; // small scenes: depth_order_small_kernel left tiles_sorted and the block sums behind
+    if (P <= 0 || depth_small_ok(P) || depth_split_ok(P, g.rs)) return; // depth_order_small_kernel / depth_bucket_sort_kernel left tiles_sorted and the block sums behind
     hipLaunchKernelGGL(gather_blocksum_kernel, dim3((unsigned)((P + SB - 1) / SB)), dim3(256), 0, s, P, g, scan_two_level(P));
 }
 
@@ -1302,3 +1875,8 @@ void ts_launch_zero_words(uint32_t *p, size_t n, hipStream_t s) // n 32-bit word
     else hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n);
 }
 void ts_force_depth_pass4(bool on) { g_force_pass4 = on; }
+void ts_lab_depth_split(int mode, int bucket_cap)
+{
+    g_depth_split_mode = mode;
+    g_depth_bucket_cap = bucket_cap > 0 && bucket_cap < DB_CAP ? bucket_cap : DB_CAP;
+}

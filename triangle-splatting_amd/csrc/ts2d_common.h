@@ -270,6 +270,7 @@ size_t ts_radix_scratch_bytes(size_t n);                                        
 int ts_radix_sort_pairs(uint32_t *const k[2], uint32_t *const v[2], size_t n, int end_bit, void *scratch, hipStream_t s, bool force_tickets = false);
 void ts_force_ticket_passes(bool on); // lab library only (csrc/ts2d_lab.h): no exported entry point of the product library reaches it
 void ts_force_depth_pass4(bool on);   // likewise
+void ts_lab_depth_split(int mode, int bucket_cap); // mode 1: never the sampled-splitter depth order, 2: up to 1.6 M triangles; bucket_cap > 0: its per-bucket register capacity
 
 struct RenderArgs
 {
