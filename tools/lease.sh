@@ -37,6 +37,11 @@ abflag() { local n=$1 f=$2; shift 2; for i in $(seq $n); do
     TS2D_LIBRARY_PATH=$R/tools/bin/libts2d_lab.so bench abflag_off --no-cpu-baseline "$@"
     TS2D_LIBRARY_PATH=$R/tools/bin/libts2d_lab.so bench "abflag_${f#--}" --no-cpu-baseline $f "$@"; done; }
 
+# abprod <rounds> <flag> [bench.py args]: the PRODUCT library with and without one bench.py switch (e.g. --no-prepare-backward), alternating
+abprod() { local n=$1 f=$2; shift 2; for i in $(seq $n); do
+    bench abprod_off --no-cpu-baseline "$@"
+    bench "abprod_${f#--}" --no-cpu-baseline $f "$@"; done; }
+
 # prof <name> [bench.py args]: rocprofv3 kernel trace + stats of bench.py (no counters in this pass)
 prof() { local n=$1; shift; rm -rf $O/prof_$n; (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof_$n -o $n --output-format csv -- python $R/bench.py --no-cpu-baseline "$@" > $O/prof_$n.log 2>&1)
     f=$(find $O/prof_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${n}_kernel_stats.csv && head -25 $f
