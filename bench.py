@@ -116,8 +116,6 @@ def main():
                     help="NOT the headline metric: every step also runs the fused Adam step (diff_recon_hip.FusedAdam: vertex, opacity and the SH tensor "
                          "with the reference's f_dc / f_rest learning-rate split, one launch) on the step's gradients, with all learning rates 0 so that "
                          "the scene stays the one BASELINE.json names; reported as config.optimizer")
-    ap.add_argument("--no-prepare-backward", action="store_true", help="A/B: every backward clears its own gradient records (the form of rounds 1-5) instead of the "
-                    "forward's blend kernel clearing them on the side (TS2D_FLAG_PREPARE_BACKWARD)")
     ap.add_argument("--depth-lsd", action="store_true", help="lab library only: the LSD depth sort of rounds 2-5 at every size instead of the sampled-splitter "
                     "form (binning.hip: depth_split_*), for A/B runs")
     ap.add_argument("--force-depth-pass4", action="store_true",
@@ -189,9 +187,6 @@ def main():
         if not hasattr(_C._lib, "ts2d_lab_force_depth_pass4"):
             raise SystemExit("--force-depth-pass4 needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
         _C._lib.ts2d_lab_force_depth_pass4(1)
-    if args.no_prepare_backward:
-        import diff_triangle_rasterization_2D as _pkg
-        _pkg._prepare_backward = False
     if args.depth_lsd:
         if not hasattr(_C._lib, "ts2d_lab_depth_split"):
             raise SystemExit("--depth-lsd needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")

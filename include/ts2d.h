@@ -62,14 +62,6 @@ extern "C" {
                                        the clamp-masked colour gradient dL_dRGB (P*3) from which ts2d_sh_grad_expand
                                        rebuilds dL_dshs -- the multi-GPU exchange format (new; no reference counterpart) */
 
-#define TS2D_FLAG_PREPARE_BACKWARD 0x40u  /* forward entry points: a backward pass will follow -- the forward's blend kernel also clears the gradient
-                                             records (rasterizer.cu:290-300), which live in the geometry state; its stores ride along in a kernel that
-                                             leaves the memory system idle, and the backward's own clear launch (12 us at 1 M triangles, 7 us of pure
-                                             launch latency on small scenes) goes away (new; no reference counterpart) */
-#define TS2D_FLAG_BACKWARD_PREPARED 0x80u /* ts2d_backward*: THIS backward is the first one on a state whose forward ran with
-                                             TS2D_FLAG_PREPARE_BACKWARD: the records are clear, no clear launch.  A second backward on the same state
-                                             (retain_graph) must not pass it: the first one left its sums in the records */
-
 #define TS2D_MAX_CHANNELS 3 /* R2D/src/config.h:3 */
 #define TS2D_TILE 16        /* R2D/src/config.h:4-5 (BLOCK_X = BLOCK_Y = 16) */
 

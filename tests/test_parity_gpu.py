@@ -285,48 +285,6 @@ def test_one_launch_depth_order_equals_the_multi_launch_forms():
         assert (case["num_rendered"] == 0) == case["culled"], case
 
 
-@pytest.mark.parametrize("variant,rich,use_feature", [(2, True, False), (2, False, False), (3, True, False), (2, True, True)])
-def test_prepared_backward_equals_the_backward_that_clears_for_itself(variant, rich, use_feature):
-    """Round 6 (include/ts2d.h: TS2D_FLAG_PREPARE_BACKWARD / TS2D_FLAG_BACKWARD_PREPARED): the module's forward lets the blend kernel clear the
-    gradient records of the state on the side and its FIRST backward runs without a clear launch; a second backward on the same state
-    (retain_graph) clears its own records in its scratch like rasterizer.cu:290-300.  Same state, same upstream gradients, the two forms one after
-    the other: equal up to the order of the atomic adds; and the first one against the oracle."""
-    import torch
-    if variant == 3:
-        from diff_triangle_rasterization_3D import TriangleRasterizer
-    else:
-        from diff_triangle_rasterization_2D import TriangleRasterizer
-    s = synthetic.scene(7000, 176, 120, 2, seed=99)
-    if use_feature:
-        s["feature"] = np.random.default_rng(3).random((7000, 3), dtype=np.float32)
-    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    vertex, opacity = t(s["vertex"]).requires_grad_(), t(s["opacity"]).requires_grad_()
-    colour = t(s["feature"] if use_feature else s["shs"]).requires_grad_()
-    center2D = torch.zeros((7000, 2), device="cuda", requires_grad=True)
-    out = TriangleRasterizer(helpers.hip_settings(s, rich))(vertex, center2D, opacity, **({"feature": colour} if use_feature else {"shs": colour}))
-    node = out[0].grad_fn
-    loss = (out[0] * t(s["dL_dout_feature"])).sum()
-    if rich:
-        loss = loss + (out[2] * t(s["dL_dout_depth"])).sum() + (out[3] * t(s["dL_dout_normal"])).sum()
-    inputs = [vertex, center2D, opacity, colour]
-    assert node.records_prepared is True
-    first = torch.autograd.grad(loss, inputs, retain_graph=True)
-    assert node.records_prepared is False
-    second = torch.autograd.grad(loss, inputs)
-    for a, b, name in zip(first, second, ("vertex", "center2D", "opacity", "colour")):
-        assert float(b.abs().max()) > 0, name
-        assert helpers.rel_l2(a.cpu().numpy(), b.cpu().numpy()) < 2e-6, name
-    if variant == 2 and not use_feature:
-        of = helpers.oracle_forward(s, rich)
-        ob = helpers.oracle_backward(s, of, rich)
-        for g, k in zip(first, ("dL_dvertex", "dL_dcenter2D", "dL_dopacity", "dL_dshs")):
-            assert helpers.rel_l2(g.cpu().numpy().reshape(ob[k].shape), ob[k]) < GRAD_TOL, k
-    # no gradient asked for: nothing is prepared
-    with torch.no_grad():
-        ev = TriangleRasterizer(helpers.hip_settings(s, rich))(vertex, center2D, opacity, **({"feature": colour} if use_feature else {"shs": colour}))
-    assert torch.equal(ev[0], out[0].detach())
-
-
 def test_split_depth_order_equals_the_multi_launch_forms():
     """Round 6: the sampled-splitter depth order (the product's path between 12 288 and 500 000 triangles; tested up to the 1.6 M it supports) against the LSD passes and against its own
     global-memory path, on scenes that bend the buckets -- tests/lab_worker.py, LAB_DEPTH_SPLIT."""

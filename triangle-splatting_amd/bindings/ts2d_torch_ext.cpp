@@ -55,7 +55,7 @@ rasterizeTrianglesForwardEx(const int image_width, const int image_height, const
                             const float gamma, const float scale_modifier, const float background_depth, const torch::Tensor &background_,
                             const torch::Tensor &vertex_, const torch::Tensor &shs_, const torch::Tensor &feature_, const torch::Tensor &opacity_,
                             const bool back_culling, const bool rich_info, const bool debug, const int variant, const int64_t instance_capacity,
-                            const std::optional<torch::Tensor> &background_depth_dev, const bool prepare_backward)
+                            const std::optional<torch::Tensor> &background_depth_dev)
 {
     // R3D/src/extension_interface.cu:82-92 takes .contiguous() of every input where the 2D module raises
     const bool v3 = variant == 3;
@@ -103,8 +103,7 @@ rasterizeTrianglesForwardEx(const int image_width, const int image_height, const
         ts2d_geometry geom{P, sh_degree, s.M, s.C, gamma, scale_modifier, bg_dev ? 0.0f : background_depth, fptr(background), fptr(vertex),
                            s.use_shs ? fptr(shs) : nullptr, s.use_shs ? nullptr : fptr(feature), fptr(opacity), bg_dev};
         const uint32_t flags = (back_culling ? TS2D_FLAG_BACK_CULLING : 0u) | (rich_info ? TS2D_FLAG_RICH_INFO : 0u) |
-                               (debug ? TS2D_FLAG_DEBUG : 0u) | (s.use_shs ? TS2D_FLAG_USE_SHS : 0u) | (v3 ? TS2D_FLAG_3D : 0u) |
-                               (prepare_backward ? TS2D_FLAG_PREPARE_BACKWARD : 0u); // the blend kernel clears the gradient records of the state on the side
+                               (debug ? TS2D_FLAG_DEBUG : 0u) | (s.use_shs ? TS2D_FLAG_USE_SHS : 0u) | (v3 ? TS2D_FLAG_3D : 0u);
         geometryBuffer = torch::empty({(int64_t)ts2d_geometry_state_bytes(P)}, u8);
         imageBuffer = torch::empty({(int64_t)ts2d_image_state_bytes(W, H)}, u8);
         if (instance_capacity > 0) // sync-free forward: nothing is read back; num_rendered = the capacity (it sizes the state for the backward)
@@ -145,7 +144,7 @@ rasterizeTrianglesForward(const int image_width, const int image_height, const f
                           const bool back_culling, const bool rich_info, const bool debug)
 {
     auto r = rasterizeTrianglesForwardEx(image_width, image_height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
-                                         background_depth, background, vertex, shs, feature, opacity, back_culling, rich_info, debug, 2, 0, std::nullopt, false);
+                                         background_depth, background, vertex, shs, feature, opacity, back_culling, rich_info, debug, 2, 0, std::nullopt);
     return std::make_tuple((int)std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r), std::get<4>(r), std::get<5>(r), std::get<6>(r), std::get<7>(r),
                            std::get<8>(r), std::get<9>(r));
 }
@@ -164,7 +163,7 @@ rasterizeTrianglesBackwardEx(const float tan_fovx, const float tan_fovy, const t
                              const bool rich_info, const bool debug, const int variant, const bool sh_factored_,
                              const std::optional<torch::Tensor> &out_vertex, const std::optional<torch::Tensor> &out_center2D,
                              const std::optional<torch::Tensor> &out_color, const std::optional<torch::Tensor> &out_opacity,
-                             const std::optional<torch::Tensor> &background_depth_dev, const std::vector<int64_t> &range_events, const bool prepared)
+                             const std::optional<torch::Tensor> &background_depth_dev, const std::vector<int64_t> &range_events)
 {
     const bool v3 = variant == 3; // R3D/src/extension_interface.cu:186-206: .contiguous() instead of the 2D module's error
     const torch::Tensor viewmatrix = v3 ? viewmatrix_.contiguous() : viewmatrix_, projmatrix = v3 ? projmatrix_.contiguous() : projmatrix_;
@@ -211,12 +210,11 @@ rasterizeTrianglesBackwardEx(const float tan_fovx, const float tan_fovy, const t
         ts2d_geometry geom{P, sh_degree, s.M, s.C, gamma, scale_modifier, bg_dev ? 0.0f : background_depth, fptr(background), fptr(vertex),
                            s.use_shs ? fptr(shs) : nullptr, s.use_shs ? nullptr : fptr(feature), fptr(opacity), bg_dev};
         const uint32_t flags = (rich_info ? TS2D_FLAG_RICH_INFO : 0u) | (debug ? TS2D_FLAG_DEBUG : 0u) | (s.use_shs ? TS2D_FLAG_USE_SHS : 0u) |
-                               (v3 ? TS2D_FLAG_3D : 0u) | (sh_factored ? TS2D_FLAG_SH_FACTORED : 0u) |
-                               (prepared ? TS2D_FLAG_BACKWARD_PREPARED : 0u); // first backward behind a forward with TS2D_FLAG_PREPARE_BACKWARD: no clear launch
+                               (v3 ? TS2D_FLAG_3D : 0u) | (sh_factored ? TS2D_FLAG_SH_FACTORED : 0u);
         ts2d_state st{geometryBuffer.data_ptr(), (size_t)geometryBuffer.numel(), binningBuffer.numel() ? binningBuffer.data_ptr() : nullptr,
                       (size_t)binningBuffer.numel(), imageBuffer.data_ptr(), (size_t)imageBuffer.numel()};
         ts2d_loss_grads loss{fptr(dL_dout_feature), rich_info ? fptr(dL_dout_depth) : nullptr, rich_info ? fptr(dL_dout_normal) : nullptr};
-        torch::Tensor scratch = torch::empty({prepared ? (int64_t)0 : (int64_t)ts2d_backward_scratch_bytes(P)}, opts.dtype(torch::kByte)); // prepared: the records are in the state
+        torch::Tensor scratch = torch::empty({(int64_t)ts2d_backward_scratch_bytes(P)}, opts.dtype(torch::kByte));
         ts2d_backward_out bo{fptr_mut(dL_dvertex), fptr_mut(dL_dcenter2D), dL_dshs.defined() ? fptr_mut(dL_dshs) : nullptr, fptr_mut(dL_dfeature),
                              fptr_mut(dL_dopacity)};
         if (!range_events.empty())
@@ -247,7 +245,7 @@ rasterizeTrianglesBackward(const float tan_fovx, const float tan_fovy, const tor
 {
     auto r = rasterizeTrianglesBackwardEx(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier, background_depth, background, vertex,
                                           shs, feature, opacity, num_rendered, radii, geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
-                                          dL_dout_normal, rich_info, debug, 2, false, std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, {}, false);
+                                          dL_dout_normal, rich_info, debug, 2, false, std::nullopt, std::nullopt, std::nullopt, std::nullopt, std::nullopt, {});
     return std::make_tuple(std::get<0>(r), std::get<1>(r), *std::get<2>(r), std::get<3>(r), std::get<4>(r));
 }
 

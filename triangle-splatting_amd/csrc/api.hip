@@ -166,8 +166,6 @@ RenderArgs make_render(const ts2d_camera *cam, const ts2d_geometry *geom, uint32
     r.background = geom->background;
     r.rich_info = flags & TS2D_FLAG_RICH_INFO;
     r.ablate = r.bwd_mfma = r.legacy_blend = 0;
-    r.clear4 = nullptr;
-    r.clear4_count = 0;
 #ifdef TS2D_LAB
     // libts2d_lab.so only (tools/build_lab.py; never the product library): measurement / triage kernels selected by environment
     // variables, read ONCE per process.  TS2D_BLEND=wave: round 1's whole-quadrant kernels (render.hip, render3d.hip);
@@ -447,18 +445,9 @@ int forward_render_impl(const ts2d_camera *cam, const ts2d_geometry *geom, uint3
         if (!n_dev) ts_binning_set_count(b, N); // the host knows the count: no launch covers more than it
     }
     ts_carve_image((char *)state->image, W, H, im);
-    RenderArgs r = make_render(cam, geom, flags);
+    const RenderArgs r = make_render(cam, geom, flags);
     const int ntiles = r.grid_x * r.grid_y;
     if (n_dev) n_dev = ts_instance_count_dev(g, P);
-    // TS2D_FLAG_PREPARE_BACKWARD: the blend kernel clears the state's gradient records on the side (the lab library's other blend kernels do not
-    // know how: a launch of its own in front of them)
-    const bool prepare = (flags & TS2D_FLAG_PREPARE_BACKWARD) && P > 0;
-    bool prepared_by_blend = prepare && ntiles > 0;
-#ifdef TS2D_LAB
-    if (r.legacy_blend != 0) prepared_by_blend = false;
-#endif
-    if (prepared_by_blend) { r.clear4 = (float4 *)g.grad_rec; r.clear4_count = (size_t)P * (TS_GRAD_FLOATS / 4); }
-    else if (prepare) ts_launch_zero_words((uint32_t *)g.grad_rec, (size_t)TS_GRAD_FLOATS * (size_t)P, s);
 
     // tile ranges (rasterizer.cu:223) and the contribution statistics are cleared by the emission kernel, not by memsets
     if (P > 0)
@@ -721,8 +710,7 @@ int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint
     if (!out->dL_dvertex || !out->dL_dcenter2D || !out->dL_dfeature || !out->dL_dopacity || (use_shs && !factored && !out->dL_dshs))
         return fail(TS2D_ERR_INVALID, "gradient outputs are null");
     if (!radii) return fail(TS2D_ERR_INVALID, "radii is null");
-    if (!(flags & TS2D_FLAG_BACKWARD_PREPARED) && (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P)))
-        return fail(TS2D_ERR_CAPACITY, "backward scratch too small"); // (a prepared backward keeps its records in the state and needs none)
+    if (!scratch || scratch_bytes < ts2d_backward_scratch_bytes(P)) return fail(TS2D_ERR_CAPACITY, "backward scratch too small");
     if (!state->geometry || state->geometry_bytes < ts2d_geometry_state_bytes(P) || !state->image ||
         state->image_bytes < ts2d_image_state_bytes(W, H) ||
         (N > 0 && (!state->binning || ts_binning_capacity(state->binning_bytes, W, H) < N)))
@@ -735,11 +723,8 @@ int ts2d_backward_ranged(const ts2d_camera *cam, const ts2d_geometry *geom, uint
     ts_carve_image((char *)state->image, W, H, im);
     RenderArgs r = make_render(cam, geom, flags);
     if (colour_only) r.rich_info = false; // selects the pixel kernel's template only (the launchers dispatch on it)
-    // TS2D_FLAG_BACKWARD_PREPARED: the forward (TS2D_FLAG_PREPARE_BACKWARD) left the state's records clear, and nobody has added to them since
-    const bool prepared = flags & TS2D_FLAG_BACKWARD_PREPARED;
-    float *grad_rec = prepared ? g.grad_rec : (float *)ts_align_up((size_t)scratch);
+    float *grad_rec = (float *)ts_align_up((size_t)scratch);
 
-    if (!prepared)
     {
         ProfScope ps("zero_grad_records", s);
         // rasterizer.cu:290-300.  A KERNEL, not hipMemsetAsync: captured into a HIP graph (GraphedStep, bench.py --hip-graph) the memset became a

@@ -207,7 +207,6 @@ __global__ void __launch_bounds__(256, 6) render3d_fwd_group_kernel(RenderArgs a
     __shared__ unsigned long long tsum[RICH ? TCAP : 1]; // 16.48 fixed point (ts2d_group.h)
     __shared__ int tmax[RICH ? TCAP : 1];
 
-    ts_clear_share(a); // TS2D_FLAG_PREPARE_BACKWARD: the gradient records, on the side
     const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
     if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;

@@ -207,7 +207,6 @@ __global__ void __launch_bounds__(256, TSG_FWD_WAVES) render_fwd_group_kernel(Re
     if (a.W < 0) pad_lds[threadIdx.x] = 1, atomicAdd(&tmax[0], pad_lds[255 - threadIdx.x]);
 #endif
 
-    ts_clear_share(a); // TS2D_FLAG_PREPARE_BACKWARD: the gradient records, on the side (this kernel leaves the memory system idle)
     const int tile = tile_of_block(blockIdx.x, a.grid_x, a.grid_y);
     if (tile < 0) return; // the grid is padded (ts2d_wave.h)
     const int tx = tile % a.grid_x, ty = tile / a.grid_x;

@@ -85,7 +85,6 @@ struct GeometryStateView
     uint64_t *blocksum;      // ceil(P / 1024) + 2   raw per-block sums of tiles_sorted; [nblocks] = N (scratch of the depth sort's census before that)
     uint64_t *supersum;      // ceil(nblocks / 64) + 1   sums of 64 consecutive block sums (atomics; zeroed by the step's first launch)
     RadixScratchView rs;
-    float *grad_rec;         // P * TS_GRAD_FLOATS   the backward's gradient records when the forward prepared them (TS2D_FLAG_PREPARE_BACKWARD)
 };
 
 struct BinningStateView
@@ -153,7 +152,6 @@ static inline size_t ts_carve_geometry(char *base, int32_t P, GeometryStateView 
     ts_carve(p, v.supersum, ((n + 1023) / 1024 + 63) / 64 + 1);
     ts_carve_radix(p, n, v.rs, ts_depth_chunk(n));
     v.top_const = v.rs.tickets + v.rs.slabs + 4;
-    ts_carve(p, v.grad_rec, n * 16); // TS_GRAD_FLOATS (defined below)
     return (size_t)(p - base) + TS_ALIGN;
 }
 
@@ -284,22 +282,7 @@ struct RenderArgs
     int ablate; // profiling only (env TS2D_ABLATE, builds with -DTS2D_ABLATION): 0 = full kernel; see render.hip
     int legacy_blend; // measurement only (env TS2D_BLEND=wave, read once): round-1 one-triangle-per-wave blend kernels
     int bwd_mfma;  // experiment (env TS2D_BWD=mfma): render_bwd forms its per-entry sums with f32 MFMA instead of VALU reduction networks
-    float4 *clear4;       // forward blend kernels (group form): `clear4_count` float4 to clear on the side (the gradient records), or null
-    size_t clear4_count;
 };
-// every workgroup of a forward blend kernel clears its share of RenderArgs::clear4 before anything else (also the padded ones that return at once)
-__device__ __forceinline__ void ts_clear_share(const RenderArgs &a)
-{
-    if (!a.clear4) return;
-    const size_t per = (a.clear4_count + gridDim.x - 1) / gridDim.x, i0 = (size_t)blockIdx.x * per;
-    const size_t i1 = i0 + per < a.clear4_count ? i0 + per : a.clear4_count;
-    // streaming stores: the zeros must not push the tile's records and lists out of L2 (plain stores cost the blend kernel as much as the
-    // clear launch they replace: render_fwd 0.388 -> 0.399 ms at 1 M triangles)
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f *p = (v4f *)a.clear4;
-    const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
-    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) __builtin_nontemporal_store(z, p + i);
-}
 void ts_launch_render_fwd(const RenderArgs &a, const GeometryStateView &g, const BinningStateView &b,
                           const ImageStateView &im, float *out_feature, float *out_depth, float *out_normal,
                           float *contrib_sum, float *contrib_max, hipStream_t s);

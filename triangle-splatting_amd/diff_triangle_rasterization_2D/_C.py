@@ -65,7 +65,7 @@ def binding() -> str:
     return "compiled" if _ext is not None else "ctypes"
 
 
-FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS, FLAG_3D, FLAG_SH_FACTORED, FLAG_PREPARE_BACKWARD, FLAG_BACKWARD_PREPARED = 1, 2, 4, 8, 16, 32, 64, 128
+FLAG_BACK_CULLING, FLAG_RICH_INFO, FLAG_DEBUG, FLAG_USE_SHS, FLAG_3D, FLAG_SH_FACTORED = 1, 2, 4, 8, 16, 32
 MAX_CHANNELS = 3
 
 _fp = C.c_void_p
@@ -227,21 +227,18 @@ def _state(geometryBuffer, binningBuffer, imageBuffer) -> _State:
 
 def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma,
                         scale_modifier, background_depth, background, vertex, shs, feature, opacity, back_culling,
-                        rich_info, debug, *, variant=2, instance_capacity=None, prepare_backward=False):
+                        rich_info, debug, *, variant=2, instance_capacity=None):
     """`variant=3` selects the 3D rasterizer (TS2D_FLAG_3D; used by the sibling package diff_triangle_rasterization_3D).
     `instance_capacity` (an int > 0) selects the SYNC-FREE forward (ts2d_forward): the binning state is sized for that many tile
     instances, nothing is read back, and the returned `num_rendered` is the capacity (it only sizes the state for the backward
     call); whether the true count fitted is reported by `forward_status`.  Default None = the reference's sequence with its one
-    blocking read of num_rendered.
-    `prepare_backward` (TS2D_FLAG_PREPARE_BACKWARD): a backward pass will follow; the forward's blend kernel clears the gradient records of the
-    geometry state on the side, and the FIRST backward on these buffers runs with `prepared=True` and no clear launch."""
+    blocking read of num_rendered."""
     if _ext is not None:
         bg_t = background_depth if isinstance(background_depth, torch.Tensor) else None
         return _ext.rasterize_triangles_ex(int(image_width), int(image_height), tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, int(sh_degree), gamma,
                                            scale_modifier, 0.0 if bg_t is not None else float(background_depth), background, vertex, shs, feature, opacity,
                                            bool(back_culling), bool(rich_info), bool(debug), int(variant),
-                                           int(instance_capacity) if (instance_capacity is not None and vertex.size(0) > 0) else 0, bg_t,
-                                           bool(prepare_backward))
+                                           int(instance_capacity) if (instance_capacity is not None and vertex.size(0) > 0) else 0, bg_t)
     P = vertex.size(0)
     H, W = int(image_height), int(image_width)
     use_shs = _use_shs(shs, feature)
@@ -294,8 +291,7 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
                     torch.empty((0,), **u8), torch.empty((0,), **u8))
 
         flags = ((FLAG_BACK_CULLING if back_culling else 0) | (FLAG_RICH_INFO if rich_info else 0) |
-                 (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) | (FLAG_3D if variant == 3 else 0) |
-                 (FLAG_PREPARE_BACKWARD if prepare_backward else 0))
+                 (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) | (FLAG_3D if variant == 3 else 0))
         cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
         geometryBuffer = torch.empty((_lib.ts2d_geometry_state_bytes(P),), **u8)
@@ -332,14 +328,13 @@ def rasterize_triangles(image_width, image_height, tan_fovx, tan_fovy, viewmatri
 def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                                  background_depth, background, vertex, shs, feature, opacity, num_rendered, radii,
                                  geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
-                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False, out=None, range_events=None, prepared=False):
+                                 dL_dout_normal, rich_info, debug, *, variant=2, sh_factored=False, out=None, range_events=None):
     """`sh_factored=True` (SH mode only; TS2D_FLAG_SH_FACTORED): dL_dshs is not formed (returned as None) and the fourth
     result holds the clamp-masked colour gradient dL_dRGB (P, 3) for `sh_grad_expand` -- see parallel.py.
     `out`: optional dict of preallocated contiguous float32 device tensors ("vertex" (P,3,3), "center2D" (P,2), "opacity" (P,1),
     "color" = dL_dshs (P,M,3) or dL_dfeature (P,C)) that the library writes instead of fresh allocations (parallel.GradBucket).
     `range_events`: a list of K torch.cuda.Event (each recorded at least once before): the per-triangle kernel runs as K launches over
-    consecutive triangle ranges of `backward_range_rows(P, K)` rows and event k is recorded behind range k (ts2d_backward_ranged).
-    `prepared` (TS2D_FLAG_BACKWARD_PREPARED): this is the first backward on state buffers whose forward ran with `prepare_backward=True`."""
+    consecutive triangle ranges of `backward_range_rows(P, K)` rows and event k is recorded behind range k (ts2d_backward_ranged)."""
     if _ext is not None:
         bg_t = background_depth if isinstance(background_depth, torch.Tensor) else None
         o = out or {}
@@ -348,7 +343,7 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
                                                     int(num_rendered), radii, geometryBuffer, binningBuffer, imageBuffer, dL_dout_feature, dL_dout_depth,
                                                     dL_dout_normal, bool(rich_info), bool(debug), int(variant), bool(sh_factored), o.get("vertex"),
                                                     o.get("center2D"), o.get("color"), o.get("opacity"), bg_t,
-                                                    [int(e.cuda_event) for e in range_events] if range_events else [], bool(prepared))
+                                                    [int(e.cuda_event) for e in range_events] if range_events else [])
     P = vertex.size(0)
     H, W = dL_dout_feature.size(1), dL_dout_feature.size(2)  # extension_interface.cu:182-183
     use_shs = _use_shs(shs, feature)
@@ -392,13 +387,13 @@ def rasterize_triangles_backward(tan_fovx, tan_fovy, viewmatrix, projmatrix, cam
         if P == 0:
             return dL_dvertex, dL_dcenter2D, dL_dshs, dL_dfeature, dL_dopacity
         flags = ((FLAG_RICH_INFO if rich_info else 0) | (FLAG_DEBUG if debug else 0) | (FLAG_USE_SHS if use_shs else 0) |
-                 (FLAG_3D if variant == 3 else 0) | (FLAG_SH_FACTORED if sh_factored else 0) | (FLAG_BACKWARD_PREPARED if prepared else 0))
+                 (FLAG_3D if variant == 3 else 0) | (FLAG_SH_FACTORED if sh_factored else 0))
         cam, geom = _marshal(W, H, tan_fovx, tan_fovy, viewmatrix, projmatrix, campos, sh_degree, gamma, scale_modifier,
                              background_depth, background, vertex, shs, feature, opacity, use_shs, Cn, M)
         st = _state(geometryBuffer, binningBuffer, imageBuffer)
         loss = _LossGrads(_ptr(dL_dout_feature), _ptr(dL_dout_depth) if rich_info else None,
                           _ptr(dL_dout_normal) if rich_info else None)
-        scratch = torch.empty((0 if prepared else _lib.ts2d_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
+        scratch = torch.empty((_lib.ts2d_backward_scratch_bytes(P),), device=dev, dtype=torch.uint8)
         scratch_bytes = scratch.numel()
         out = _BackwardOut(_ptr(dL_dvertex), _ptr(dL_dcenter2D), _ptr(dL_dshs), _ptr(dL_dfeature), _ptr(dL_dopacity))
         if range_events:

@@ -78,7 +78,6 @@ def _camera_and_geometry_args(rs: TriangleRasterizationSettings, background_dept
 # dL_dshs; they append (dL_dRGB (P,3), campos (3,)) to the sink and return no gradient for `shs` (parallel.py rebuilds the
 # sum over all ranks' views from the exchanged factors).
 _sh_grad_sink = None
-_prepare_backward = True  # measurement switch (bench.py --no-prepare-backward): False = every backward clears its own gradient records, the form of rounds 1-5
 # Sync-free forward (include/ts2d.h: ts2d_forward): None = off (the reference's sequence, one blocking read of num_rendered per
 # forward); an int, or a callable (P, width, height) -> int, = the capacity in tile instances the binning state is sized for.
 # With it on, forward() never waits for the GPU; call `forward_overflowed(out_feature)` (one blocking read) once per step, e.g. after
@@ -158,17 +157,12 @@ class _RasterizeTriangles(torch.autograd.Function):
             bg_depth = float(bg_depth)
         native_args = (rs.image_width, rs.image_height) + _camera_and_geometry_args(rs, bg_depth) + (
             vertex, shs, feature, opacity, rs.back_culling, rs.rich_info, rs.debug)
-        # a backward pass will follow (some input asks for its gradient): the forward's blend kernel clears the gradient records on the side
-        # (include/ts2d.h: TS2D_FLAG_PREPARE_BACKWARD) and the FIRST backward on this state runs without its clear launch
-        prepare = _prepare_backward and any(ctx.needs_input_grad) and vertex.shape[0] > 0
-        ctx.records_prepared = prepare
         with _snapshot_on_error("rasterize_triangles", native_args, rs.debug):
             (num_rendered, out_feature, radii, depth, normal, contrib_sum, contrib_max,
              geometryBuffer, binningBuffer, imageBuffer) = _C.rasterize_triangles(
                 *native_args, variant=ctx._forward_cls._variant,
                 instance_capacity=(_instance_capacity(vertex.shape[0], rs.image_width, rs.image_height) if callable(_instance_capacity)
-                                   else _instance_capacity) if vertex.shape[0] > 0 else None,
-                prepare_backward=prepare)
+                                   else _instance_capacity) if vertex.shape[0] > 0 else None)
 
         if _instance_capacity is not None and vertex.shape[0] > 0:
             global _last_sync_free_forward
@@ -229,9 +223,8 @@ class _RasterizeTriangles(torch.autograd.Function):
             # a bucket prepared for a ranged exchange (GradBucket.prepare_ranges): the per-triangle kernel runs range by range with an event behind
             # each, so that the exchange of range k overlaps range k + 1 -- only for the backward that WRITES the bucket (the first under a capture)
             ranged = place is not None and getattr(bucket, "range_events", None)
-            prepared, ctx.records_prepared = ctx.records_prepared, False  # a second backward on this state (retain_graph) clears for itself
             g_vertex, g_center2D, g_shs, g_feat, g_opacity = _C.rasterize_triangles_backward(
-                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place, range_events=ranged or None, prepared=prepared)
+                *native_args, variant=ctx._forward_cls._variant, sh_factored=sink is not None, out=place, range_events=ranged or None)
             if ranged:
                 bucket._ranges_recorded = True
             if sink is not None:
