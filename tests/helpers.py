@@ -115,6 +115,9 @@ def lab_library():
         L.ts2d_debug_read_state.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]
         L.ts2d_test_sort_pairs.restype = C.c_int
         L.ts2d_test_sort_pairs.argtypes = [C.c_void_p] * 4 + [C.c_size_t, C.c_int32, C.c_int32, C.c_void_p]
+        L.ts2d_test_quantile_scratch_bytes.restype = C.c_size_t
+        L.ts2d_test_quantile.restype = C.c_int
+        L.ts2d_test_quantile.argtypes = [C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.ts2d_test_inclusive_scan_rocprim.restype = C.c_int
         L.ts2d_test_inclusive_scan_rocprim.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.ts2d_lab_force_ticket_passes.argtypes = [C.c_int]

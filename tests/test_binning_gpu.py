@@ -156,3 +156,28 @@ def test_last_arrival_handoffs_under_uneven_load():
             bad += 1
     torch.cuda.synchronize()
     assert bad == 0, f"{bad} of 60 sorts differ from the stable reference under load"
+
+
+@pytest.mark.parametrize("n", [1, 2, 17, 4096, 4097, 640_000, 1 << 20, (1 << 20) + 1, 3_000_001])
+def test_radix_select_quantile_equals_torch_quantile(n):
+    """select.hip: torch.quantile(G, q) of non-negative floats by a most-significant-digit radix select (four histogram passes + a neighbour pass)
+    against torch.quantile itself (linear interpolation), on uniform values, values spread over many octaves, a few distinct values with heavy
+    duplicates, and mostly zeros; q at the ends and inside; sizes around the kernels' block and chunk boundaries.  (Round 6 also built the five
+    launches as ONE, the workgroups handing the digit totals to each other through a counter: 37 -> 46 us at 640 k keys, 96 with the totals spread
+    over eight copies -- a hand-off between workgroups costs more than a launch on this chip.  Not adopted.)"""
+    import torch
+    L = _lib()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    base = torch.rand(n, device="cuda", generator=g)
+    data = {"uniform": base, "octaves": torch.exp2(40.0 * base - 30.0), "duplicates": torch.round(base * 7.0) / 7.0,
+            "zeros": torch.where(base < 0.95, torch.zeros_like(base), base)}
+    scratch = torch.empty(L.ts2d_test_quantile_scratch_bytes(), device="cuda", dtype=torch.uint8)
+    out = torch.empty(1, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+    for name, x in data.items():
+        x = x.float().contiguous()
+        for q in (0.0, 0.1, 0.5, 0.9, 0.999, 1.0):
+            want = float(torch.quantile(x, q))
+            assert L.ts2d_test_quantile(x.data_ptr(), n, q, scratch.data_ptr(), out.data_ptr(), stream) == 0
+            got = float(out)
+            assert got == want or abs(got - want) <= 2e-7 * abs(want), (name, q, got, want)

@@ -57,6 +57,16 @@ int ts2d_test_sort_pairs(const uint32_t *keys_in, const uint32_t *vals_in, uint3
     return rc ? TS2D_ERR_HIP : TS2D_OK;
 }
 
+// torch.quantile(keys as non-negative floats, q) by the library's radix select (select.hip).  `scratch`: ts2d_test_quantile_scratch_bytes() bytes;
+// `out`: one float, both in device memory.
+size_t ts2d_test_quantile_scratch_bytes(void) { return ts_quantile_scratch_bytes(); }
+int ts2d_test_quantile(const uint32_t *keys, size_t n, float q, void *scratch, float *out, void *stream)
+{
+    if (n == 0 || !keys || !scratch || !out) return TS2D_ERR_INVALID;
+    ts_quantile_threshold(keys, n, q, scratch, out, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? TS2D_OK : TS2D_ERR_HIP;
+}
+
 int ts2d_test_inclusive_scan_rocprim(const uint32_t *in, uint32_t *out, size_t n, void *stream)
 {
     hipStream_t s = (hipStream_t)stream;

@@ -40,6 +40,8 @@ void ts2d_lab_force_ticket_passes(int on);
  * share the top key byte (sign + 7 exponent bits: depths within a factor of four -- every synthetic scene of bench.py; not a real scene
  * that spans more): bench.py --force-depth-pass4 reports the headline without that data-dependent shortcut. */
 void ts2d_lab_force_depth_pass4(int on);
+size_t ts2d_test_quantile_scratch_bytes(void);
+int ts2d_test_quantile(const uint32_t *keys, size_t n, float q, void *scratch, float *out, void *stream); // torch.quantile by the library's radix select
 void ts2d_lab_depth_split(int mode, int bucket_cap); // mode 0: the product's choice (sampled splitters from 12 289 to 500 000 triangles), 1: the LSD depth sort at every size, 2: sampled splitters up to 1.6 M; bucket_cap > 0: a smaller per-bucket register capacity (the kernel's global-memory path)
 /* on != 0: the emission kernel of later forwards in this library flags EVERY quadrant of every instance (the masks' machinery runs, the test
  * always passes).  The masks are pure culling of work that contributes nothing, so every output must be what it is with them on:
