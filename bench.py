@@ -118,6 +118,8 @@ def main():
                          "the scene stays the one BASELINE.json names; reported as config.optimizer")
     ap.add_argument("--depth-lsd", action="store_true", help="lab library only: the LSD depth sort of rounds 2-5 at every size instead of the sampled-splitter "
                     "form (binning.hip: depth_split_*), for A/B runs")
+    ap.add_argument("--depth-split-all", action="store_true", help="lab library only: the sampled-splitter depth order up to the 1.6 M triangles it supports "
+                    "(the product switches to the LSD sort above 500 000), for A/B runs")
     ap.add_argument("--force-depth-pass4", action="store_true",
                     help="NOT the headline: the depth sort runs its fourth pass although every depth of the synthetic scene shares the top key byte "
                          "(what a scene spanning more than a factor of four in depth costs).  Needs the lab library: "
@@ -193,6 +195,12 @@ def main():
         import ctypes
         _C._lib.ts2d_lab_depth_split.argtypes = [ctypes.c_int, ctypes.c_int]
         _C._lib.ts2d_lab_depth_split(1, 0)
+    if args.depth_split_all:
+        if not hasattr(_C._lib, "ts2d_lab_depth_split"):
+            raise SystemExit("--depth-split-all needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")
+        import ctypes
+        _C._lib.ts2d_lab_depth_split.argtypes = [ctypes.c_int, ctypes.c_int]
+        _C._lib.ts2d_lab_depth_split(2, 0)
     if args.side_stream:
         if not hasattr(_C._lib, "ts2d_lab_side_stream"):
             raise SystemExit("--side-stream needs TS2D_LIBRARY_PATH=tools/bin/libts2d_lab.so")

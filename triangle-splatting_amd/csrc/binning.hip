@@ -483,10 +483,15 @@ __device__ __forceinline__ void rs_scatter_body(const uint32_t *__restrict__ kin
         // and a launch of a few resident workgroups per SIMD spends a good part of its time issuing exactly these)
         const unsigned long long vm = ballot64(valid);
         uint32_t mis_lo = ~(uint32_t)vm, mis_hi = ~(uint32_t)(vm >> 32);
-        for (int bit = 0; bit < nbits; bit++)
+        // all eight bits, unrolled, whatever `nbits` is (the digit's bits above it are zero in every lane and cost a ballot that changes nothing): with
+        // the bit index a compile-time constant a bit is four instructions (v_bfe_i32, the compare behind the ballot, two fused xor-or); as a loop
+        // over the run-time `nbits` it was twelve (shift by an SGPR, select, loop control, two s_nop) -- 96 of the ~135 instructions of a 64-pair
+        // step, in kernels whose time IS this ranking (round 6: profiles/r06_rank_unroll.txt)
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++)
         {
             const unsigned long long bb = ballot64((d >> bit) & 1u);
-            const uint32_t e = 0u - ((d >> bit) & 1u); // all ones when my bit is set
+            const uint32_t e = (uint32_t)__builtin_amdgcn_sbfe((int)d, bit, 1); // all ones when my bit is set
             mis_lo |= (uint32_t)bb ^ e;
             mis_hi |= (uint32_t)(bb >> 32) ^ e;
         }
@@ -1179,7 +1184,10 @@ __global__ void __launch_bounds__(64 * DS_WAVES) depth_order_small_kernel(int P,
 // Measured against the LSD passes alternating on one box (profiles/r06_depth_split.txt): 93 k triangles 57 -> 43 us (step 0.335 -> 0.321 ms), 300 k
 // 59 -> 47 (0.613 -> 0.605), 1 M 75 -> 65 us of kernels and NO difference in the step (the largest bucket holds 7 500 pairs = 8 steps x 2 passes of
 // a ranking that is issue-bound with 16 waves on the compute unit: K3 takes 35 us there) -- hence the switch-over below.
-constexpr int TS_DEPTH_SPLIT_MAX = 500000;       // the product's switch-over: measured level with the LSD passes at 1 M triangles, ahead below
+#ifndef TS_DEPTH_SPLIT_MAX_VALUE // (variant builds: tools/build_obj_variant.sh ... binning "-DTS_DEPTH_SPLIT_MAX_VALUE=1600000")
+#define TS_DEPTH_SPLIT_MAX_VALUE 500000
+#endif
+constexpr int TS_DEPTH_SPLIT_MAX = TS_DEPTH_SPLIT_MAX_VALUE; // the product's switch-over: measured level with the LSD passes at 1 M triangles, ahead below
 constexpr int TS_DEPTH_SPLIT_HARD_MAX = 1600000; // what the form supports (buckets of P / 256 pairs on average against DB_CAP = 16384): lab library, mode 2
 constexpr int DSPL_SAMPLES = 4096, DSPL_PER = DSPL_SAMPLES / NB;
 constexpr int DB_WAVES = 16, DB_KB = 16, DB_CAP = 64 * DB_WAVES * DB_KB; // the large form of depth_bucket_sort_kernel
@@ -1381,7 +1389,7 @@ __global__ void __launch_bounds__(256) depth_split_scatter_kernel(int64_t n, Geo
         for (int bit = 0; bit < 8; bit++)
         {
             const unsigned long long bb = ballot64((d >> bit) & 1u);
-            const uint32_t e = 0u - ((d >> bit) & 1u);
+            const uint32_t e = (uint32_t)__builtin_amdgcn_sbfe((int)d, bit, 1);
             mis_lo |= (uint32_t)bb ^ e;
             mis_hi |= (uint32_t)(bb >> 32) ^ e;
         }
@@ -1478,10 +1486,11 @@ __device__ __forceinline__ void bucket_rank_pass(const uint32_t (&key)[KBX], uin
         const uint32_t d = ((key[b] - kmin) >> shift) & 0xFFu;
         const unsigned long long vm = ballot64(valid);
         uint32_t mis_lo = ~(uint32_t)vm, mis_hi = ~(uint32_t)(vm >> 32);
-        for (int bit = 0; bit < nbits; bit++) // the digit's bits above nbits are zero in every key of the bucket
+#pragma unroll
+        for (int bit = 0; bit < 8; bit++) // unrolled over all eight bits (see rs_scatter_body); `nbits` is not needed
         {
             const unsigned long long bb = ballot64((d >> bit) & 1u);
-            const uint32_t e = 0u - ((d >> bit) & 1u);
+            const uint32_t e = (uint32_t)__builtin_amdgcn_sbfe((int)d, bit, 1);
             mis_lo |= (uint32_t)bb ^ e;
             mis_hi |= (uint32_t)(bb >> 32) ^ e;
         }
@@ -1521,17 +1530,31 @@ __device__ __forceinline__ void bucket_rank_pass(const uint32_t (&key)[KBX], uin
 
 // What gather_blocksum_kernel does, for 64 consecutive depth-order positions (first one `pos0`, this lane's `pos`): the tile counts in depth order
 // and their sums per scan block -- 64 consecutive positions meet at most two blocks; the sums were cleared by K0.
-__device__ __forceinline__ void bucket_emit_tiles(const GeometryStateView &g, int pos0, int pos, bool in, uint32_t tt, int lane)
+// `lsum` (fast path): the workgroup's scan-block sums in LDS, entry 0 = the block of the bucket's first position; they leave as ONE global atomic
+// per (bucket, scan block) at the end (2 k atomics at 1 M triangles instead of 16 k, one or two per wave and step).  Null: straight to memory.
+__device__ __forceinline__ void bucket_emit_tiles(const GeometryStateView &g, int pos0, int pos, bool in, uint32_t tt, int lane, uint32_t *lsum = nullptr,
+                                                  int lblk0 = 0)
 {
     if (in) g.tiles_sorted[pos] = tt;
+    // 64 tile counts fit 32 bits together (their sum is at most N, and a forward with N >= 2^31 is refused on the host).  The positions grow with
+    // the lane, so the lanes of the first scan block are a prefix of the wave: its sum is the inclusive scan at the last of them, the second block's
+    // the rest -- one DPP scan (a 64-bit butterfly per block took 24 ds_bpermute per step).
     const int blk0 = pos0 / SB;
-    // tile counts are < 2^32 each, the sum of 64 of them may not be
-    unsigned long long a = (in && pos / SB == blk0) ? (unsigned long long)tt : 0ull, b = (in && pos / SB != blk0) ? (unsigned long long)tt : 0ull;
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    const uint32_t inc = wave_inclusive_scan(in ? tt : 0u, lane);
+    const int nfirst = min(64, (blk0 + 1) * SB - pos0); // lanes whose position lies in blk0 (>= 1)
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63), a = (uint32_t)__builtin_amdgcn_readlane((int)inc, nfirst - 1);
     if (lane == 0)
     {
-        if (a) __hip_atomic_fetch_add((unsigned long long *)g.blocksum + blk0, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (b) __hip_atomic_fetch_add((unsigned long long *)g.blocksum + blk0 + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lsum)
+        {
+            if (a) atomicAdd(&lsum[blk0 - lblk0], a);
+            if (total - a) atomicAdd(&lsum[blk0 - lblk0 + 1], total - a);
+        }
+        else
+        {
+            if (a) __hip_atomic_fetch_add((unsigned long long *)g.blocksum + blk0, (unsigned long long)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (total - a) __hip_atomic_fetch_add((unsigned long long *)g.blocksum + blk0 + 1, (unsigned long long)(total - a), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -1615,22 +1638,33 @@ __global__ void __launch_bounds__(64 * W) depth_bucket_sort_kernel(int P, Geomet
                 if (64 * b < per) { key[b] = stage_k[base + 64 * b + lane]; val[b] = stage_v[base + 64 * b + lane]; }
             __syncthreads();
         }
-        // the tile counts of all steps are requested before any of them is used: one gather latency per wave, not one per step
+        // the tile counts of all steps are requested before anything else happens: one gather latency per wave, not one per step
+#pragma unroll
+        for (int b = 0; b < DB_KB; b++)
+            rk[b] = 64 * b >= per ? 0u : g.tiles_touched[64 * b + lane < mine ? val[b] : 0u];
 #pragma unroll
         for (int b = 0; b < DB_KB; b++)
         {
             if (64 * b >= per) continue;
-            const bool in = 64 * b + lane < mine;
             const int pos = s0 + base + 64 * b + lane;
-            if (in) { g.sk[1][pos] = depth_key_restore(key[b], kmin); g.sv[1][pos] = val[b]; }
-            rk[b] = g.tiles_touched[in ? val[b] : 0u]; // branch-free, like the loads above
+            if (64 * b + lane < mine) { g.sk[1][pos] = depth_key_restore(key[b], kmin); g.sv[1][pos] = val[b]; }
         }
+        // (a bucket of n <= DB_CAP pairs meets at most DB_CAP / SB + 2 scan blocks; a block's sum stays below N < 2^31)
+        constexpr int LB = DB_CAP / SB + 2;
+        uint32_t *lsum = dstart; // free on this path (NB >= LB words)
+        static_assert(LB <= NB, "the scan-block sums borrow dstart");
+        if (t < LB) lsum[t] = 0u;
+        __syncthreads();
+        const int lblk0 = s0 / SB;
 #pragma unroll
         for (int b = 0; b < DB_KB; b++)
         {
             if (64 * b >= per) continue;
-            bucket_emit_tiles(g, s0 + base + 64 * b, s0 + base + 64 * b + lane, 64 * b + lane < mine, 64 * b + lane < mine ? rk[b] : 0u, lane);
+            bucket_emit_tiles(g, s0 + base + 64 * b, s0 + base + 64 * b + lane, 64 * b + lane < mine, 64 * b + lane < mine ? rk[b] : 0u, lane, lsum, lblk0);
         }
+        __syncthreads();
+        if (t < LB && lsum[t])
+            __hip_atomic_fetch_add((unsigned long long *)g.blocksum + lblk0 + t, (unsigned long long)lsum[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     else
     {
