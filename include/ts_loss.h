@@ -93,6 +93,14 @@ int tsl_downsample_forward(const float *in, int32_t channels, int32_t in_height,
                            void *stream);
 int tsl_downsample_backward(const float *grad_out, int32_t channels, int32_t in_height, int32_t in_width, int32_t out_height, int32_t out_width,
                             float *grad_in, void *stream);
+/* The same resize for planes that are NOT one tensor -- the render (3), depth (1) and normal (3) images of VanillaTS_model.py:649-656 are three:
+ * `in_planes` / `out_planes` (backward: `grad_out_planes` / `grad_in_planes`) are HOST arrays of num_planes device pointers, one per image plane;
+ * up to TS_RESAMPLE_PLANES planes share a launch (at 800 x 800 a launch is latency, not work: six launches per iteration become two). */
+#define TS_RESAMPLE_PLANES 8
+int tsl_downsample_forward_planes(int32_t num_planes, const float *const *in_planes, int32_t in_height, int32_t in_width, int32_t out_height,
+                                  int32_t out_width, float *const *out_planes, void *stream);
+int tsl_downsample_backward_planes(int32_t num_planes, const float *const *grad_out_planes, int32_t in_height, int32_t in_width, int32_t out_height,
+                                   int32_t out_width, float *const *grad_in_planes, void *stream);
 
 #ifdef __cplusplus
 }

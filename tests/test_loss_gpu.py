@@ -350,3 +350,33 @@ def test_downsample_bilinear_equals_interpolate_and_its_autograd(shape, factor):
     assert float((gx - gr).abs().max()) < 2e-7
     with pytest.raises(RuntimeError):
         downsample_bilinear(x, (h + 1, w))  # not an integer factor
+
+
+@pytest.mark.parametrize("H,W,factor", [(96, 160, 2), (90, 150, 3), (94, 158, 2)])
+def test_downsample_bilinear_many_is_the_single_tensor_kernel_on_every_tensor(H, W, factor):
+    """Round 6: the render (3), depth (1) and normal (3) images of a step through ONE launch each way (tsl_downsample_*_planes; nine planes here:
+    more than a launch holds) -- the same bits as downsample_bilinear on each tensor, gradients included; an output nobody differentiates hands
+    its input None (the rasterizer's backward then takes its colour-only form), not zeros."""
+    import torch
+    from diff_recon_hip import downsample_bilinear, downsample_bilinear_many
+    g = torch.Generator(device="cuda").manual_seed(H)
+    buf = torch.rand(H * W + 1, device="cuda", generator=g)
+    # three tensors that are not contiguous with each other; the second starts 4 bytes off an 8-byte boundary (the factor-2 kernel's float2 loads
+    # need that alignment: the launch falls back to the general kernel, same bits)
+    xs = [torch.rand((3, H, W), device="cuda", generator=g).requires_grad_(True), buf[1:].view(H, W).detach().requires_grad_(True),
+          torch.rand((5, H, W), device="cuda", generator=g).requires_grad_(True)]
+    h, w = H // factor, W // factor
+    many = downsample_bilinear_many(xs, (h, w))
+    single = [downsample_bilinear(x, (h, w)) for x in xs]
+    assert [tuple(m.shape) for m in many] == [(3, h, w), (h, w), (5, h, w)]
+    for m, s1 in zip(many, single):
+        assert torch.equal(m, s1)
+    ups = [torch.rand(m.shape, device="cuda", generator=g) for m in many]
+    gm = torch.autograd.grad(many, xs, ups)
+    gs = torch.autograd.grad(single, xs, ups)
+    for a, b in zip(gm, gs):
+        assert torch.equal(a, b)
+    # only the first output is differentiated: the others' inputs get no gradient at all
+    many = downsample_bilinear_many(xs, (h, w))
+    got = torch.autograd.grad(many[0].sum(), xs, allow_unused=True)
+    assert got[0] is not None and got[1] is None and got[2] is None

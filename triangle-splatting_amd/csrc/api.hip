@@ -910,6 +910,33 @@ int tsl_downsample_backward(const float *grad_out, int32_t C, int32_t H, int32_t
     return TS2D_OK;
 }
 
+static int downsample_planes_ok(int32_t n, const float *const *a, float *const *b, int32_t H, int32_t W, int32_t h, int32_t w)
+{
+    if (n < 0) return fail(TS2D_ERR_INVALID, "num_planes must be >= 0");
+    if (n == 0) return TS2D_OK;
+    if (!a || !b) return fail(TS2D_ERR_INVALID, "null pointer");
+    for (int k = 0; k < n; k++)
+        if (int rc = downsample_args_ok(a[k], b[k], 1, H, W, h, w)) return rc;
+    return TS2D_OK;
+}
+int tsl_downsample_forward_planes(int32_t n, const float *const *in_planes, int32_t H, int32_t W, int32_t h, int32_t w, float *const *out_planes, void *stream)
+{
+    if (int rc = downsample_planes_ok(n, in_planes, out_planes, H, W, h, w)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("downsample_fwd", s);
+    TS_HIP(ts_downsample_forward_planes(n, in_planes, H, W, h, w, out_planes, s));
+    return TS2D_OK;
+}
+int tsl_downsample_backward_planes(int32_t n, const float *const *grad_out_planes, int32_t H, int32_t W, int32_t h, int32_t w, float *const *grad_in_planes,
+                                   void *stream)
+{
+    if (int rc = downsample_planes_ok(n, grad_out_planes, grad_in_planes, H, W, h, w)) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps("downsample_bwd", s);
+    TS_HIP(ts_downsample_backward_planes(n, grad_out_planes, H, W, h, w, grad_in_planes, s));
+    return TS2D_OK;
+}
+
 // ---- DoGLoss / SmoothnessLoss (aux_losses.hip) ------------------------------------------------------------------------------------
 size_t tsl_aux_loss_workspace_bytes(int32_t channels, int32_t height, int32_t width, double scale_factor)
 {

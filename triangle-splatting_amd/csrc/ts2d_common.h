@@ -351,6 +351,8 @@ hipError_t ts_scharr_smoothness_backward(const float *img, const float *mask, in
                                          hipStream_t s);
 hipError_t ts_downsample_forward(const float *in, int C, int H, int W, int h, int w, float *out, hipStream_t s);   // resample.hip
 hipError_t ts_downsample_backward(const float *gout, int C, int H, int W, int h, int w, float *gin, hipStream_t s);
+hipError_t ts_downsample_forward_planes(int n, const float *const *src, int H, int W, int h, int w, float *const *dst, hipStream_t s);
+hipError_t ts_downsample_backward_planes(int n, const float *const *gout, int H, int W, int h, int w, float *const *gin, hipStream_t s);
 size_t ts_depth_normal_workspace_bytes(int H, int W, double scale);
 hipError_t ts_depth_normal_forward(const float *depth, const float *normal, int H, int W, float tan_fovx, float tan_fovy, double scale, float quantile,
                                    void *workspace, float *out, hipStream_t s);

@@ -25,7 +25,7 @@
 
 Native code: libts2d.so (include/ts_loss.h, include/ts_model.h, include/ts_optim.h, include/ts2d.h).  No CPU / eager fallback anywhere.
 """
-from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss, DepthNormalLoss, DoGLoss, SmoothnessLoss, dogLoss, smoothnessLoss, downsample_bilinear  # noqa: F401
+from .losses import L1, SSIMLoss, ssimLoss, PhotometricLoss, photometric_loss, DepthNormalLoss, DoGLoss, SmoothnessLoss, dogLoss, smoothnessLoss, downsample_bilinear, downsample_bilinear_many  # noqa: F401
 from .triangle_renderer import TriangleRenderer  # noqa: F401
 from .model_forward import background_depth, gamma_rescale_ratio, rescale_triangles, ste_opacity, render_view  # noqa: F401
 from .model_update import (DensificationStats, prune_points, densification, opacity_pruning, opacity_clipping, scale_pruning,  # noqa: F401

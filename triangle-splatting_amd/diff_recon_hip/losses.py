@@ -340,6 +340,9 @@ _lib.tsl_downsample_forward.restype = C.c_int
 _lib.tsl_downsample_forward.argtypes = [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]
 _lib.tsl_downsample_backward.restype = C.c_int
 _lib.tsl_downsample_backward.argtypes = [_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _fp, _fp]
+for _name in ("tsl_downsample_forward_planes", "tsl_downsample_backward_planes"):
+    getattr(_lib, _name).restype = C.c_int
+    getattr(_lib, _name).argtypes = [C.c_int32, C.POINTER(C.c_void_p), C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), _fp]
 
 
 class _Downsample(torch.autograd.Function):
@@ -364,6 +367,63 @@ class _Downsample(torch.autograd.Function):
         with torch.cuda.device(g.device):
             _native._check(_lib.tsl_downsample_backward(gc.data_ptr(), c, H, W, h, w, gin.data_ptr(), torch.cuda.current_stream().cuda_stream), "downsample_bilinear backward")
         return gin, None, None
+
+
+def _plane_ptrs(t: torch.Tensor, hw: int):
+    lead = t.numel() // hw
+    return [t.data_ptr() + 4 * hw * k for k in range(lead)]
+
+
+class _DownsampleMany(torch.autograd.Function):
+    """downsample_bilinear of several tensors with the same (H, W) in ONE launch each way (include/ts_loss.h: tsl_downsample_*_planes)."""
+
+    @staticmethod
+    def forward(ctx, h, w, *xs):
+        xs = [x.contiguous() for x in xs]
+        H, W = xs[0].shape[-2:]
+        outs = [torch.empty(tuple(x.shape[:-2]) + (h, w), device=x.device, dtype=torch.float32) for x in xs]
+        src = sum((_plane_ptrs(x, H * W) for x in xs), [])
+        dst = sum((_plane_ptrs(o, h * w) for o in outs), [])
+        n = len(src)
+        with torch.cuda.device(xs[0].device):
+            _native._check(_lib.tsl_downsample_forward_planes(n, (C.c_void_p * n)(*src), H, W, h, w, (C.c_void_p * n)(*dst),
+                                                              torch.cuda.current_stream().cuda_stream), "downsample_bilinear")
+        ctx.dims = (H, W, h, w, [tuple(x.shape) for x in xs])
+        ctx.set_materialize_grads(False)  # an output nobody differentiates (depth / normal without the geometry loss) hands its input no gradient
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        H, W, h, w, shapes = ctx.dims
+        live = [(i, g.contiguous()) for i, g in enumerate(gs) if g is not None]
+        gins = [None] * len(gs)
+        if live:
+            dev = live[0][1].device
+            for i, _ in live:
+                gins[i] = torch.empty(shapes[i], device=dev, dtype=torch.float32)
+            src = sum((_plane_ptrs(g, h * w) for _, g in live), [])
+            dst = sum((_plane_ptrs(gins[i], H * W) for i, _ in live), [])
+            n = len(src)
+            with torch.cuda.device(dev):
+                _native._check(_lib.tsl_downsample_backward_planes(n, (C.c_void_p * n)(*src), H, W, h, w, (C.c_void_p * n)(*dst),
+                                                                   torch.cuda.current_stream().cuda_stream), "downsample_bilinear backward")
+        return (None, None) + tuple(gins)
+
+
+def downsample_bilinear_many(xs, size):
+    """[downsample_bilinear(x, size) for x in xs] for tensors of one (H, W) -- the render, depth and normal images of a step -- in one launch each
+    way instead of one per tensor (at 800 x 800 a launch is ~9 us of latency for ~3 of work).  An output without an incoming gradient gives its
+    input none (not zeros): the rasterizer's backward then takes its colour-only form."""
+    h, w = int(size[0]), int(size[1])
+    xs = list(xs)
+    if not xs:
+        return []
+    for x in xs:
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise RuntimeError("downsample_bilinear (MI355X build) needs float32 tensors on a HIP device; there is no CPU fallback")
+        if tuple(x.shape[-2:]) != tuple(xs[0].shape[-2:]):
+            raise ValueError("downsample_bilinear_many: the tensors must share their last two dimensions")
+    return list(_DownsampleMany.apply(h, w, *xs))
 
 
 def downsample_bilinear(x: torch.Tensor, size) -> torch.Tensor:

@@ -23,7 +23,7 @@ import torch.nn.functional as F
 
 from diff_triangle_rasterization_2D import _C as _native
 
-from .losses import downsample_bilinear
+from .losses import downsample_bilinear, downsample_bilinear_many
 from .triangle_renderer import TriangleRenderer
 
 
@@ -97,12 +97,11 @@ def render_view(camera, vertex: torch.Tensor, f_dc: torch.Tensor, f_rest: torch.
     if up > 1:
         # F.interpolate(..., size=(h, w), mode="bilinear") of the reference (:649-656); for the integer factor this is, one gather kernel each way
         # (diff_recon_hip.downsample_bilinear, csrc/resample.hip; pinned against F.interpolate + autograd in tests/test_loss_gpu.py)
-        out["render"] = downsample_bilinear(out["render"], (h, w))
+        # -- and ONE launch for the three images (downsample_bilinear_many: a launch is latency at this size)
+        names = [k for k in ("render", "depth", "normal") if k in out]
+        for k, small in zip(names, downsample_bilinear_many([out[k] for k in names], (h, w))):
+            out[k] = small
         out["radii"] = out["radii"] // up
-        if "depth" in out:
-            out["depth"] = downsample_bilinear(out["depth"], (h, w))
-        if "normal" in out:
-            out["normal"] = downsample_bilinear(out["normal"], (h, w))
     pkg = {"render": out["render"]}
     if is_training:  # :664-679
         pkg.update(radii=out["radii"], center2D=out["center2D"], contrib_sum=out["contrib_sum"], contrib_max=out["contrib_max"],
