@@ -62,6 +62,19 @@ int tso_adam_step(const tso_adam_slice *slices, int32_t num_slices, double beta1
  * Coefficient 0 of triangle i lives at {param,exp_avg,exp_avg_sq}_dc + i * dc_stride, coefficient k >= 1 at ..._rest + i * rest_stride + 3 (k - 1)
  * (strides in floats): the reference's two tensors f_dc (P, 1, 3) / f_rest (P, M - 1, 3) are strides 3 / 3 (M - 1); ONE (P, M, 3) tensor is
  * dc = base, rest = base + 3, both strides 3 M.  Coefficients above sh_degree take a zero gradient (the reference's dense array holds zeros there). */
+typedef struct tso_row_slice
+{
+    float *param;
+    const float *grad;
+    float *exp_avg;
+    float *exp_avg_sq;
+    int32_t floats_per_row;   /* 9 for (P, 3, 3) vertices, 1 for (P, 1) opacities */
+    float step_size;
+    float bias2_sqrt;
+    float grad_scale;
+} tso_row_slice;
+#define TSO_SH_ROW_SLICES 2
+
 typedef struct tso_sh_factored_step
 {
     int32_t P, M, sh_degree, V;   /* M = (max degree + 1)^2 in {1, 4, 9, 16}; V views >= 1 */
@@ -73,6 +86,11 @@ typedef struct tso_sh_factored_step
     int64_t dc_stride, rest_stride;
     float step_size_dc, bias2_sqrt_dc, step_size_rest, bias2_sqrt_rest;
     float grad_scale;
+    /* optional: further per-triangle parameters (the vertices, the opacities) stepped from their DENSE gradients by the same launch -- the workgroup
+     * that owns 64 triangles updates their rows after it has read what it needs of them (the direction comes from the vertices BEFORE the step):
+     * one launch for the whole optimizer step, and the vertices are read once.  floats_per_row * P floats each. */
+    int32_t num_rows;             /* 0 .. TSO_SH_ROW_SLICES */
+    tso_row_slice rows[TSO_SH_ROW_SLICES];
 } tso_sh_factored_step;
 
 int tso_adam_step_sh_factored(const tso_sh_factored_step *step, double beta1, double beta2, double eps, void *stream);

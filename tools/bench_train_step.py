@@ -140,7 +140,8 @@ def main():
     n_img = 3 * c.h * c.w
     nparam = c.P * (9 + 1 + 3 * M)
     V = 1
-    alg_sh = {"adam_step": 28 * c.P * 10, "adam_step_sh_factored": c.P * (36 + 12 * V + 36 * M + 36 * M)} if not a.dense_adam else {}
+    # one launch: the SH coefficients from the factors + the vertices and opacities from their dense gradients (the vertices are read once)
+    alg_sh = {"adam_step_sh_factored": c.P * (12 * V + 36 * M + 36 * M) + 28 * c.P * 10} if not a.dense_adam else {}
     alg = {"photometric_fwd": 5 * 4 * n_img, "photometric_bwd": 6 * 4 * n_img, "adam_step": 28 * nparam, "training_statistic": 68 * c.P,
            "depth_normal_fwd": 16 * c.h * c.w, "depth_normal_bwd": 32 * c.h * c.w}
     alg.update(alg_sh)

@@ -1080,6 +1080,13 @@ int tso_adam_step_sh_factored(const tso_sh_factored_step *a, double beta1, doubl
     if (a->M > 1 && (!a->param_rest || !a->exp_avg_rest || !a->exp_avg_sq_rest)) return fail(TS2D_ERR_INVALID, "null f_rest pointer");
     if (a->dc_stride < 3 || (a->M > 1 && a->rest_stride < 3 * (a->M - 1))) return fail(TS2D_ERR_INVALID, "row strides too small");
     if (!(a->bias2_sqrt_dc > 0.0f) || (a->M > 1 && !(a->bias2_sqrt_rest > 0.0f))) return fail(TS2D_ERR_INVALID, "bias2_sqrt must be positive (step >= 1)");
+    if (a->num_rows < 0 || a->num_rows > TSO_SH_ROW_SLICES) return fail(TS2D_ERR_INVALID, "num_rows must be in 0..%d", TSO_SH_ROW_SLICES);
+    for (int r = 0; r < a->num_rows; r++)
+    {
+        if (!a->rows[r].param || !a->rows[r].grad || !a->rows[r].exp_avg || !a->rows[r].exp_avg_sq) return fail(TS2D_ERR_INVALID, "row slice %d: null pointer", r);
+        if (a->rows[r].floats_per_row < 1) return fail(TS2D_ERR_INVALID, "row slice %d: floats_per_row must be >= 1", r);
+        if (!(a->rows[r].bias2_sqrt > 0.0f)) return fail(TS2D_ERR_INVALID, "row slice %d: bias2_sqrt must be positive (step >= 1)", r);
+    }
     hipStream_t st = (hipStream_t)stream;
     ProfScope ps("adam_step_sh_factored", st);
     TS_HIP(ts_optim_adam_step_sh_factored(*a, beta1, beta2, eps, st));

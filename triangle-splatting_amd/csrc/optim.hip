@@ -218,6 +218,48 @@ __global__ void __launch_bounds__(256) adam_sh_factored_vec4_kernel(const ShFact
         *M_ = make_float4(m[0], m[1], m[2], m[3]);
         *V_ = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
+    // the other per-triangle parameters of these 64 triangles, from their dense gradients (the barrier above lies between this workgroup's reads of
+    // its vertices and these writes; no other workgroup looks at them)
+    for (int r = 0; r < a.num_rows; r++)
+    {
+        const tso_row_slice &rs = a.rows[r];
+        const int64_t f0 = i0 * rs.floats_per_row;
+        const int nf = (int)(left < 64 ? left : 64) * rs.floats_per_row;
+        const bool vec = (((size_t)rs.param | (size_t)rs.grad | (size_t)rs.exp_avg | (size_t)rs.exp_avg_sq) & 15) == 0 && ((f0 & 3) == 0);
+        for (int e0 = 4 * (int)threadIdx.x; e0 < nf; e0 += 4 * 256)
+        {
+            const int cnt = nf - e0 < 4 ? nf - e0 : 4;
+            float p[4], g[4], m[4], vv[4];
+            if (vec && cnt == 4)
+            {
+                const float4 P4 = *(const float4 *)(rs.param + f0 + e0), G4 = *(const float4 *)(rs.grad + f0 + e0), M4 = *(const float4 *)(rs.exp_avg + f0 + e0),
+                             V4 = *(const float4 *)(rs.exp_avg_sq + f0 + e0);
+                p[0] = P4.x; p[1] = P4.y; p[2] = P4.z; p[3] = P4.w; g[0] = G4.x; g[1] = G4.y; g[2] = G4.z; g[3] = G4.w;
+                m[0] = M4.x; m[1] = M4.y; m[2] = M4.z; m[3] = M4.w; vv[0] = V4.x; vv[1] = V4.y; vv[2] = V4.z; vv[3] = V4.w;
+            }
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (j < cnt) { p[j] = rs.param[f0 + e0 + j]; g[j] = rs.grad[f0 + e0 + j]; m[j] = rs.exp_avg[f0 + e0 + j]; vv[j] = rs.exp_avg_sq[f0 + e0 + j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (j < cnt) adam_element(p[j], g[j], m[j], vv[j], co, rs.step_size, rs.bias2_sqrt, rs.grad_scale);
+            if (vec && cnt == 4)
+            {
+                *(float4 *)(rs.param + f0 + e0) = make_float4(p[0], p[1], p[2], p[3]);
+                *(float4 *)(rs.exp_avg + f0 + e0) = make_float4(m[0], m[1], m[2], m[3]);
+                *(float4 *)(rs.exp_avg_sq + f0 + e0) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            }
+            else
+            {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (j < cnt) { rs.param[f0 + e0 + j] = p[j]; rs.exp_avg[f0 + e0 + j] = m[j]; rs.exp_avg_sq[f0 + e0 + j] = vv[j]; }
+            }
+        }
+    }
 }
 } // namespace
 
@@ -235,6 +277,7 @@ hipError_t ts_optim_adam_step_sh_factored(const tso_sh_factored_step &a, double 
         else hipLaunchKernelGGL(adam_sh_factored_vec4_kernel<3>, grid4, dim3(256), 0, s, t);
         return hipGetLastError();
     }
+    t.a.num_rows = 0; // the per-coefficient kernel below does not take them: a launch of the dense kernel behind it (same results)
     const int64_t threads = (int64_t)a.P * a.M;
     const dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     switch (a.M)
@@ -245,7 +288,19 @@ hipError_t ts_optim_adam_step_sh_factored(const tso_sh_factored_step &a, double 
     case 16: hipLaunchKernelGGL(adam_sh_factored_kernel<3>, grid, block, 0, s, t); break;
     default: return hipErrorInvalidValue;
     }
-    return hipGetLastError();
+    if (hipError_t e = hipGetLastError()) return e;
+    if (a.num_rows > 0)
+    {
+        tso_adam_slice sl[TSO_SH_ROW_SLICES] = {};
+        for (int r = 0; r < a.num_rows; r++)
+        {
+            sl[r].param = a.rows[r].param; sl[r].grad = a.rows[r].grad; sl[r].exp_avg = a.rows[r].exp_avg; sl[r].exp_avg_sq = a.rows[r].exp_avg_sq;
+            sl[r].count = (int64_t)a.P * a.rows[r].floats_per_row;
+            sl[r].step_size = a.rows[r].step_size; sl[r].bias2_sqrt = a.rows[r].bias2_sqrt; sl[r].grad_scale = a.rows[r].grad_scale;
+        }
+        return ts_optim_adam_step(sl, a.num_rows, beta1, beta2, eps, s);
+    }
+    return hipSuccess;
 }
 
 hipError_t ts_optim_adam_step(const tso_adam_slice *slices, int n, double beta1, double beta2, double eps, hipStream_t s)

@@ -40,11 +40,20 @@ _lib.tso_adam_step.restype = C.c_int
 _lib.tso_adam_step.argtypes = [C.POINTER(_Slice), C.c_int32, C.c_double, C.c_double, C.c_double, _fp]
 
 
+class _RowSlice(C.Structure):  # tso_row_slice, include/ts_optim.h
+    _fields_ = [("param", _fp), ("grad", _fp), ("exp_avg", _fp), ("exp_avg_sq", _fp), ("floats_per_row", C.c_int32), ("step_size", C.c_float),
+                ("bias2_sqrt", C.c_float), ("grad_scale", C.c_float)]
+
+
+SH_ROW_SLICES = 2  # TSO_SH_ROW_SLICES
+
+
 class _ShFactoredStep(C.Structure):  # tso_sh_factored_step, include/ts_optim.h
     _fields_ = [("P", C.c_int32), ("M", C.c_int32), ("sh_degree", C.c_int32), ("V", C.c_int32), ("vertex", _fp), ("campos", _fp), ("dL_dcolor", _fp),
                 ("param_dc", _fp), ("exp_avg_dc", _fp), ("exp_avg_sq_dc", _fp), ("param_rest", _fp), ("exp_avg_rest", _fp), ("exp_avg_sq_rest", _fp),
                 ("dc_stride", C.c_int64), ("rest_stride", C.c_int64), ("step_size_dc", C.c_float), ("bias2_sqrt_dc", C.c_float),
-                ("step_size_rest", C.c_float), ("bias2_sqrt_rest", C.c_float), ("grad_scale", C.c_float)]
+                ("step_size_rest", C.c_float), ("bias2_sqrt_rest", C.c_float), ("grad_scale", C.c_float), ("num_rows", C.c_int32),
+                ("rows", _RowSlice * SH_ROW_SLICES)]
 
 
 _lib.tso_adam_step_sh_factored.restype = C.c_int
@@ -179,10 +188,26 @@ class FusedAdam(torch.optim.Optimizer):
                                   f.f_dc.data_ptr(), states[0]["exp_avg"].data_ptr(), states[0]["exp_avg_sq"].data_ptr(),
                                   f.f_rest.data_ptr() if M > 1 else None, states[1]["exp_avg"].data_ptr() if M > 1 else None,
                                   states[1]["exp_avg_sq"].data_ptr() if M > 1 else None, 3, 3 * (M - 1), s_dc, b_dc, s_rest, b_rest, f.grad_scale)
+        # the other per-triangle parameters of this optimizer (the vertices, the opacities) ride along: same launch, from their dense gradients
+        # (include/ts_optim.h: tso_row_slice); step() then has nothing left for them
+        fused = []
+        for group in self.param_groups:
+            if group["betas"] != betas or group["eps"] != eps or group.get("tail_period"):
+                continue
+            for q in group["params"]:
+                if (len(fused) < SH_ROW_SLICES and all(q is not t for t in tensors) and q.grad is not None and not q.grad.is_sparse and q.dim() >= 1
+                        and q.shape[0] == P and q.numel() > 0 and q.is_cuda and q.dtype == torch.float32 and q.is_contiguous() and q.grad.is_contiguous()):
+                    st = self._moments(q)
+                    ss, bs = _corrections(group["lr"], st["step"], *betas)
+                    fused.append((q, _RowSlice(q.data_ptr(), q.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), q.numel() // P, ss, bs, 1.0)))
+        row.num_rows = len(fused)
+        for k, (_, rs) in enumerate(fused):
+            row.rows[k] = rs
         with torch.cuda.device(dev):
             _native._check(_lib.tso_adam_step_sh_factored(C.byref(row), betas[0], betas[1], eps, torch.cuda.current_stream().cuda_stream),
                            "adam_step_sh_factored")
         sink.clear()
+        return [q for q, _ in fused]
 
     @torch.no_grad()
     def step(self, closure=None, sh_factors: Optional[ShFactors] = None):
@@ -190,13 +215,14 @@ class FusedAdam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        done = ()
         if sh_factors is not None:
-            self._step_sh_factored(sh_factors)  # FIRST: it reads the vertices the backward ran on, the launch below updates them
+            done = self._step_sh_factored(sh_factors)  # FIRST: it reads the vertices the backward ran on (and steps them itself, see there)
         by_hyper: Dict[Tuple[float, float, float, torch.device], List[dict]] = {}
         for group in self.param_groups:
             beta1, beta2 = group["betas"]
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or any(p is q for q in done):
                     continue
                 if p.grad.is_sparse:
                     raise RuntimeError("Adam does not support sparse gradients")
