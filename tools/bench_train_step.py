@@ -163,11 +163,20 @@ def main():
     lib_ms = sum(ms * launches.get(n, 1) for n, ms in rows.items())
     raster_lib_ms = sum(ms for n, ms in rows.items() if n in raster_names)
 
+    # the eager loop WITHOUT the host's wait for the instance count (diff_triangle_rasterization_2D.set_instance_capacity: the sync-free forward, the
+    # binning state sized from what this scene rendered x 1.3; overflow is reported through forward_overflowed()): the host runs ahead of the GPU
+    pkg2d.set_instance_capacity(int(1.3 * node_n) + 4096)
+    timed(iteration, 30)
+    eager_sync_free_ms = timed(iteration, a.iters)
+    sync_free_overflowed = bool(pkg2d.forward_overflowed()[0])
+    pkg2d.set_instance_capacity(None)
+
     def emit(graph_ms, graph_err):
         it = graph_ms if graph_ms else eager_ms
         line = {"config": a.config, "workload": f"P={c.P}, camera {c.w}x{c.h}, render_up_scale {c.up} (raster {W}x{H}), {c.rast}, SH degree {c.D}, gamma {c.gamma:g}, "
                                                  f"L1 + SSIM{' + %.2f x depth/normal' % c.w_geo if c.w_geo else ''}, FusedAdam{'' if a.dense_adam else ' (colours from the factored gradient)'}, statistics",
-                "iteration_ms_eager": round(eager_ms, 4), "iteration_ms_graph": None if graph_ms is None else round(graph_ms, 4), "graph_note": graph_err,
+                "iteration_ms_eager": round(eager_ms, 4), "iteration_ms_eager_sync_free": round(eager_sync_free_ms, 4), "sync_free_overflowed": sync_free_overflowed,
+                "iteration_ms_graph": None if graph_ms is None else round(graph_ms, 4), "graph_note": graph_err,
                 "raster_step_ms": round(raster_ms, 4), "iteration_minus_raster_ms": round(it - raster_ms, 4),
                 "library_kernels_ms_per_iteration": round(lib_ms, 4), "of_which_rasterizer": round(raster_lib_ms, 4),
                 "torch_glue_ms_per_iteration": round(max(it - lib_ms, 0.0), 4), "kernels": table}

@@ -61,7 +61,7 @@ import json,sys
 for l in sys.stdin:
     if not l.startswith('{'): continue
     j=json.loads(l); k=j['kernels']
-    print(j['config'], 'eager', j['iteration_ms_eager'], 'graph', j['iteration_ms_graph'], j['graph_note'] or '', 'raster', j['raster_step_ms'], 'diff', j['iteration_minus_raster_ms'], 'glue', j['torch_glue_ms_per_iteration'])
+    print(j['config'], 'eager', j['iteration_ms_eager'], 'eager_sync_free', j.get('iteration_ms_eager_sync_free'), 'graph', j['iteration_ms_graph'], j['graph_note'] or '', 'raster', j['raster_step_ms'], 'diff', j['iteration_minus_raster_ms'], 'glue', j['torch_glue_ms_per_iteration'])
     print('   ', ' '.join('%s=%.4f(%s)' % (n, e['avg_ms'], e.get('hbm_frac','-')) for n,e in k.items() if n not in ('depth_census','depth_sort','scan','emit_keys','tile_sort','tile_ranges')))"; }
 # loss [H W]: tools/bench_loss.py (the fused L1 + SSIM against the eager-torch kernel sequence)
 loss() { timeout 600 python tools/bench_loss.py "$@" 2>/dev/null | tee -a $O/loss_bench.jsonl; }
