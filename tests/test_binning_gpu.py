@@ -181,3 +181,37 @@ def test_radix_select_quantile_equals_torch_quantile(n):
             assert L.ts2d_test_quantile(x.data_ptr(), n, q, scratch.data_ptr(), out.data_ptr(), stream) == 0
             got = float(out)
             assert got == want or abs(got - want) <= 2e-7 * abs(want), (name, q, got, want)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_depth_order_of_random_scenes_is_the_stable_sort_of_the_depth_keys(seed):
+    """The product's three depth-order forms by size -- one launch up to 12 288 triangles, sampled splitters + per-bucket sorts to 500 000, LSD passes
+    beyond -- on random sizes around their switch-overs and random depth layouts (plain, quantised to a few values, a far cluster, depths over several
+    octaves, a share of culled triangles): the permutation must be numpy's STABLE argsort of the depth keys (bit patterns of the view-space depth, 0
+    for culled triangles: rasterizer.cu:211's SortPairs is stable), and the instance offsets its inclusive scan of the tile counts in that order."""
+    rng = np.random.default_rng(1000 + seed)
+    P = int([rng.integers(2, 12288), rng.integers(12289, 40000), rng.integers(40000, 300000), rng.integers(300000, 500001),
+             rng.integers(500001, 700000), 12288, 12289, 500000, 500001][seed % 9])
+    s = synthetic.scene(P, 256, 160, 0, seed=int(rng.integers(1 << 30)))
+    v = s["vertex"]
+    kind = ["plain", "quantised", "far", "octaves", "culled", "one_depth"][seed % 6]
+    zc = v[:, :, 2].mean(axis=1, keepdims=True)
+    if kind == "quantised":
+        v[:, :, 2] = np.round(zc / 15.0) * 15.0
+    elif kind == "far":
+        v[: max(1, P // 40), :, 2] -= 20000.0
+    elif kind == "octaves":
+        scale = np.exp2(rng.uniform(-3.0, 0.0, size=(P, 1))).astype(np.float32)
+        v[:, :, 2] = s["campos"][2] + (v[:, :, 2] - s["campos"][2]) * scale
+    elif kind == "culled":
+        v[rng.random(P) < 0.3, :, 2] += 5000.0
+    elif kind == "one_depth":
+        v[: P // 2, :, 2] = zc[: P // 2].mean()
+    hf = helpers.hip_forward_backward(s, True, backward=False)
+    keys = helpers.hip_state(hf, s, "depth").view(np.uint32)
+    perm = helpers.hip_state(hf, s, "depth_perm")
+    want = np.argsort(keys, kind="stable")
+    assert np.array_equal(perm.astype(np.int64), want), (P, kind)
+    tiles = helpers.hip_state(hf, s, "tiles_touched").astype(np.int64)
+    assert np.array_equal(helpers.hip_state(hf, s, "point_offsets").astype(np.int64), np.cumsum(tiles[want])), (P, kind)
+    assert int(hf["num_rendered"]) == int(tiles.sum())
