@@ -50,8 +50,17 @@ __global__ void __launch_bounds__(256) preprocess_fwd_direct_kernel(PreprocessAr
 // the lane's registers with SHROW / 4 dwordx4 loads (SH_REGS = true).  Both read the rows at the same rate in isolation
 // (tools/sh_stage_bench.hip: 5.5-5.7 TB/s), but 12.5 KB of LDS per single-wave workgroup held the kernel at 2 waves per SIMD with
 // 73 % of the wave cycles spent waiting (profiles/r02_notes.md); without it the registers are the only limit.
+#ifndef TS_PRE_FWD_WAVES // register budget of the staged forward kernel in waves per SIMD (0: the compiler's choice, 105 registers = 4 waves at SH degree 3:
+                         // 72.3 us at 1 M triangles; round 6, variant builds alternating on one box: 5 waves / 96 registers 76.5 us, 6 waves / 80 registers 139 us)
+#define TS_PRE_FWD_WAVES 0
+#endif
 template <class Body, int SHROW, bool SH_REGS, int MODE>
-__global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
+#if TS_PRE_FWD_WAVES > 0
+__global__ void __launch_bounds__(64, TS_PRE_FWD_WAVES) preprocess_fwd_staged_kernel(
+#else
+__global__ void __launch_bounds__(64) preprocess_fwd_staged_kernel(
+#endif
+    PreprocessArgs a, int32_t *__restrict__ radii, GeometryStateView g)
 {
     __shared__ float s_v[64 * 9];
     __shared__ float s_sh[(SHROW > 0 && !SH_REGS) ? 64 * (SHROW + 1) : 1];
