@@ -1201,7 +1201,6 @@ struct DepthSplit
     uint32_t *bucket_start;        // 256 words
     unsigned long long *chunk_sum; // per chunk: sum of tiles_touched
     uint8_t *digit;                // P bytes (lives in sv[1] until K3 overwrites it)
-    uint32_t *ticket;              // zero between steps
 };
 __host__ __device__ inline DepthSplit depth_split_of(const GeometryStateView &g)
 {
@@ -1211,7 +1210,6 @@ __host__ __device__ inline DepthSplit depth_split_of(const GeometryStateView &g)
     d.bucket_start = g.offsets + NB;
     d.chunk_sum = (unsigned long long *)(g.offsets + 1024);
     d.digit = (uint8_t *)g.sv[1];
-    d.ticket = g.rs.tickets + g.rs.slabs + 5; // TS_RS_TICKET_EXTRA words behind the slab tickets: [4] = top_const, [5] = this
     return d;
 }
 
