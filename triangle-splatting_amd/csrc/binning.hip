@@ -1165,7 +1165,8 @@ __global__ void __launch_bounds__(64 * DS_WAVES) depth_order_small_kernel(int P,
 // Above TS_DEPTH_SMALL_MAX triangles the LSD sort above is eight dependent launches (census histogram, four scatters, three histograms; the fourth
 // pair returns at once on most scenes) + the launch of the block sums: 57 us for 0.7 MB of pairs at 93 k triangles, 59 at 300 k, 75 at 1 M --
 // launch and load -> LDS -> store latency, not bytes.  Four launches instead:
-//   K0  depth_split_sample_kernel   4096 keys taken at equal index strides; workgroup b finds splitter b (the sample of rank 16 b + 15) by a radix select.
+//   K0  depth_split_sample_kernel   4096 keys taken at equal index strides (1024 below 150 k triangles: -2 us, and the buckets are small against K3's capacity
+//                                   whatever their balance); workgroup b finds splitter b (the sample of rank 16 b + 15) by a radix select.
 //                                   (Splitters from a SAMPLE, not from the key range: the buckets hold P / 256 +- 25 % pairs whatever the depth
 //                                   distribution is -- a far background, an object that fills one octave -- where equal slices of the bit range
 //                                   would put most of the scene into a few of them.)
@@ -1189,7 +1190,7 @@ __global__ void __launch_bounds__(64 * DS_WAVES) depth_order_small_kernel(int P,
 #endif
 constexpr int TS_DEPTH_SPLIT_MAX = TS_DEPTH_SPLIT_MAX_VALUE; // the product's switch-over: measured level with the LSD passes at 1 M triangles, ahead below
 constexpr int TS_DEPTH_SPLIT_HARD_MAX = 1600000; // what the form supports (buckets of P / 256 pairs on average against DB_CAP = 16384): lab library, mode 2
-constexpr int DSPL_SAMPLES = 4096, DSPL_PER = DSPL_SAMPLES / NB;
+constexpr int DSPL_SAMPLES = 4096, DSPL_SAMPLES_SMALL = 1024, DSPL_SMALL_BELOW = 150000; // below: P / 256 < 600 pairs per bucket against K3's 4096
 constexpr int DB_WAVES = 16, DB_KB = 16, DB_CAP = 64 * DB_WAVES * DB_KB; // the large form of depth_bucket_sort_kernel
 constexpr int DB_SMALL_WAVES = 4, DB_SMALL_BELOW = 300000; // below: buckets of P / 256 < 1200 pairs on average against 4096
 int g_depth_split_mode = 0; // lab library: 0 = by size, 1 = never (the LSD passes), 2 = up to TS_DEPTH_SPLIT_HARD_MAX
@@ -1223,8 +1224,10 @@ __device__ __forceinline__ uint32_t depth_key_restore(uint32_t adj, uint32_t kmi
 // workgroups on an otherwise idle chip.  The select runs on (sample - smallest sample) and only over the bytes the samples' range needs: depth keys
 // share their top bytes, and a pass on a byte that every sample shares is 4096 atomic adds on ONE LDS word (the same select over all four bytes
 // of the raw keys: 12 us; one workgroup sorting the samples with a bitonic network: 13; eight workgroups ranking them by counting: 53).
+template <int SAMPLES> // 4096, or 1024 for scenes whose buckets are small against K3's capacity whatever their balance
 __global__ void __launch_bounds__(256) depth_split_sample_kernel(int P, GeometryStateView g, DepthSplit ds)
 {
+    constexpr int DSPL_SAMPLES = SAMPLES, DSPL_PER = SAMPLES / NB;
     __shared__ uint32_t hist[NB], wtot[4], pick[2], rmin[4], rmax[4];
     constexpr int K = DSPL_SAMPLES / 256;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1762,7 +1765,8 @@ void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long
     {
         const DepthSplit ds = depth_split_of(g);
         const dim3 grid((unsigned)g.rs.chunks);
-        hipLaunchKernelGGL(depth_split_sample_kernel, dim3(NB - 1), dim3(256), 0, s, P, g, ds);
+        if (P < DSPL_SMALL_BELOW) hipLaunchKernelGGL(depth_split_sample_kernel<DSPL_SAMPLES_SMALL>, dim3(NB - 1), dim3(256), 0, s, P, g, ds);
+        else hipLaunchKernelGGL(depth_split_sample_kernel<DSPL_SAMPLES>, dim3(NB - 1), dim3(256), 0, s, P, g, ds);
         TS_WITH_CHUNK(g.rs.chunk,
                       hipLaunchKernelGGL((depth_split_hist_kernel<CH>), grid, dim3(256), 0, s, (int64_t)P, g, g.rs, g.rs.slabacc[0], ds);
                       hipLaunchKernelGGL((depth_split_scatter_kernel<CH>), grid, dim3(256), 0, s, (int64_t)P, g, g.rs, (const uint32_t *)g.rs.slabacc[0], ds, host_out))
