@@ -28,7 +28,8 @@ if os.environ.get("LAB_DEPTH_ORDER") == "1":
     # the instance offsets (= block sums + scan), the instance count and the sorted instance list must be IDENTICAL.
     from diff_triangle_rasterization_2D import _C
     _C._lib.ts2d_lab_force_depth_pass4.argtypes = [__import__("ctypes").c_int]
-    for P, culled in [(1, False), (63, False), (64, False), (65, False), (1023, False), (12287, False), (12288, False), (12289, False), (700, True), (12288, True)]:
+    # (round 6: the one-launch form is used up to 9 216 triangles, the sampled-splitter form above: the sizes straddle both switch-overs)
+    for P, culled in [(1, False), (63, False), (64, False), (65, False), (1023, False), (9215, False), (9216, False), (9217, False), (12288, False), (12289, False), (700, True), (9216, True)]:
         s = synthetic.scene(P, 160, 96, 1, seed=500 + P)
         if culled:
             s["vertex"][:, :, 2] += 5000.0  # every triangle behind the camera: all culled, zero instances

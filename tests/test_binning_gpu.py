@@ -185,13 +185,13 @@ def test_radix_select_quantile_equals_torch_quantile(n):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_depth_order_of_random_scenes_is_the_stable_sort_of_the_depth_keys(seed):
-    """The product's three depth-order forms by size -- one launch up to 12 288 triangles, sampled splitters + per-bucket sorts to 500 000, LSD passes
+    """The product's three depth-order forms by size -- one launch up to 9 216 triangles, sampled splitters + per-bucket sorts to 500 000, LSD passes
     beyond -- on random sizes around their switch-overs and random depth layouts (plain, quantised to a few values, a far cluster, depths over several
     octaves, a share of culled triangles): the permutation must be numpy's STABLE argsort of the depth keys (bit patterns of the view-space depth, 0
     for culled triangles: rasterizer.cu:211's SortPairs is stable), and the instance offsets its inclusive scan of the tile counts in that order."""
     rng = np.random.default_rng(1000 + seed)
-    P = int([rng.integers(2, 12288), rng.integers(12289, 40000), rng.integers(40000, 300000), rng.integers(300000, 500001),
-             rng.integers(500001, 700000), 12288, 12289, 500000, 500001][seed % 9])
+    P = int([rng.integers(2, 9216), rng.integers(9217, 40000), rng.integers(40000, 300000), rng.integers(300000, 500001),
+             rng.integers(500001, 700000), 9216, 9217, 500000, 500001][seed % 9])
     s = synthetic.scene(P, 256, 160, 0, seed=int(rng.integers(1 << 30)))
     v = s["vertex"]
     kind = ["plain", "quantised", "far", "octaves", "culled", "one_depth"][seed % 6]

@@ -279,7 +279,7 @@ def test_one_launch_depth_order_equals_the_multi_launch_forms():
                        text=True, timeout=400)
     assert r.returncode == 0, r.stderr[-2000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("LAB_RESULT ")][-1][len("LAB_RESULT "):])
-    assert len(res) == 10
+    assert len(res) == 12
     for case in res:
         assert case["multi_launch"] == 0.0 and case["tickets"] == 0.0, case
         assert (case["num_rendered"] == 0) == case["culled"], case

@@ -1008,7 +1008,7 @@ __global__ void zero_words_kernel(uint32_t *p, size_t n) // 64-bit count and ind
 // them through LDS after every pass, and then does what the census, publish_census and gather_blocksum_kernel do: N to the device word and
 // the pinned host word, tiles_sorted, the raw block sums.  Same passes (the fourth skipped under the same condition), same stable order,
 // so sv[1] holds exactly the ids the multi-launch path leaves in sorted_ids(); top_const stays 0 (the order is always in sk[1] / sv[1]).
-constexpr int TS_DEPTH_SMALL_MAX = 12288; // level with the multi-launch path (1024-pair chunks) at ~12 k triangles: 34 us either way
+constexpr int TS_DEPTH_SMALL_MAX = 12288; // the kernel's capacity (level with the LSD passes of 1024-pair chunks at ~12 k triangles: 34 us either way); used up to TS_DEPTH_SMALL_USE
 constexpr int DS_WAVES = 16, DS_KB = TS_DEPTH_SMALL_MAX / (64 * DS_WAVES);
 // The one-launch form lives on gfx950's 160 KB of LDS per workgroup (two stages of TS_DEPTH_SMALL_MAX words + the per-wave digit table): 64 KB
 // parts cannot hold it, and nothing else in the library may quietly push it over
@@ -1745,12 +1745,17 @@ __global__ void __launch_bounds__(64 * W) depth_bucket_sort_kernel(int P, Geomet
 // as well when given) and the key-bit census: the first histogram, and on the ticket-free path the first scatter too; `finish` = the other
 // launches (the 4th pass returns at once when the census found the top byte constant: then sk[0] / sv[0] hold the order).
 // The one-launch form (depth_order_small_kernel) -- never under the lab library's switches, which exist to run the multi-launch forms on small scenes.
-static bool depth_small_ok(int32_t P) { return P <= TS_DEPTH_SMALL_MAX && !g_force_tickets && !g_force_pass4; }
+#ifndef TS_DEPTH_SMALL_USE_VALUE // up to how many triangles the one-launch form is USED (<= its capacity TS_DEPTH_SMALL_MAX)
+#define TS_DEPTH_SMALL_USE_VALUE 9216 // measured against the split form (variant builds, 256 x 256, graph replay): 3 k 17 vs 30 us, 5 k 22 vs 30, 10 k 32 vs 30 (step 0.133 -> 0.128 ms)
+#endif
+constexpr int TS_DEPTH_SMALL_USE = TS_DEPTH_SMALL_USE_VALUE;
+static_assert(TS_DEPTH_SMALL_USE <= TS_DEPTH_SMALL_MAX && TS_DEPTH_SMALL_USE >= 2048, "the split form's scratch needs 1024 + 2 chunks words of `offsets`");
+static bool depth_small_ok(int32_t P) { return P <= TS_DEPTH_SMALL_USE && !g_force_tickets && !g_force_pass4; }
 // The sampled-splitter form: every size between the one-launch form and TS_DEPTH_SPLIT_MAX whose scratch takes the ticket-free passes; never under the
 // lab library's switches that ask for the LSD forms.
 static bool depth_split_ok(int32_t P, const RadixScratchView &r)
 {
-    return P > TS_DEPTH_SMALL_MAX && P <= (g_depth_split_mode == 2 ? TS_DEPTH_SPLIT_HARD_MAX : TS_DEPTH_SPLIT_MAX) && g_depth_split_mode != 1 && !g_force_tickets &&
+    return P > TS_DEPTH_SMALL_USE && P <= (g_depth_split_mode == 2 ? TS_DEPTH_SPLIT_HARD_MAX : TS_DEPTH_SPLIT_MAX) && g_depth_split_mode != 1 && !g_force_tickets &&
            !g_force_pass4 && radix_direct_ok(r);
 }
 void ts_sort_by_depth_begin(const GeometryStateView &g, int32_t P, unsigned long long *host_out, hipStream_t s)
