@@ -1192,7 +1192,10 @@ constexpr int TS_DEPTH_SPLIT_MAX = TS_DEPTH_SPLIT_MAX_VALUE; // the product's sw
 constexpr int TS_DEPTH_SPLIT_HARD_MAX = 1600000; // what the form supports (buckets of P / 256 pairs on average against DB_CAP = 16384): lab library, mode 2
 constexpr int DSPL_SAMPLES = 4096, DSPL_SAMPLES_SMALL = 1024, DSPL_SMALL_BELOW = 150000; // below: P / 256 < 600 pairs per bucket against K3's 4096
 constexpr int DB_WAVES = 16, DB_KB = 16, DB_CAP = 64 * DB_WAVES * DB_KB; // the large form of depth_bucket_sort_kernel
-constexpr int DB_SMALL_WAVES = 4, DB_SMALL_BELOW = 300000; // below: buckets of P / 256 < 1200 pairs on average against 4096
+#ifndef TS_DB_SMALL_BELOW_VALUE
+#define TS_DB_SMALL_BELOW_VALUE 300000
+#endif
+constexpr int DB_SMALL_WAVES = 4, DB_SMALL_BELOW = TS_DB_SMALL_BELOW_VALUE; // below: buckets of P / 256 < 1200 pairs on average against 4096
 int g_depth_split_mode = 0; // lab library: 0 = by size, 1 = never (the LSD passes), 2 = up to TS_DEPTH_SPLIT_HARD_MAX
 int g_depth_bucket_cap = DB_CAP; // lab library: a smaller register capacity sends ordinary buckets through K3's global-memory path
 
